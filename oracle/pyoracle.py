@@ -1,0 +1,227 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.
+
+ctypes front end of ``oracle/liboracle.so`` (the CPU restatement of the reference's
+``src/registration.cpp`` / ``src/pipeline.cpp`` arithmetic; see ``oracle.cpp``).
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module, and only as the checker / the reported CPU baseline.  The product
+(``3dvision_amd``) never imports it.
+
+Conventions: clouds are ``float32 [n,3]`` C-contiguous; FPFH ``float32 [n,33]``;
+4x4 transforms cross this API as ordinary ``[4,4]`` numpy matrices (row = row) and are
+converted to/from the column-major ``float[16]`` of ``Eigen::Matrix4f::data()`` here.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    """Compile the oracle (g++).  Building the checker is not using it."""
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_unproject.restype = C.c_int
+        _LIB.orc_count_nonzero.restype = C.c_int
+        _LIB.orc_demo_model.restype = C.c_int
+        _LIB.orc_voxel_downsample.restype = C.c_int
+        _LIB.orc_self_adjoint_eig3.restype = C.c_int
+        _LIB.orc_icp.restype = C.c_int
+    return _LIB
+
+
+def _p(a, t=C.c_void_p):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def to_colmajor16(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T).reshape(16)
+
+
+def from_colmajor16(t):
+    return np.asarray(t, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+# ----------------------------------------------------------------- solvers
+def jacobi_svd3(A):
+    A = np.asarray(A, np.float32)
+    a = np.ascontiguousarray(A.T).reshape(9)
+    U = np.zeros(9, np.float32); S = np.zeros(3, np.float32); V = np.zeros(9, np.float32)
+    lib().orc_jacobi_svd3(_p(a), _p(U), _p(S), _p(V))
+    return U.reshape(3, 3).T.copy(), S, V.reshape(3, 3).T.copy()
+
+
+def kabsch_rotation(H):
+    h = np.ascontiguousarray(np.asarray(H, np.float32).T).reshape(9)
+    R = np.zeros(9, np.float32)
+    lib().orc_kabsch_rotation(_p(h), _p(R))
+    return R.reshape(3, 3).T.copy()
+
+
+def self_adjoint_eig3(A):
+    a = np.ascontiguousarray(np.asarray(A, np.float32).T).reshape(9)
+    w = np.zeros(3, np.float32); V = np.zeros(9, np.float32)
+    rc = lib().orc_self_adjoint_eig3(_p(a), _p(w), _p(V))
+    return w, V.reshape(3, 3).T.copy(), rc
+
+
+def ldlt6_solve(A, b):
+    a = _f32(np.asarray(A).reshape(36)); bb = _f32(b); x = np.zeros(6, np.float32)
+    lib().orc_ldlt6_solve(_p(a), _p(bb), _p(x))
+    return x
+
+
+def euler_xyz_matrix(a, b, g):
+    R = np.zeros(9, np.float32)
+    lib().orc_euler_xyz_matrix(C.c_float(a), C.c_float(b), C.c_float(g), _p(R))
+    return R.reshape(3, 3).T.copy()
+
+
+def hypothesis_from_pairs(s3, t3):
+    s = _f32(s3).reshape(9); t = _f32(t3).reshape(9); T = np.zeros(16, np.float32)
+    lib().orc_hypothesis_from_pairs(_p(s), _p(t), _p(T))
+    return from_colmajor16(T)
+
+
+# ----------------------------------------------------------------- depth / unproject
+def depth_preprocess(raw, mask, scale):
+    raw = np.ascontiguousarray(raw, np.uint16)
+    h, w = raw.shape
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    out = np.empty((h, w), np.float32)
+    lib().orc_depth_preprocess(_p(raw), _p(m), w, h, C.c_float(scale), _p(out))
+    return out
+
+
+def unproject(depth, bgr, fx, fy, cx, cy, clipping_max):
+    depth = _f32(depth)
+    h, w = depth.shape
+    b = None if bgr is None else np.ascontiguousarray(bgr, np.uint8)
+    xyz = np.empty((h * w, 3), np.float32)
+    rgb = np.empty((h * w, 3), np.float32) if b is not None else None
+    n = lib().orc_unproject(_p(depth), _p(b), w, h, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                            C.c_float(clipping_max), _p(xyz), _p(rgb))
+    return xyz[:n].copy(), (None if rgb is None else rgb[:n].copy())
+
+
+def demo_scene(w=1280, h=720, scale=1000.0):
+    depth = np.empty((h, w), np.uint16); bgr = np.empty((h, w, 3), np.uint8)
+    lib().orc_demo_scene(w, h, C.c_float(scale), _p(depth), _p(bgr))
+    return depth, bgr
+
+
+def demo_mask(w=1280, h=720):
+    m = np.empty((h, w), np.uint8)
+    lib().orc_demo_mask(w, h, _p(m))
+    return m
+
+
+def demo_model():
+    n = lib().orc_demo_model(None, None, 0)
+    xyz = np.empty((n, 3), np.float32); nrm = np.empty((n, 3), np.float32)
+    lib().orc_demo_model(_p(xyz), _p(nrm), n)
+    return xyz, nrm
+
+
+# ----------------------------------------------------------------- registration ops
+def voxel_downsample(xyz, rgb, voxel):
+    xyz = _f32(xyz); rgb = _f32(rgb)
+    n = len(xyz)
+    oxyz = np.empty((n, 3), np.float32)
+    orgb = np.empty((n, 3), np.float32) if rgb is not None else None
+    first = np.empty(n, np.int32)
+    m = lib().orc_voxel_downsample(_p(xyz), _p(rgb), n, C.c_float(voxel), _p(oxyz), _p(orgb), _p(first), n)
+    return oxyz[:m].copy(), (None if orgb is None else orgb[:m].copy()), first[:m].copy()
+
+
+def estimate_normals(xyz, k=30, want_knn=False):
+    xyz = _f32(xyz); n = len(xyz)
+    nrm = np.empty((n, 3), np.float32)
+    knn = np.empty((n, k), np.int32) if want_knn else None
+    lib().orc_estimate_normals(_p(xyz), n, k, _p(nrm), _p(knn))
+    return (nrm, knn) if want_knn else nrm
+
+
+def compute_fpfh(xyz, normals, radius, want_neighbors=False):
+    xyz = _f32(xyz); normals = _f32(normals); n = len(xyz)
+    desc = np.empty((n, 33), np.float32)
+    nb = np.empty((n, 100), np.int32) if want_neighbors else None
+    cnt = np.empty(n, np.int32) if want_neighbors else None
+    lib().orc_compute_fpfh(_p(xyz), _p(normals), n, C.c_float(radius), _p(desc), _p(nb), _p(cnt))
+    return (desc, nb, cnt) if want_neighbors else desc
+
+
+def feature_match(fs, ft):
+    fs = _f32(fs); ft = _f32(ft)
+    corr = np.empty(len(fs), np.int32)
+    lib().orc_feature_match(_p(fs), len(fs), _p(ft), len(ft), _p(corr))
+    return corr
+
+
+def sample_triples(n, count, seed=42):
+    out = np.empty((count, 3), np.uint64)
+    lib().orc_sample_triples(C.c_uint32(seed), C.c_uint64(n), count, _p(out))
+    return out
+
+
+def ransac(src, tgt, fs=None, ft=None, corr=None, voxel=0.001, max_iterations=100000, confidence=0.999, trace=False):
+    src = _f32(src); tgt = _f32(tgt); fs = _f32(fs); ft = _f32(ft)
+    c = None if corr is None else np.ascontiguousarray(corr, np.int32)
+    T = np.zeros(16, np.float32); fit = C.c_float(); rmse = C.c_float()
+    tr = np.full(max_iterations, -2, np.int32) if trace else None
+    oc = np.empty(len(src), np.int32)
+    bi = C.c_int(); ir = C.c_int()
+    lib().orc_ransac(_p(src), len(src), _p(tgt), len(tgt), _p(fs), _p(ft), _p(c),
+                     C.c_float(voxel), max_iterations, C.c_float(confidence),
+                     _p(T), C.byref(fit), C.byref(rmse), _p(tr), _p(oc), C.byref(bi), C.byref(ir))
+    res = dict(T=from_colmajor16(T), fitness=np.float32(fit.value), rmse=np.float32(rmse.value),
+               corr=oc, best_iter=bi.value, iters_run=ir.value)
+    if trace:
+        res["inliers"] = tr
+    return res
+
+
+def icp_correspondences(src, tgt, tgt_normals, T, thr, point_to_plane=True):
+    src = _f32(src); tgt = _f32(tgt); tn = _f32(tgt_normals)
+    ns = len(src)
+    corr = np.empty(ns, np.int32); d2 = np.empty(ns, np.float32); acc = np.empty(ns, np.uint8)
+    nc = C.c_int(); te = C.c_float(); ATA = np.zeros(36, np.float32); ATb = np.zeros(6, np.float32)
+    t = to_colmajor16(T)
+    lib().orc_icp_correspondences(_p(src), ns, _p(tgt), _p(tn), len(tgt), _p(t), C.c_float(thr), int(point_to_plane),
+                                  _p(corr), _p(d2), _p(acc), C.byref(nc), C.byref(te), _p(ATA), _p(ATb))
+    return dict(corr=corr, d2=d2, accepted=acc.astype(bool), n_corr=nc.value, total_error=np.float32(te.value),
+                ATA=ATA.reshape(6, 6), ATb=ATb)
+
+
+def icp(src, tgt, tgt_normals, T0, thr, max_iterations=200, point_to_plane=True, trace=False):
+    src = _f32(src); tgt = _f32(tgt); tn = _f32(tgt_normals)
+    T = np.zeros(16, np.float32); fit = C.c_float(); rmse = C.c_float()
+    tr = np.zeros((max_iterations, 20), np.float32) if trace else None
+    t0 = to_colmajor16(T0)
+    it = lib().orc_icp(_p(src), len(src), _p(tgt), _p(tn), len(tgt), _p(t0), C.c_float(thr), max_iterations,
+                       int(point_to_plane), _p(T), C.byref(fit), C.byref(rmse), _p(tr))
+    res = dict(T=from_colmajor16(T), fitness=np.float32(fit.value), rmse=np.float32(rmse.value), iterations=it)
+    if trace:
+        res["trace"] = tr[:it]
+    return res
+
+
+def pose_compose(extrinsics, T):
+    e = to_colmajor16(extrinsics); t = to_colmajor16(T); o = np.zeros(16, np.float32)
+    lib().orc_pose_compose(_p(e), _p(t), _p(o))
+    return from_colmajor16(o)
