@@ -1,0 +1,439 @@
+"""3dvision_amd — MI355X (gfx950) point-cloud registration backend.
+
+Python front end over the C ABI of ``include/tdv_hip.h`` (``lib3dvision_hip.so``, hand-written
+HIP).  It mirrors the reference's operator API so that tests read like calls into the reference:
+
+    reference (C++, namespace industry_picking)           here
+    ------------------------------------------------      -----------------------------------
+    PointCloud / FPFHFeatures / RegistrationResult        PointCloud / ndarray[n,33] / RegistrationResult
+    GPUDepth::preprocess, ::isCudaAvailable               GPUDepth.preprocess, .isCudaAvailable
+    GPUPointCloud::generate                               GPUPointCloud.generate
+    GPURegistration::icpRefine                            GPURegistration.icpRefine
+    Registration::voxelDownsample / estimateNormals /     Registration.voxelDownsample / ...
+      computeFPFH / ransacRegistration / icpRefine
+
+(include/gpu_depth.hpp:9-22, include/gpu_registration.hpp:8-19, include/registration.hpp:10-60 of the
+reference).  The package directory name starts with a digit, so import it with
+``importlib.import_module("3dvision_amd")``.
+
+There is NO CPU fallback: every operator calls the HIP library and raises if the library or a GPU
+is missing (``isCudaAvailable()`` is the only call that answers without one).  4x4 transforms are
+ordinary row-major ``[4,4]`` numpy arrays at this level; the column-major ``float[16]`` of
+``Eigen::Matrix4f::data()`` is the ABI's layout and is converted here.
+"""
+import ctypes as C
+import os
+import threading
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib3dvision_hip.so")
+
+TDV_MASK_THRESHOLD10 = 0
+TDV_MASK_NONZERO = 1
+TDV_VOXEL_ORDER_FIRST = 0
+TDV_VOXEL_ORDER_REFERENCE = 1
+TIMER_ICP_NN, TIMER_RANSAC_SCORE, TIMER_FEATURE_MATCH, TIMER_KNN, TIMER_RADIUS, TIMER_DEPTH, TIMER_VOXEL = range(7)
+
+# every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
+ABI_SYMBOLS = [
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
+    "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
+    "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
+    "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
+    "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
+]
+
+
+class TdvError(RuntimeError):
+    pass
+
+
+class RansacResultC(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("fitness", C.c_float), ("rmse", C.c_float), ("inliers", C.c_int),
+                ("best_iteration", C.c_int), ("iterations_run", C.c_int)]
+
+
+class IcpResultC(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("fitness", C.c_float), ("rmse", C.c_float), ("iterations", C.c_int),
+                ("n_corr", C.c_int)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def build():
+    """Compile the HIP library in-tree (hipcc cross-compiles for gfx950 without a GPU)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tdv_build", os.path.join(_HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()
+
+
+def lib():
+    """The loaded C-ABI library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise TdvError("lib3dvision_hip.so is not built (%s). Run `python 3dvision_amd/build.py` or "
+                               "__graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+            l = C.CDLL(LIB_PATH)
+            l.tdv_status_string.restype = C.c_char_p
+            l.tdv_last_error.restype = C.c_char_p
+            l.tdv_version.restype = C.c_char_p
+            l.tdv_ctx_get_stream.restype = C.c_void_p
+            _lib = l
+    return _lib
+
+
+def _check(ctx, status, what):
+    if status != 0:
+        msg = lib().tdv_status_string(status).decode()
+        detail = lib().tdv_last_error(ctx).decode() if ctx else ""
+        raise TdvError("%s: %s (%d) %s" % (what, msg, status, detail))
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def to_colmajor16(T):
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).T).reshape(16)
+
+
+def from_colmajor16(t):
+    return np.array(t, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(None, lib().tdv_device_count(C.byref(n)), "tdv_device_count")
+    return n.value
+
+
+@dataclass
+class PointCloud:
+    """include/registration.hpp:10-19."""
+    points: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), np.float32))
+    normals: Optional[np.ndarray] = None
+    colors: Optional[np.ndarray] = None
+
+    def size(self):
+        return len(self.points)
+
+    def empty(self):
+        return len(self.points) == 0
+
+    def hasNormals(self):
+        return self.normals is not None and len(self.normals) == len(self.points)
+
+    def hasColors(self):
+        return self.colors is not None and len(self.colors) == len(self.points)
+
+
+@dataclass
+class RegistrationResult:
+    """include/registration.hpp:26-30 (+ diagnostics the ABI also returns)."""
+    transformation: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))
+    fitness: float = 0.0
+    rmse: float = 0.0
+    iterations: int = 0
+    inliers: int = 0
+    best_iteration: int = -1
+    iterations_run: int = 0
+    n_corr: int = 0
+    trace_inliers: Optional[np.ndarray] = None
+
+
+class Context:
+    """One tdv_ctx (stream + workspace).  Not thread-safe; one per host thread."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        _check(None, lib().tdv_ctx_create(int(device), C.byref(self._h)), "tdv_ctx_create")
+        self.device = device
+        if stream is not None:
+            _check(self._h, lib().tdv_ctx_set_stream(self._h, C.c_void_p(stream)), "tdv_ctx_set_stream")
+
+    def close(self):
+        if self._h:
+            lib().tdv_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return lib().tdv_ctx_get_stream(self._h)
+
+    def synchronize(self):
+        _check(self._h, lib().tdv_ctx_synchronize(self._h), "tdv_ctx_synchronize")
+
+    def timing_enable(self, on=True):
+        _check(self._h, lib().tdv_timing_enable(self._h, int(on)), "tdv_timing_enable")
+
+    def timing_read(self, slot):
+        ms = C.c_double(); n = C.c_int()
+        _check(self._h, lib().tdv_timing_read(self._h, slot, C.byref(ms), C.byref(n)), "tdv_timing_read")
+        return ms.value, n.value
+
+    # ---------------------------------------------------------------- R1 / R2
+    def depth_preprocess(self, raw, mask, scale, mask_mode=TDV_MASK_THRESHOLD10):
+        raw = np.ascontiguousarray(raw, np.uint16)
+        h, w = raw.shape
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        out = np.empty((h, w), np.float32)
+        _check(self._h, lib().tdv_depth_preprocess(self._h, _ptr(raw), _ptr(m), w, h, C.c_float(scale), mask_mode, _ptr(out)),
+               "tdv_depth_preprocess")
+        return out
+
+    def deproject(self, depth, bgr, fx, fy, cx, cy, zmax, capacity=None):
+        depth = _f32(depth)
+        h, w = depth.shape
+        b = None if bgr is None else np.ascontiguousarray(bgr, np.uint8)
+        cap = h * w if capacity is None else capacity
+        xyz = np.empty((cap, 3), np.float32)
+        rgb = np.empty((cap, 3), np.float32) if b is not None else None
+        n = C.c_int()
+        _check(self._h, lib().tdv_deproject(self._h, _ptr(depth), _ptr(b), w, h, C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                            C.c_float(cy), C.c_float(zmax), _ptr(xyz), _ptr(rgb), cap, C.byref(n)), "tdv_deproject")
+        return xyz[:n.value].copy(), (None if rgb is None else rgb[:n.value].copy())
+
+    def depth_to_cloud(self, raw, mask, bgr, scale, fx, fy, cx, cy, zmax, mask_mode=TDV_MASK_THRESHOLD10):
+        raw = np.ascontiguousarray(raw, np.uint16)
+        h, w = raw.shape
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        b = None if bgr is None else np.ascontiguousarray(bgr, np.uint8)
+        xyz = np.empty((h * w, 3), np.float32)
+        rgb = np.empty((h * w, 3), np.float32) if b is not None else None
+        n = C.c_int()
+        _check(self._h, lib().tdv_depth_to_cloud(self._h, _ptr(raw), _ptr(m), _ptr(b), w, h, C.c_float(scale), mask_mode,
+                                                 C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(zmax),
+                                                 _ptr(xyz), _ptr(rgb), h * w, C.byref(n)), "tdv_depth_to_cloud")
+        return xyz[:n.value].copy(), (None if rgb is None else rgb[:n.value].copy())
+
+    # ---------------------------------------------------------------- R3
+    def voxel_downsample(self, xyz, rgb, voxel, order=TDV_VOXEL_ORDER_REFERENCE):
+        xyz = _f32(xyz); rgb = _f32(rgb)
+        n = len(xyz)
+        oxyz = np.empty((max(n, 1), 3), np.float32)
+        orgb = np.empty((max(n, 1), 3), np.float32) if rgb is not None else None
+        m = C.c_int()
+        _check(self._h, lib().tdv_voxel_downsample(self._h, _ptr(xyz), _ptr(rgb), n, C.c_float(voxel), order, _ptr(oxyz), _ptr(orgb),
+                                                   n, C.byref(m)), "tdv_voxel_downsample")
+        return oxyz[:m.value].copy(), (None if orgb is None else orgb[:m.value].copy())
+
+    # ---------------------------------------------------------------- R4
+    def estimate_normals(self, xyz, k=30, want_knn=False):
+        xyz = _f32(xyz); n = len(xyz)
+        nrm = np.empty((n, 3), np.float32)
+        knn = np.empty((n, k), np.int32) if want_knn else None
+        _check(self._h, lib().tdv_estimate_normals(self._h, _ptr(xyz), n, k, _ptr(nrm), _ptr(knn)), "tdv_estimate_normals")
+        return (nrm, knn) if want_knn else nrm
+
+    def compute_fpfh(self, xyz, normals, radius, want_neighbors=False):
+        xyz = _f32(xyz); normals = _f32(normals); n = len(xyz)
+        desc = np.empty((n, 33), np.float32)
+        nb = np.empty((n, 100), np.int32) if want_neighbors else None
+        cnt = np.empty(n, np.int32) if want_neighbors else None
+        _check(self._h, lib().tdv_compute_fpfh(self._h, _ptr(xyz), _ptr(normals), n, C.c_float(radius), _ptr(desc), _ptr(nb), _ptr(cnt)),
+               "tdv_compute_fpfh")
+        return (desc, nb, cnt) if want_neighbors else desc
+
+    # ---------------------------------------------------------------- R5
+    def feature_match(self, fs, ft):
+        fs = _f32(fs); ft = _f32(ft)
+        corr = np.empty(len(fs), np.int32)
+        _check(self._h, lib().tdv_feature_match(self._h, _ptr(fs), len(fs), _ptr(ft), len(ft), _ptr(corr)), "tdv_feature_match")
+        return corr
+
+    def ransac(self, src, tgt, fs=None, ft=None, corr=None, voxel=0.001, max_iterations=100000, confidence=0.999,
+               seed=42, trace=False):
+        src = _f32(src); tgt = _f32(tgt); fs = _f32(fs); ft = _f32(ft)
+        c = None if corr is None else np.ascontiguousarray(corr, np.int32)
+        res = RansacResultC()
+        tr = np.full(max(max_iterations, 1), -2, np.int32) if trace else None
+        _check(self._h, lib().tdv_ransac(self._h, _ptr(src), len(src), _ptr(tgt), len(tgt), _ptr(fs), _ptr(ft), _ptr(c),
+                                         C.c_float(voxel), max_iterations, C.c_float(confidence), C.c_uint32(seed),
+                                         C.byref(res), _ptr(tr)), "tdv_ransac")
+        return RegistrationResult(transformation=from_colmajor16(res.T), fitness=np.float32(res.fitness), rmse=np.float32(res.rmse),
+                                  inliers=res.inliers, best_iteration=res.best_iteration, iterations_run=res.iterations_run,
+                                  trace_inliers=tr)
+
+    # ---------------------------------------------------------------- R6
+    def icp(self, src, tgt, tgt_normals, T0, thr, max_iterations=200, point_to_plane=True):
+        src = _f32(src); tgt = _f32(tgt); tn = _f32(tgt_normals)
+        res = IcpResultC()
+        t0 = to_colmajor16(T0)
+        _check(self._h, lib().tdv_icp(self._h, _ptr(src), len(src), _ptr(tgt), _ptr(tn), len(tgt), _ptr(t0), C.c_float(thr),
+                                      max_iterations, int(point_to_plane), C.byref(res)), "tdv_icp")
+        return RegistrationResult(transformation=from_colmajor16(res.T), fitness=np.float32(res.fitness), rmse=np.float32(res.rmse),
+                                  iterations=res.iterations, n_corr=res.n_corr)
+
+    def icp_correspondences(self, src, tgt, T, thr):
+        src = _f32(src); tgt = _f32(tgt)
+        ns = len(src)
+        corr = np.empty(ns, np.int32); d2 = np.empty(ns, np.float32); acc = np.empty(ns, np.uint8); nc = C.c_int()
+        t = to_colmajor16(T)
+        _check(self._h, lib().tdv_icp_correspondences(self._h, _ptr(src), ns, _ptr(tgt), len(tgt), _ptr(t), C.c_float(thr),
+                                                      _ptr(corr), _ptr(d2), _ptr(acc), C.byref(nc)), "tdv_icp_correspondences")
+        return dict(corr=corr, d2=d2, accepted=acc.astype(bool), n_corr=nc.value)
+
+    # ---------------------------------------------------------------- device-resident (pointers are ints)
+    def icp_dev(self, d_src, ns, d_tgt, d_tgt_normals, nt, T0, thr, max_iterations, point_to_plane=True, fixed_iterations=False):
+        res = IcpResultC()
+        t0 = to_colmajor16(T0)
+        _check(self._h, lib().tdv_icp_dev(self._h, _ptr(d_src), ns, _ptr(d_tgt), _ptr(d_tgt_normals), nt, _ptr(t0), C.c_float(thr),
+                                          max_iterations, int(point_to_plane), int(fixed_iterations), C.byref(res)), "tdv_icp_dev")
+        return RegistrationResult(transformation=from_colmajor16(res.T), fitness=np.float32(res.fitness), rmse=np.float32(res.rmse),
+                                  iterations=res.iterations, n_corr=res.n_corr)
+
+    def ransac_dev(self, d_src, ns, d_tgt, nt, d_fs, d_ft, d_corr, voxel, max_iterations, confidence=0.999, seed=42):
+        res = RansacResultC()
+        _check(self._h, lib().tdv_ransac_dev(self._h, _ptr(d_src), ns, _ptr(d_tgt), nt, _ptr(d_fs), _ptr(d_ft), _ptr(d_corr),
+                                             C.c_float(voxel), max_iterations, C.c_float(confidence), C.c_uint32(seed),
+                                             C.byref(res), None), "tdv_ransac_dev")
+        return RegistrationResult(transformation=from_colmajor16(res.T), fitness=np.float32(res.fitness), rmse=np.float32(res.rmse),
+                                  inliers=res.inliers, best_iteration=res.best_iteration, iterations_run=res.iterations_run)
+
+    def feature_match_dev(self, d_fs, ns, d_ft, nt, d_corr):
+        _check(self._h, lib().tdv_feature_match_dev(self._h, _ptr(d_fs), ns, _ptr(d_ft), nt, _ptr(d_corr)), "tdv_feature_match_dev")
+
+    def estimate_normals_dev(self, d_xyz, n, k, d_normals, d_knn=None):
+        _check(self._h, lib().tdv_estimate_normals_dev(self._h, _ptr(d_xyz), n, k, _ptr(d_normals), _ptr(d_knn)), "tdv_estimate_normals_dev")
+
+    def compute_fpfh_dev(self, d_xyz, d_normals, n, radius, d_desc, d_nbr=None, d_cnt=None):
+        _check(self._h, lib().tdv_compute_fpfh_dev(self._h, _ptr(d_xyz), _ptr(d_normals), n, C.c_float(radius), _ptr(d_desc),
+                                                   _ptr(d_nbr), _ptr(d_cnt)), "tdv_compute_fpfh_dev")
+
+    def depth_to_cloud_dev(self, d_raw, d_mask, d_bgr, w, h, scale, fx, fy, cx, cy, zmax, d_xyz, d_rgb, capacity,
+                           mask_mode=TDV_MASK_THRESHOLD10):
+        n = C.c_int()
+        _check(self._h, lib().tdv_depth_to_cloud_dev(self._h, _ptr(d_raw), _ptr(d_mask), _ptr(d_bgr), w, h, C.c_float(scale), mask_mode,
+                                                     C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(zmax),
+                                                     _ptr(d_xyz), _ptr(d_rgb), capacity, C.byref(n)), "tdv_depth_to_cloud_dev")
+        return n.value
+
+    def voxel_downsample_dev(self, d_xyz, d_rgb, n, voxel, d_out_xyz, d_out_rgb, capacity):
+        m = C.c_int()
+        _check(self._h, lib().tdv_voxel_downsample_dev(self._h, _ptr(d_xyz), _ptr(d_rgb), n, C.c_float(voxel), _ptr(d_out_xyz),
+                                                       _ptr(d_out_rgb), capacity, C.byref(m)), "tdv_voxel_downsample_dev")
+        return m.value
+
+
+def sample_triples(n, count, seed=42):
+    out = np.empty((count, 3), np.uint64)
+    _check(None, lib().tdv_sample_triples(C.c_uint32(seed), C.c_uint64(n), count, _ptr(out)), "tdv_sample_triples")
+    return out
+
+
+def pose_compose(extrinsics, T):
+    e = to_colmajor16(extrinsics); t = to_colmajor16(T); o = np.zeros(16, np.float32)
+    _check(None, lib().tdv_pose_compose(_ptr(e), _ptr(t), _ptr(o)), "tdv_pose_compose")
+    return from_colmajor16(o)
+
+
+# --------------------------------------------------------------------------------------------------
+# Operator API in the reference's own names.  A thread-local default Context stands in for the
+# per-thread state the reference's static methods hide.
+_tls = threading.local()
+
+
+def default_context():
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = Context(0)
+        _tls.ctx = ctx
+    return ctx
+
+
+class GPUDepth:
+    """include/gpu_depth.hpp:9-13."""
+
+    @staticmethod
+    def isCudaAvailable():
+        try:
+            return device_count() > 0
+        except TdvError:
+            return False
+
+    @staticmethod
+    def preprocess(raw_depth, mask, scale):
+        if not GPUDepth.isCudaAvailable():
+            raise RuntimeError("CUDA not available")  # src/gpu_impl.cpp:64
+        return default_context().depth_preprocess(raw_depth, mask, scale)
+
+
+class GPUPointCloud:
+    """include/gpu_depth.hpp:15-22.  zmax defaults to the reference dispatch's hard-coded 10.0
+    (src/gpu_impl.cpp:97); pass config.depth.clipping_max to follow the CPU branch."""
+
+    @staticmethod
+    def generate(depth, rgb, fx, fy, cx, cy, zmax=10.0):
+        if not GPUDepth.isCudaAvailable():
+            return PointCloud()  # src/gpu_impl.cpp:126
+        xyz, col = default_context().deproject(depth, rgb, fx, fy, cx, cy, zmax)
+        return PointCloud(points=xyz, colors=col)
+
+
+class GPURegistration:
+    """include/gpu_registration.hpp:8-19."""
+
+    @staticmethod
+    def isCudaAvailable():
+        return GPUDepth.isCudaAvailable()
+
+    @staticmethod
+    def icpRefine(source, target, initial_transform, distance_threshold, max_iterations=200):
+        if not GPURegistration.isCudaAvailable():
+            raise RuntimeError("CUDA not available")  # src/gpu_impl.cpp:258
+        tn = target.normals if target.hasNormals() else None
+        return default_context().icp(source.points, target.points, tn, initial_transform, distance_threshold, max_iterations, True)
+
+
+class Registration:
+    """include/registration.hpp:32-60, served by the HIP backend."""
+
+    @staticmethod
+    def voxelDownsample(cloud, voxel_size, order=TDV_VOXEL_ORDER_REFERENCE):
+        col = cloud.colors if cloud.hasColors() else None
+        xyz, c = default_context().voxel_downsample(cloud.points, col, voxel_size, order)
+        return PointCloud(points=xyz, colors=c)
+
+    @staticmethod
+    def estimateNormals(cloud, k=30):
+        cloud.normals = default_context().estimate_normals(cloud.points, k)
+
+    @staticmethod
+    def computeFPFH(cloud, radius):
+        return default_context().compute_fpfh(cloud.points, cloud.normals, radius)
+
+    @staticmethod
+    def ransacRegistration(source, target, source_features, target_features, voxel_size, max_iterations=100000, confidence=0.999):
+        return default_context().ransac(source.points, target.points, source_features, target_features, None, voxel_size,
+                                        max_iterations, confidence)
+
+    @staticmethod
+    def icpRefine(source, target, initial_transform, distance_threshold, max_iterations=200, point_to_plane=True):
+        tn = target.normals if target.hasNormals() else None
+        return default_context().icp(source.points, target.points, tn, initial_transform, distance_threshold, max_iterations,
+                                     point_to_plane)

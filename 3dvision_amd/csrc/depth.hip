@@ -1,0 +1,210 @@
+// Depth scale + mask and depth -> point-cloud unprojection on gfx950 (HBM-bound scans).
+//
+// Replaces GPUDepth::preprocess (/root/reference/src/gpu_impl.cpp:28-66, kernel
+// cuda/depth_processing.cu:10-30) and GPUPointCloud::generate (gpu_impl.cpp:69-128, kernel
+// cuda/pointcloud.cu:11-51); results follow the CPU branches src/pipeline.cpp:46-54 and :61-84:
+//   depth  = float(raw) * float(1.0/scale), zero where the mask rejects the pixel
+//   keep 0 < z <= zmax ; x = (u - cx) * z / fx ; y = (v - cy) * z / fy ; colour = BGR->RGB / 255
+// and — unlike the reference's CUDA kernel, whose global atomicAdd makes the order
+// nondeterministic — points are emitted in the CPU's row-major scan order:
+//   pass 1 (k_valid_count)  : 1024 pixels per workgroup, ballot/popcount -> one count per block
+//   pass 2 (k_block_scan)   : exclusive scan of the block counts (one workgroup)
+//   pass 3 (k_emit)         : recompute validity, wave-ballot prefix + block offset -> slot
+// Algorithmic HBM bytes per frame (fused u16+mask+bgr path): 2x(2+1) in + 3 in + 24n out.
+#include "tdv_internal.hpp"
+#include <cfloat>
+#include <cmath>
+#include <algorithm>
+
+namespace tdv {
+
+constexpr int DP_BLOCK = 256;
+constexpr int DP_PX_PER_THREAD = 4;
+constexpr int DP_PX_PER_BLOCK = DP_BLOCK * DP_PX_PER_THREAD;
+
+__device__ __forceinline__ float scaled_depth(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ mask,
+                                              size_t i, float inv_scale, int mask_mode) {
+    float v = (float)raw[i] * inv_scale;
+    if (mask) {
+        uint8_t m = mask[i];
+        bool keep = mask_mode == TDV_MASK_THRESHOLD10 ? (m > 10) : (m != 0);
+        if (!keep) v = 0.f;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(DP_BLOCK)
+void k_depth_preprocess(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ mask, size_t n,
+                        float inv_scale, int mask_mode, float* __restrict__ out) {
+    // 4 consecutive pixels per lane: 8 B of depth, 4 B of mask in, 16 B out
+    size_t i4 = ((size_t)blockIdx.x * DP_BLOCK + threadIdx.x) * 4;
+    if (i4 + 3 < n) {
+        ushort4 r = *reinterpret_cast<const ushort4*>(raw + i4);
+        float4 o = make_float4((float)r.x * inv_scale, (float)r.y * inv_scale, (float)r.z * inv_scale, (float)r.w * inv_scale);
+        if (mask) {
+            uchar4 m = *reinterpret_cast<const uchar4*>(mask + i4);
+            if (mask_mode == TDV_MASK_THRESHOLD10) {
+                if (!(m.x > 10)) o.x = 0.f; if (!(m.y > 10)) o.y = 0.f; if (!(m.z > 10)) o.z = 0.f; if (!(m.w > 10)) o.w = 0.f;
+            } else {
+                if (m.x == 0) o.x = 0.f; if (m.y == 0) o.y = 0.f; if (m.z == 0) o.z = 0.f; if (m.w == 0) o.w = 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(out + i4) = o;
+    } else {
+        for (size_t i = i4; i < n; ++i) out[i] = scaled_depth(raw, mask, i, inv_scale, mask_mode);
+    }
+}
+
+// depth of pixel i from either the raw u16 (+mask) image or an f32 depth image
+template <bool RAW>
+__device__ __forceinline__ float pixel_depth(const uint16_t* __restrict__ raw, const float* __restrict__ depth,
+                                             const uint8_t* __restrict__ mask, size_t i, float inv_scale, int mask_mode) {
+    if (RAW) return scaled_depth(raw, mask, i, inv_scale, mask_mode);
+    return depth[i];
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(DP_BLOCK)
+void k_valid_count(const uint16_t* __restrict__ raw, const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                   size_t n, float inv_scale, int mask_mode, float zmax, int* __restrict__ block_counts) {
+    // pixel p of the block = threadIdx.x + k*256 (coalesced), k = 0..3
+    const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        size_t i = base + k * DP_BLOCK + threadIdx.x;
+        if (i < n) {
+            float z = pixel_depth<RAW>(raw, depth, mask, i, inv_scale, mask_mode);
+            c += !(z <= 0.f || z > zmax);
+        }
+    }
+    __shared__ int red[DP_BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// exclusive scan of nblocks counts by ONE workgroup of 1024 threads; total -> offsets[nblocks]
+__global__ __launch_bounds__(1024)
+void k_block_scan(const int* __restrict__ counts, int nblocks, int* __restrict__ offsets) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        int i = b0 + threadIdx.x;
+        int v = i < nblocks ? counts[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        int carry = carry_s;
+        if (i < nblocks) offsets[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[nblocks] = carry_s;
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(DP_BLOCK)
+void k_emit(const uint16_t* __restrict__ raw, const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+            const uint8_t* __restrict__ bgr, int width, size_t n, float inv_scale, int mask_mode,
+            float fx, float fy, float cx, float cy, float zmax,
+            const int* __restrict__ offsets, int capacity, float* __restrict__ xyz, float* __restrict__ rgb) {
+    const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wcnt[DP_PX_PER_THREAD][DP_BLOCK / 64];
+    float zs[DP_PX_PER_THREAD]; bool ok[DP_PX_PER_THREAD]; int rank[DP_PX_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        size_t i = base + k * DP_BLOCK + threadIdx.x;
+        float z = 0.f;
+        if (i < n) z = pixel_depth<RAW>(raw, depth, mask, i, inv_scale, mask_mode);
+        ok[k] = (i < n) && !(z <= 0.f || z > zmax);
+        zs[k] = z;
+        unsigned long long b = __ballot(ok[k]);
+        rank[k] = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[k][wave] = __popcll(b);
+    }
+    __syncthreads();
+    int run = offsets[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < DP_BLOCK / 64; ++w) before += (w < wave) ? wcnt[k][w] : 0;
+        int slot = run + before + rank[k];
+        if (ok[k] && slot < capacity) {
+            size_t i = base + k * DP_BLOCK + threadIdx.x;
+            int v = (int)(i / width), u = (int)(i - (size_t)v * width);
+            float z = zs[k];
+            float x = ((float)u - cx) * z / fx;   // pipeline.cpp:73
+            float y = ((float)v - cy) * z / fy;   // pipeline.cpp:74
+            xyz[3 * (size_t)slot] = x; xyz[3 * (size_t)slot + 1] = y; xyz[3 * (size_t)slot + 2] = z;
+            if (rgb && bgr) {
+                const uint8_t* p = bgr + i * 3;
+                rgb[3 * (size_t)slot] = (float)p[2] / 255.0f;
+                rgb[3 * (size_t)slot + 1] = (float)p[1] / 255.0f;
+                rgb[3 * (size_t)slot + 2] = (float)p[0] / 255.0f;
+            }
+        }
+        run += (wcnt[k][0] + wcnt[k][1]) + (wcnt[k][2] + wcnt[k][3]);
+    }
+}
+
+int depth_preprocess_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, int w, int h, float scale,
+                         int mask_mode, float* d_out) {
+    if (!ctx || !d_raw || !d_out || w < 0 || h < 0) return TDV_ERR_BAD_ARG;
+    const size_t n = (size_t)w * h;
+    if (n == 0) return TDV_OK;
+    const float inv_scale = (float)(1.0 / (double)scale);  // cv::Mat::convertTo(CV_32F, 1.0/scale)
+    const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
+    ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
+    k_depth_preprocess<<<blocks, DP_BLOCK, 0, ctx->stream>>>(d_raw, d_mask, n, inv_scale, mask_mode, d_out);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth, const uint8_t* d_mask,
+                       const uint8_t* d_bgr, int w, int h, float scale, int mask_mode,
+                       float fx, float fy, float cx, float cy, float zmax,
+                       float* d_xyz, float* d_rgb, int capacity, int* n_out) {
+    if (!ctx || (!d_raw && !d_depth) || !n_out || w < 0 || h < 0 || capacity < 0) return TDV_ERR_BAD_ARG;
+    *n_out = 0;
+    const size_t n = (size_t)w * h;
+    if (n == 0) return TDV_OK;
+    const float inv_scale = (float)(1.0 / (double)scale);
+    const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
+    int *counts, *offsets;
+    TDV_TRY(ws_alloc(ctx, (size_t)blocks, &counts));
+    TDV_TRY(ws_alloc(ctx, (size_t)blocks + 1, &offsets));
+    TDV_TRY(pin_reserve(ctx, 64));
+    hipStream_t s = ctx->stream;
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
+        if (d_raw) k_valid_count<true><<<blocks, DP_BLOCK, 0, s>>>(d_raw, nullptr, d_mask, n, inv_scale, mask_mode, zmax, counts);
+        else k_valid_count<false><<<blocks, DP_BLOCK, 0, s>>>(nullptr, d_depth, nullptr, n, 0.f, 0, zmax, counts);
+        k_block_scan<<<1, 1024, 0, s>>>(counts, blocks, offsets);
+        if (d_xyz && capacity > 0) {
+            if (d_raw) k_emit<true><<<blocks, DP_BLOCK, 0, s>>>(d_raw, nullptr, d_mask, d_bgr, w, n, inv_scale, mask_mode, fx, fy, cx, cy, zmax, offsets, capacity, d_xyz, d_rgb);
+            else k_emit<false><<<blocks, DP_BLOCK, 0, s>>>(nullptr, d_depth, nullptr, d_bgr, w, n, 0.f, 0, fx, fy, cx, cy, zmax, offsets, capacity, d_xyz, d_rgb);
+        }
+    }
+    TDV_CHECK_LAUNCH(ctx);
+    int* h_total = reinterpret_cast<int*>(ctx->pin);
+    TDV_HIP(ctx, hipMemcpyAsync(h_total, offsets + blocks, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    *n_out = *h_total;
+    if (*h_total > capacity) return TDV_ERR_BAD_ARG;  // caller's buffers too small; *n_out = needed
+    return TDV_OK;
+}
+
+}  // namespace tdv

@@ -1,0 +1,399 @@
+// ICP on gfx950: brute-force nearest-neighbour correspondence search + normal equations +
+// small solve, the whole loop resident on the device.
+//
+// Replaces GPURegistration::icpRefine (/root/reference/src/gpu_impl.cpp:141-260, kernels
+// cuda/icp.cu:14-55 and :90-142); results follow the CPU oracle Registration::icpRefine
+// (/root/reference/src/registration.cpp:297-414), including where the CUDA path differs
+// (transformed point in J and r, inclusive threshold, n_corr<3 break, point-to-point mode).
+//
+// Kernel design (VALU-bound, not HBM- and not MFMA-bound: 8 f32 ops per pair, K=3):
+//  * icp_nn_scan: each lane keeps NN_SPL transformed source points in VGPRs; the target cloud
+//    is read as structure-of-arrays through the SCALAR data path (wave-uniform s_load_dwordx8
+//    of 8 x, 8 y, 8 z), so every distance op is one VALU instruction with an SGPR operand and
+//    neither LDS nor vector-memory instructions sit in the inner loop.  Argmin is two-level:
+//    the loop tracks min d2 and the first CHUNK of 8 targets that reached it (strict <),
+//    8 + 0.5 + 0.4 VALU ops per pair; the exact index inside the chunk is recovered later by
+//    re-evaluating 8 distances.  d2 = dx*dx + (dy*dy + dz*dz) with no FMA contraction, so the
+//    argmin is bit-identical to the CPU scan (lowest index wins ties).
+//    The grid is (source blocks) x (target splits) so that >> 256 workgroups are in flight;
+//    splits are combined in split order with strict <, which preserves the tie rule.
+//  * icp_accumulate: one lane per source; resolves the index, applies the sqrt-free inclusive
+//    threshold, builds J = [p x n | n], r = (p-q).n (or the point-to-point moments) and reduces
+//    in a FIXED order (wave64 shuffles -> LDS -> one slab per block); f64 accumulators.
+//  * icp_solve: one block folds the slabs in fixed order, one lane solves the 6x6 system
+//    (pivoted LDL^T) or the 3x3 Kabsch SVD, updates T on the device and evaluates convergence.
+// No float atomics anywhere: two runs give identical bits.
+#include "tdv_internal.hpp"
+#include "device_linalg.hpp"
+#include <cfloat>
+#include <cmath>
+#include <algorithm>
+
+namespace tdv {
+
+constexpr int NN_SPL = 4;      // source points per lane
+constexpr int NN_CH = 8;       // targets per chunk (one s_load_dwordx8 per coordinate)
+constexpr int NN_BLOCK = 256;
+constexpr int NN_SRC_PER_BLOCK = NN_SPL * NN_BLOCK;
+constexpr int ACC_NV = 32;     // reduction slots per block (29 used p2plane, 17 p2point)
+
+struct IcpState {
+    float T[16];       // current transform, column-major
+    float res_T[16];   // result.transformation
+    float fitness, rmse;
+    int n_corr;        // accepted correspondences of the last evaluated iteration
+    int applied;       // iterations whose update was applied
+    int done;          // loop finished (converged / n_corr < 3)
+    int iter;          // iterations evaluated
+    int last_n_corr_applied;
+    int pad;
+};
+
+__global__ void k_aos_to_soa_pad(const float* __restrict__ aos, int n, int n_pad, float pad,
+                                 float* __restrict__ x, float* __restrict__ y, float* __restrict__ z) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pad) return;
+    if (i < n) { x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; z[i] = aos[3 * i + 2]; }
+    else { x[i] = pad; y[i] = pad; z[i] = pad; }
+}
+
+__device__ __forceinline__ void transform_point(const float* __restrict__ T, float sx, float sy, float sz,
+                                                float& px, float& py, float& pz) {
+    // p = R*s + t with each row evaluated as r0*sx + (r1*sy + r2*sz), then + t (column-major T)
+    px = (T[0] * sx + (T[4] * sy + T[8] * sz)) + T[12];
+    py = (T[1] * sx + (T[5] * sy + T[9] * sz)) + T[13];
+    pz = (T[2] * sx + (T[6] * sy + T[10] * sz)) + T[14];
+}
+
+__global__ __launch_bounds__(NN_BLOCK)
+void k_icp_nn_scan(const float* __restrict__ src, int ns, int ns_pad,
+                   const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                   int n_chunks, int chunks_per_split,
+                   const IcpState* __restrict__ st,
+                   float* __restrict__ pd2, int* __restrict__ pchunk) {
+    if (st->done) return;
+    const int split = blockIdx.y;
+    const int c0 = split * chunks_per_split;
+    const int c1 = min(n_chunks, c0 + chunks_per_split);
+    const int base = blockIdx.x * NN_SRC_PER_BLOCK + threadIdx.x;
+    float px[NN_SPL], py[NN_SPL], pz[NN_SPL], best[NN_SPL];
+    int bc[NN_SPL];
+#pragma unroll
+    for (int s = 0; s < NN_SPL; ++s) {
+        int i = min(base + s * NN_BLOCK, ns - 1);
+        transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px[s], py[s], pz[s]);
+        best[s] = FLT_MAX; bc[s] = 0;
+    }
+    for (int c = c0; c < c1; ++c) {
+        const int j = c * NN_CH;
+        float qx[NN_CH], qy[NN_CH], qz[NN_CH];
+#pragma unroll
+        for (int t = 0; t < NN_CH; ++t) { qx[t] = tx[j + t]; qy[t] = ty[j + t]; qz[t] = tz[j + t]; }
+#pragma unroll
+        for (int s = 0; s < NN_SPL; ++s) {
+            float m = FLT_MAX;
+#pragma unroll
+            for (int t = 0; t < NN_CH; ++t) {
+                float dx = px[s] - qx[t], dy = py[s] - qy[t], dz = pz[s] - qz[t];
+                float d2 = dx * dx + (dy * dy + dz * dz);
+                m = fminf(m, d2);
+            }
+            bool lt = m < best[s];
+            best[s] = lt ? m : best[s];
+            bc[s] = lt ? j : bc[s];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NN_SPL; ++s) {
+        size_t o = (size_t)split * ns_pad + base + s * NN_BLOCK;
+        pd2[o] = best[s]; pchunk[o] = bc[s];
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// MODE 0: point-to-plane (21 upper-triangular JtJ + 6 Jtr), MODE 1: point-to-point moments,
+// MODE 2: outputs only (no accumulation beyond count / error).
+template <int MODE>
+__global__ __launch_bounds__(256)
+void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
+                      const float* __restrict__ tgt, const float* __restrict__ tgt_normals,
+                      const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                      int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk,
+                      const IcpState* __restrict__ st, float tau_accept,
+                      double* __restrict__ slabs,
+                      int* __restrict__ out_corr, float* __restrict__ out_d2, uint8_t* __restrict__ out_acc) {
+    if (st->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double v[ACC_NV];
+#pragma unroll
+    for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+    if (i < ns) {
+        float px, py, pz;
+        transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+        float best = FLT_MAX; int bc = 0;
+        for (int s = 0; s < nsplit; ++s) {
+            float d = pd2[(size_t)s * ns_pad + i];
+            int c = pchunk[(size_t)s * ns_pad + i];
+            if (d < best) { best = d; bc = c; }
+        }
+        int idx = 0;
+        if (best < FLT_MAX) {
+            idx = bc;
+#pragma unroll
+            for (int t = NN_CH - 1; t >= 0; --t) {
+                float dx = px - tx[bc + t], dy = py - ty[bc + t], dz = pz - tz[bc + t];
+                float d2 = dx * dx + (dy * dy + dz * dz);
+                if (d2 == best) idx = bc + t;
+            }
+        }
+        bool acc = best <= tau_accept;
+        if (out_corr) out_corr[i] = idx;
+        if (out_d2) out_d2[i] = best;
+        if (out_acc) out_acc[i] = acc ? 1 : 0;
+        if (acc) {
+            v[0] = 1.0; v[1] = (double)best;
+            float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
+            if (MODE == 0) {
+                float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
+                float J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+                float ex = px - qx, ey = py - qy, ez = pz - qz;
+                float r = ex * nx + (ey * ny + ez * nz);
+                int k = 2;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b) v[k++] = (double)(J[a] * J[b]);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) v[k++] = (double)(J[a] * r);
+            } else if (MODE == 1) {
+                double P[3] = {px, py, pz}, Q[3] = {qx, qy, qz};
+                v[2] = P[0]; v[3] = P[1]; v[4] = P[2];
+                v[5] = Q[0]; v[6] = Q[1]; v[7] = Q[2];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) v[8 + a * 3 + b] = P[a] * Q[b];
+            }
+        }
+    }
+    constexpr int NV = MODE == 0 ? 29 : (MODE == 1 ? 17 : 2);
+    __shared__ double red[4][ACC_NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < ACC_NV) {
+        double s = 0.0;
+        if (threadIdx.x < NV) s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        slabs[(size_t)blockIdx.x * ACC_NV + threadIdx.x] = s;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256)
+void k_icp_solve(const double* __restrict__ slabs, int nblocks, int ns, IcpState* __restrict__ st, int fixed_iterations) {
+    if (st->done) return;
+    __shared__ double part[8][ACC_NV];
+    __shared__ double tot[ACC_NV];
+    const int v = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double s = 0.0;
+    for (int b = g; b < nblocks; b += 8) s += slabs[(size_t)b * ACC_NV + v];
+    part[g][v] = s;
+    __syncthreads();
+    if (threadIdx.x < ACC_NV) {
+        double t = ((part[0][v] + part[1][v]) + (part[2][v] + part[3][v])) + ((part[4][v] + part[5][v]) + (part[6][v] + part[7][v]));
+        tot[v] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int n_corr = (int)(tot[0] + 0.5);
+    const int iter = st->iter;
+    st->iter = iter + 1;
+    st->n_corr = n_corr;
+    if (n_corr < 3) {  // registration.cpp:361 — break, keeping the previous result
+        if (!fixed_iterations) st->done = 1;
+        return;
+    }
+    float delta[16];
+    for (int i = 0; i < 16; ++i) delta[i] = 0.f;
+    delta[0] = delta[5] = delta[10] = delta[15] = 1.f;
+    if (MODE == 0) {
+        float ATA[36], nb[6], x[6];
+        int k = 2;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) { float val = (float)tot[k++]; ATA[a * 6 + b] = val; ATA[b * 6 + a] = val; }
+        for (int a = 0; a < 6; ++a) nb[a] = -(float)tot[k++];
+        dl::ldlt6_solve(ATA, nb, x);
+        dl::Mat3 dR = dl::euler_xyz(x[0], x[1], x[2]);
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) delta[c * 4 + r] = dl::el(dR, r, c);
+        delta[12] = x[3]; delta[13] = x[4]; delta[14] = x[5];
+    } else {
+        const double n = (double)n_corr;
+        double sm[3] = {tot[2] / n, tot[3] / n, tot[4] / n};
+        double tm[3] = {tot[5] / n, tot[6] / n, tot[7] / n};
+        dl::Mat3 H;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) dl::el(H, a, b) = (float)(tot[8 + a * 3 + b] - n * sm[a] * tm[b]);
+        dl::Mat3 dR = dl::kabsch_rotation(H);
+        float smf[3] = {(float)sm[0], (float)sm[1], (float)sm[2]};
+        float tmf[3] = {(float)tm[0], (float)tm[1], (float)tm[2]};
+        float rx, ry, rz;
+        dl::mulv3(dR, smf[0], smf[1], smf[2], rx, ry, rz);
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) delta[c * 4 + r] = dl::el(dR, r, c);
+        delta[12] = tmf[0] - rx; delta[13] = tmf[1] - ry; delta[14] = tmf[2] - rz;
+    }
+    float Tn[16];
+    dl::mul44(delta, st->T, Tn);
+    for (int i = 0; i < 16; ++i) { st->T[i] = Tn[i]; st->res_T[i] = Tn[i]; }
+    const float prev_rmse = st->rmse;
+    const float rmse = sqrtf((float)tot[1] / (float)n_corr);
+    st->rmse = rmse;
+    st->fitness = (float)n_corr / (float)ns;
+    st->applied = iter + 1;
+    st->last_n_corr_applied = n_corr;
+    if (!fixed_iterations && iter > 0 && fabsf(prev_rmse - rmse) < 1e-6f) st->done = 1;  // registration.cpp:406
+}
+
+__global__ void k_icp_count_only(const double* __restrict__ slabs, int nblocks, IcpState* __restrict__ st) {
+    // single block: total accepted count for the correspondence-only entry point
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += slabs[(size_t)b * ACC_NV];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st->n_corr = (int)(part[0] + 0.5);
+}
+
+namespace {
+
+struct NnPlan {
+    int ns_pad, nt_pad, n_chunks, blocks_x, nsplit, chunks_per_split, acc_blocks;
+};
+
+NnPlan make_plan(int ns, int nt) {
+    NnPlan p;
+    p.ns_pad = (int)align_up((size_t)ns, NN_SRC_PER_BLOCK);
+    p.nt_pad = (int)align_up((size_t)nt, NN_CH);
+    p.n_chunks = p.nt_pad / NN_CH;
+    p.blocks_x = p.ns_pad / NN_SRC_PER_BLOCK;
+    // aim for ~6k workgroups (24 per CU) but keep at least 32 chunks (256 targets) per split
+    int want = (6144 + p.blocks_x - 1) / p.blocks_x;
+    int max_split = std::max(1, p.n_chunks / 32);
+    p.nsplit = std::max(1, std::min(std::min(want, max_split), 64));
+    p.chunks_per_split = (p.n_chunks + p.nsplit - 1) / p.nsplit;
+    p.nsplit = (p.n_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
+    p.acc_blocks = (ns + 255) / 256;
+    return p;
+}
+
+struct IcpBuffers {
+    float *tx, *ty, *tz, *pd2; int* pchunk; double* slabs; IcpState* st;
+};
+
+int alloc_buffers(tdv_ctx* ctx, const NnPlan& p, IcpBuffers& b) {
+    float* soa = nullptr;
+    TDV_TRY(ws_alloc(ctx, (size_t)3 * p.nt_pad, &soa));
+    b.tx = soa; b.ty = soa + p.nt_pad; b.tz = soa + 2 * (size_t)p.nt_pad;
+    TDV_TRY(ws_alloc(ctx, (size_t)p.nsplit * p.ns_pad, &b.pd2));
+    TDV_TRY(ws_alloc(ctx, (size_t)p.nsplit * p.ns_pad, &b.pchunk));
+    TDV_TRY(ws_alloc(ctx, (size_t)p.acc_blocks * ACC_NV, &b.slabs));
+    TDV_TRY(ws_alloc(ctx, 1, &b.st));
+    return TDV_OK;
+}
+
+}  // namespace
+
+int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
+                const float* T0, float thr, int max_iterations, int point_to_plane, int fixed_iterations,
+                tdv_icp_result* out) {
+    if (!ctx || !d_src || !d_tgt || !T0 || !out || ns < 0 || nt < 0 || max_iterations < 0) return TDV_ERR_BAD_ARG;
+    TDV_HIP(ctx, hipSetDevice(ctx->device));
+    // result defaults: registration.cpp:309-311
+    std::memcpy(out->T, T0, 64);
+    out->fitness = 0.f; out->rmse = 0.f; out->iterations = 0; out->n_corr = 0;
+    if (max_iterations == 0) return TDV_OK;
+    if (ns == 0 || nt == 0) return TDV_OK;  // n_corr == 0 < 3 -> break at the first iteration
+    const NnPlan p = make_plan(ns, nt);
+    IcpBuffers b;
+    TDV_TRY(alloc_buffers(ctx, p, b));
+    TDV_TRY(pin_reserve(ctx, sizeof(IcpState)));
+    IcpState* h = reinterpret_cast<IcpState*>(ctx->pin);
+    std::memset(h, 0, sizeof(IcpState));
+    std::memcpy(h->T, T0, 64); std::memcpy(h->res_T, T0, 64);
+    hipStream_t s = ctx->stream;
+    TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
+    k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
+    TDV_CHECK_LAUNCH(ctx);
+    const bool p2pl = point_to_plane && d_tgt_normals;
+    const float tau = tau_le(thr);
+    const dim3 grid(p.blocks_x, p.nsplit);
+    const int poll = 8;
+    int it = 0;
+    while (it < max_iterations) {
+        int burst = std::min(poll, max_iterations - it);
+        for (int k = 0; k < burst; ++k) {
+            {
+                ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
+                k_icp_nn_scan<<<grid, NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
+                                                        p.chunks_per_split, b.st, b.pd2, b.pchunk);
+            }
+            if (p2pl) {
+                k_icp_accumulate<0><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, d_tgt_normals, b.tx, b.ty, b.tz,
+                                                                 p.nsplit, b.pd2, b.pchunk, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
+                k_icp_solve<0><<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, ns, b.st, fixed_iterations);
+            } else {
+                k_icp_accumulate<1><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz,
+                                                                 p.nsplit, b.pd2, b.pchunk, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
+                k_icp_solve<1><<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, ns, b.st, fixed_iterations);
+            }
+        }
+        TDV_CHECK_LAUNCH(ctx);
+        it += burst;
+        TDV_HIP(ctx, hipMemcpyAsync(h, b.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        if (h->done) break;
+    }
+    std::memcpy(out->T, h->res_T, 64);
+    out->fitness = h->fitness; out->rmse = h->rmse; out->iterations = h->applied; out->n_corr = h->last_n_corr_applied;
+    return TDV_OK;
+}
+
+int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
+                            const float* T, float thr, IcpOutputs outs, int* n_corr) {
+    if (!ctx || !d_src || !d_tgt || !T || ns <= 0 || nt <= 0) return TDV_ERR_BAD_ARG;
+    TDV_HIP(ctx, hipSetDevice(ctx->device));
+    const NnPlan p = make_plan(ns, nt);
+    IcpBuffers b;
+    TDV_TRY(alloc_buffers(ctx, p, b));
+    TDV_TRY(pin_reserve(ctx, sizeof(IcpState)));
+    IcpState* h = reinterpret_cast<IcpState*>(ctx->pin);
+    std::memset(h, 0, sizeof(IcpState));
+    std::memcpy(h->T, T, 64);
+    hipStream_t s = ctx->stream;
+    TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
+    k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
+    k_icp_nn_scan<<<dim3(p.blocks_x, p.nsplit), NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
+                                                                  p.chunks_per_split, b.st, b.pd2, b.pchunk);
+    k_icp_accumulate<2><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz, p.nsplit,
+                                                     b.pd2, b.pchunk, b.st, tau_le(thr), b.slabs, outs.corr, outs.d2, outs.accepted);
+    k_icp_count_only<<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, b.st);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_HIP(ctx, hipMemcpyAsync(h, b.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    if (n_corr) *n_corr = h->n_corr;
+    return TDV_OK;
+}
+
+}  // namespace tdv

@@ -1,0 +1,378 @@
+// RANSAC coarse alignment on gfx950.
+//
+// Replaces Registration::ransacRegistration (/root/reference/src/registration.cpp:204-295), which
+// has no GPU entry point in the reference (src/pipeline.cpp:97-102 calls the CPU static directly).
+// Sub-steps and their kernels:
+//  (i)   feature correspondences (registration.cpp:216-232): k_feature_match_scan — 33-D squared
+//        distance accumulated in d order without FMA, strict <, lowest j wins; source descriptors
+//        live in VGPRs (FM_SPL per lane), target descriptors are broadcast through the scalar
+//        data path (wave-uniform s_load of 33 floats per target).  VALU-bound: 98 ops per pair.
+//  (ii)  index triples (registration.cpp:235-239): host, mt19937 + Lemire (ctx.hip), one batch at
+//        a time; a batch is uploaded as int4 (i0,i1,i2,valid).
+//  (iii) k_ransac_hypotheses: one lane per hypothesis — centroids, H = S_c T_c^T, Jacobi SVD,
+//        R = V U^T with reflection fix, t = c_t - R c_s (registration.cpp:242-268).
+//  (iv)  k_ransac_score: lanes hold RS_HPL hypotheses (R,t in VGPRs); points (source p and its
+//        pre-gathered match q, 8 floats per point) are broadcast through the scalar data path;
+//        28 VALU ops per (hypothesis, point); the inlier test sqrt(d2) < thr is evaluated as
+//        d2 < tau with tau = min{f : sqrtf(f) >= thr} (exactly equivalent, no sqrt in the loop).
+//        Inlier counts are integers: partial counts per point-split are added with integer
+//        atomics, which are order-independent, so counts are bit-exact and reproducible.
+//  (v)   selection (registration.cpp:281-290) on the host over the batch's counts in iteration
+//        order: strict > on float(inliers)/ns, stop at the first fitness > confidence.
+//  (vi)  k_ransac_rmse: error sum of the winning hypothesis only, fixed-order reduction.
+#include "tdv_internal.hpp"
+#include "device_linalg.hpp"
+#include <cfloat>
+#include <cmath>
+#include <algorithm>
+#include <vector>
+
+namespace tdv {
+
+// ------------------------------------------------------------------ feature match
+constexpr int FM_SPL = 2;
+constexpr int FM_BLOCK = 256;
+constexpr int FM_SRC_PER_BLOCK = FM_SPL * FM_BLOCK;
+constexpr int FD = 33;
+
+__global__ __launch_bounds__(FM_BLOCK)
+void k_feature_match_scan(const float* __restrict__ fs, int ns, int ns_pad,
+                          const float* __restrict__ ft, int nt, int per_split,
+                          float* __restrict__ pd, int* __restrict__ pj) {
+    const int split = blockIdx.y;
+    const int j0 = split * per_split;
+    const int j1 = min(nt, j0 + per_split);
+    const int base = blockIdx.x * FM_SRC_PER_BLOCK + threadIdx.x;
+    float f[FM_SPL][FD];
+    float best[FM_SPL]; int bj[FM_SPL];
+#pragma unroll
+    for (int s = 0; s < FM_SPL; ++s) {
+        int i = min(base + s * FM_BLOCK, ns - 1);
+#pragma unroll
+        for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
+        best[s] = FLT_MAX; bj[s] = 0;
+    }
+    for (int j = j0; j < j1; ++j) {
+        const float* __restrict__ g = ft + (size_t)j * FD;  // wave-uniform -> scalar loads
+        float q[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) q[d] = g[d];
+#pragma unroll
+        for (int s = 0; s < FM_SPL; ++s) {
+            float dist = 0.f;
+#pragma unroll
+            for (int d = 0; d < FD; ++d) { float diff = f[s][d] - q[d]; dist += diff * diff; }
+            bool lt = dist < best[s];
+            best[s] = lt ? dist : best[s];
+            bj[s] = lt ? j : bj[s];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < FM_SPL; ++s) {
+        size_t o = (size_t)split * ns_pad + base + s * FM_BLOCK;
+        pd[o] = best[s]; pj[o] = bj[s];
+    }
+}
+
+__global__ void k_feature_match_combine(int ns, int ns_pad, int nsplit, const float* __restrict__ pd,
+                                        const int* __restrict__ pj, int* __restrict__ corr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    float best = FLT_MAX; int bj = 0;
+    for (int s = 0; s < nsplit; ++s) {
+        float d = pd[(size_t)s * ns_pad + i];
+        if (d < best) { best = d; bj = pj[(size_t)s * ns_pad + i]; }
+    }
+    corr[i] = bj;
+}
+
+int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
+    if (!ctx || !d_fs || !d_ft || !d_corr || ns < 0 || nt < 0) return TDV_ERR_BAD_ARG;
+    if (ns == 0) return TDV_OK;
+    hipStream_t s = ctx->stream;
+    if (nt == 0) { TDV_HIP(ctx, hipMemsetAsync(d_corr, 0, (size_t)ns * 4, s)); return TDV_OK; }
+    const int ns_pad = (int)align_up((size_t)ns, FM_SRC_PER_BLOCK);
+    const int blocks_x = ns_pad / FM_SRC_PER_BLOCK;
+    int want = (4096 + blocks_x - 1) / blocks_x;
+    int nsplit = std::max(1, std::min(std::min(want, std::max(1, nt / 64)), 64));
+    int per_split = (nt + nsplit - 1) / nsplit;
+    nsplit = (nt + per_split - 1) / per_split;
+    float* pd; int* pj;
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pd));
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pj));
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
+        k_feature_match_scan<<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, nt, per_split, pd, pj);
+    }
+    k_feature_match_combine<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nsplit, pd, pj, d_corr);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+// ------------------------------------------------------------------ hypotheses
+// pq layout: 8 floats per point: px py pz qx qy qz 0 0  (q = tgt[corr[i]]); padding points have
+// p = 0 and q = +inf so that d2 = +inf and they are never inliers.
+__global__ void k_gather_pq(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
+                            int ns, int ns_pad, float* __restrict__ pq) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns_pad) return;
+    float4 a, b;
+    if (i < ns) {
+        int c = corr[i];
+        a = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], tgt[3 * c]);
+        b = make_float4(tgt[3 * c + 1], tgt[3 * c + 2], 0.f, 0.f);
+    } else {
+        a = make_float4(0.f, 0.f, 0.f, INFINITY);
+        b = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+    }
+    reinterpret_cast<float4*>(pq)[2 * (size_t)i] = a;
+    reinterpret_cast<float4*>(pq)[2 * (size_t)i + 1] = b;
+}
+
+// hyp layout: SoA [12][h_pad]: r00 r10 r20 r01 r11 r21 r02 r12 r22 t0 t1 t2 (column-major R).
+// Invalid (skipped) iterations get NaN so that no comparison is ever true -> 0 inliers.
+__global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __restrict__ triples, int count, int h_pad,
+                                    float* __restrict__ hyp) {
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= h_pad) return;
+    float o[12];
+    bool valid = false;
+    int4 tr = make_int4(0, 0, 0, 0);
+    if (h < count) { tr = triples[h]; valid = tr.w != 0; }
+    if (valid) {
+        const int id[3] = {tr.x, tr.y, tr.z};
+        float sp[3][3], tp[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* r = pq + (size_t)id[k] * 8;
+            sp[k][0] = r[0]; sp[k][1] = r[1]; sp[k][2] = r[2];
+            tp[k][0] = r[3]; tp[k][1] = r[4]; tp[k][2] = r[5];
+        }
+        float sc[3], tc[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            sc[r] = dl::s3(sp[0][r], sp[1][r], sp[2][r]) / 3.0f;
+            tc[r] = dl::s3(tp[0][r], tp[1][r], tp[2][r]) / 3.0f;
+        }
+        dl::Mat3 S, Tt;  // S(r,c) = centred source column c ; Tt = (centred target)^T
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { dl::el(S, r, c) = sp[c][r] - sc[r]; dl::el(Tt, c, r) = tp[c][r] - tc[r]; }
+        dl::Mat3 H = dl::mul3(S, Tt);
+        dl::Mat3 R = dl::kabsch_rotation(H);
+        float rx, ry, rz;
+        dl::mulv3(R, sc[0], sc[1], sc[2], rx, ry, rz);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o[k] = R.a[k];
+        o[9] = tc[0] - rx; o[10] = tc[1] - ry; o[11] = tc[2] - rz;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[k] = __builtin_nanf("");
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) hyp[(size_t)k * h_pad + h] = o[k];
+}
+
+// ------------------------------------------------------------------ scoring
+constexpr int RS_HPL = 2;       // hypotheses per lane
+constexpr int RS_BLOCK = 256;
+constexpr int RS_HYP_PER_BLOCK = RS_HPL * RS_BLOCK;
+constexpr int RS_PCH = 2;       // points per scalar chunk (2 x 8 floats = one s_load_dwordx16)
+
+__global__ __launch_bounds__(RS_BLOCK)
+void k_ransac_score(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq,
+                    int n_pchunks, int pchunks_per_split, float tau, int* __restrict__ counts) {
+    const int split = blockIdx.y;
+    const int c0 = split * pchunks_per_split;
+    const int c1 = min(n_pchunks, c0 + pchunks_per_split);
+    const int base = blockIdx.x * RS_HYP_PER_BLOCK + threadIdx.x;
+    float r[RS_HPL][12];
+    int cnt[RS_HPL];
+#pragma unroll
+    for (int k = 0; k < RS_HPL; ++k) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) r[k][e] = hyp[(size_t)e * h_pad + base + k * RS_BLOCK];
+        cnt[k] = 0;
+    }
+    for (int c = c0; c < c1; ++c) {
+        const float* __restrict__ g = pq + (size_t)c * (8 * RS_PCH);  // wave-uniform -> scalar loads
+        float v[8 * RS_PCH];
+#pragma unroll
+        for (int e = 0; e < 8 * RS_PCH; ++e) v[e] = g[e];
+#pragma unroll
+        for (int p = 0; p < RS_PCH; ++p) {
+            const float px = v[8 * p], py = v[8 * p + 1], pz = v[8 * p + 2];
+            const float qx = v[8 * p + 3], qy = v[8 * p + 4], qz = v[8 * p + 5];
+#pragma unroll
+            for (int k = 0; k < RS_HPL; ++k) {
+                float x = (r[k][0] * px + (r[k][3] * py + r[k][6] * pz)) + r[k][9];
+                float y = (r[k][1] * px + (r[k][4] * py + r[k][7] * pz)) + r[k][10];
+                float z = (r[k][2] * px + (r[k][5] * py + r[k][8] * pz)) + r[k][11];
+                float dx = x - qx, dy = y - qy, dz = z - qz;
+                float d2 = dx * dx + (dy * dy + dz * dz);
+                cnt[k] += (d2 < tau) ? 1 : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RS_HPL; ++k) atomicAdd(&counts[base + k * RS_BLOCK], cnt[k]);
+}
+
+// error sum of one hypothesis (column-major R in T[0..8], t in T[9..11]) over all points
+__global__ __launch_bounds__(256)
+void k_ransac_rmse_partial(const float* __restrict__ pq, int ns, const float* __restrict__ hyp12, float tau,
+                           double* __restrict__ slabs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double e = 0.0, n = 0.0;
+    if (i < ns) {
+        const float* g = pq + (size_t)i * 8;
+        float px = g[0], py = g[1], pz = g[2];
+        float x = (hyp12[0] * px + (hyp12[3] * py + hyp12[6] * pz)) + hyp12[9];
+        float y = (hyp12[1] * px + (hyp12[4] * py + hyp12[7] * pz)) + hyp12[10];
+        float z = (hyp12[2] * px + (hyp12[5] * py + hyp12[8] * pz)) + hyp12[11];
+        float dx = x - g[3], dy = y - g[4], dz = z - g[5];
+        float d2 = dx * dx + (dy * dy + dz * dz);
+        if (d2 < tau) { float err = sqrtf(d2); e = (double)(err * err); n = 1.0; }  // d2 < tau <=> sqrtf(d2) < thr
+    }
+    __shared__ double red[2][4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off, 64); n += __shfl_down(n, off, 64); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = e; red[1][threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        slabs[2 * (size_t)blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        slabs[2 * (size_t)blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+__global__ void k_ransac_rmse_final(const double* __restrict__ slabs, int nblocks, double* __restrict__ out2) {
+    __shared__ double pe[256], pn[256];
+    double e = 0.0, n = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { e += slabs[2 * (size_t)b]; n += slabs[2 * (size_t)b + 1]; }
+    pe[threadIdx.x] = e; pn[threadIdx.x] = n;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { pe[threadIdx.x] += pe[threadIdx.x + off]; pn[threadIdx.x] += pn[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = pe[0]; out2[1] = pn[0]; }
+}
+
+int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
+                   const float* d_fs, const float* d_ft, const int* d_corr_in,
+                   float voxel, int max_iterations, float confidence, uint32_t seed,
+                   tdv_ransac_result* out, int* trace_inliers) {
+    if (!ctx || !out || ns < 0 || nt < 0 || max_iterations < 0) return TDV_ERR_BAD_ARG;
+    if (ns > 0 && (!d_src || !d_tgt)) return TDV_ERR_BAD_ARG;
+    if (!d_corr_in && ns > 0 && nt > 0 && (!d_fs || !d_ft)) return TDV_ERR_BAD_ARG;
+    TDV_HIP(ctx, hipSetDevice(ctx->device));
+    // RegistrationResult defaults (include/registration.hpp:26-30)
+    for (int i = 0; i < 16; ++i) out->T[i] = (i % 5 == 0) ? 1.f : 0.f;
+    out->fitness = 0.f; out->rmse = 0.f; out->inliers = 0; out->best_iteration = -1; out->iterations_run = 0;
+    if (ns == 0 || nt == 0 || max_iterations == 0) return TDV_OK;  // uniform_int over an empty range is UB in the reference
+    hipStream_t s = ctx->stream;
+    const float thr = voxel * 1.5f;  // registration.cpp:213
+    const float tau = tau_lt(thr);
+
+    const int* d_corr = d_corr_in;
+    if (!d_corr) {
+        int* c = nullptr;
+        TDV_TRY(ws_alloc(ctx, (size_t)ns, &c));
+        TDV_TRY(feature_match_dev(ctx, d_fs, ns, d_ft, nt, c));
+        d_corr = c;
+    }
+    const int ns_pad = (int)align_up((size_t)ns, (size_t)RS_PCH * 64);
+    float* pq = nullptr;
+    TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 8, &pq));
+    k_gather_pq<<<(ns_pad + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, ns, ns_pad, pq);
+    TDV_CHECK_LAUNCH(ctx);
+
+    // batch size: enough hypotheses to fill the chip, bounded for early exit granularity
+    const int batch = std::min(std::max(max_iterations, 1), 16384);
+    const int h_pad = (int)align_up((size_t)batch, RS_HYP_PER_BLOCK);
+    const int hblocks = h_pad / RS_HYP_PER_BLOCK;
+    const int n_pchunks = ns_pad / RS_PCH;
+    int want = (4096 + hblocks - 1) / hblocks;
+    int psplit = std::max(1, std::min(std::min(want, std::max(1, n_pchunks / 64)), 256));
+    int pchunks_per_split = (n_pchunks + psplit - 1) / psplit;
+    psplit = (n_pchunks + pchunks_per_split - 1) / pchunks_per_split;
+
+    float* hyp = nullptr; int* counts = nullptr; int4* d_tri = nullptr; double* slabs = nullptr; double* d_out2 = nullptr; float* d_best12 = nullptr;
+    TDV_TRY(ws_alloc(ctx, (size_t)12 * h_pad, &hyp));
+    TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &counts));
+    TDV_TRY(ws_alloc(ctx, (size_t)batch, &d_tri));
+    const int rblocks = (ns + 255) / 256;
+    TDV_TRY(ws_alloc(ctx, (size_t)2 * rblocks, &slabs));
+    TDV_TRY(ws_alloc(ctx, 2, &d_out2));
+    TDV_TRY(ws_alloc(ctx, 12, &d_best12));
+    // pinned: triples (int4 * batch) | counts (int * batch) | best12 (12 floats) | out2 (2 doubles)
+    const size_t pin_tri = 0, pin_cnt = align_up((size_t)batch * 16, 64), pin_b12 = pin_cnt + align_up((size_t)batch * 4, 64),
+                 pin_o2 = pin_b12 + 64, pin_total = pin_o2 + 64;
+    TDV_TRY(pin_reserve(ctx, pin_total));
+    int4* h_tri = reinterpret_cast<int4*>(ctx->pin + pin_tri);
+    int* h_cnt = reinterpret_cast<int*>(ctx->pin + pin_cnt);
+    float* h_b12 = reinterpret_cast<float*>(ctx->pin + pin_b12);
+    double* h_o2 = reinterpret_cast<double*>(ctx->pin + pin_o2);
+
+    // the index stream is sequential over the whole run: generate all draws up front (3 per iteration)
+    std::vector<uint64_t> draws((size_t)max_iterations * 3);
+    mt19937_lemire_triples(seed, (uint64_t)ns, max_iterations, draws.data());
+
+    float best_fitness = 0.f; int best_iter = -1, best_inliers = 0; bool stop = false;
+    int done_iters = 0;
+    for (int it0 = 0; it0 < max_iterations && !stop; it0 += batch) {
+        const int cnt = std::min(batch, max_iterations - it0);
+        for (int k = 0; k < cnt; ++k) {
+            uint64_t a = draws[3 * (size_t)(it0 + k)], b = draws[3 * (size_t)(it0 + k) + 1], c = draws[3 * (size_t)(it0 + k) + 2];
+            int valid = !(a == b || b == c || a == c);  // registration.cpp:240
+            h_tri[k] = make_int4((int)a, (int)b, (int)c, valid);
+        }
+        TDV_HIP(ctx, hipMemcpyAsync(d_tri, h_tri, (size_t)cnt * 16, hipMemcpyHostToDevice, s));
+        TDV_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)h_pad * 4, s));
+        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri, cnt, h_pad, hyp);
+        const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
+        {
+            ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
+            k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp, h_pad, pq, n_pchunks, pchunks_per_split, tau, counts);
+        }
+        TDV_CHECK_LAUNCH(ctx);
+        TDV_HIP(ctx, hipMemcpyAsync(h_cnt, counts, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        int batch_best = -1;
+        for (int k = 0; k < cnt; ++k) {
+            done_iters = it0 + k + 1;
+            if (!h_tri[k].w) { if (trace_inliers) trace_inliers[it0 + k] = -1; continue; }
+            int inl = h_cnt[k];
+            if (trace_inliers) trace_inliers[it0 + k] = inl;
+            float fitness = static_cast<float>(inl) / static_cast<float>((size_t)ns);  // registration.cpp:281
+            if (fitness > best_fitness) { best_fitness = fitness; best_iter = it0 + k; best_inliers = inl; batch_best = k; }
+            if (fitness > confidence) { stop = true; break; }
+        }
+        if (batch_best >= 0) {  // keep the winning (R,t) of this batch before hyp is overwritten
+            TDV_HIP(ctx, hipMemcpy2DAsync(d_best12, 4, hyp + batch_best, (size_t)h_pad * 4, 4, 12, hipMemcpyDeviceToDevice, s));
+        }
+    }
+    out->iterations_run = done_iters;
+    if (best_iter >= 0) {
+        k_ransac_rmse_partial<<<rblocks, 256, 0, s>>>(pq, ns, d_best12, tau, slabs);
+        k_ransac_rmse_final<<<1, 256, 0, s>>>(slabs, rblocks, d_out2);
+        TDV_CHECK_LAUNCH(ctx);
+        TDV_HIP(ctx, hipMemcpyAsync(h_b12, d_best12, 48, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipMemcpyAsync(h_o2, d_out2, 16, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) out->T[c * 4 + r] = h_b12[c * 3 + r];
+        out->T[12] = h_b12[9]; out->T[13] = h_b12[10]; out->T[14] = h_b12[11];
+        out->fitness = best_fitness;
+        out->inliers = best_inliers;
+        out->best_iteration = best_iter;
+        // registration.cpp:282 (float total_error / int inliers)
+        out->rmse = best_inliers > 0 ? std::sqrt((float)h_o2[0] / (float)best_inliers) : 999.0f;
+        if ((int)(h_o2[1] + 0.5) != best_inliers) {
+            snprintf(ctx->err, sizeof(ctx->err), "ransac: rmse pass counted %d inliers, scoring pass %d", (int)(h_o2[1] + 0.5), best_inliers);
+            return TDV_ERR_INTERNAL;
+        }
+    }
+    return TDV_OK;
+}
+
+}  // namespace tdv

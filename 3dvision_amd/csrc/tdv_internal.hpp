@@ -1,0 +1,117 @@
+// Internal definitions of the MI355X registration backend (not part of the C ABI).
+// One tdv_ctx = one HIP stream + a grow-only device workspace + pinned staging + optional
+// per-kernel HIP-event timers.  Steady state performs no hipMalloc.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "tdv_hip.h"
+
+namespace tdv {
+
+struct TimerSlot {
+    double total_ms = 0.0;
+    int launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace tdv
+
+struct tdv_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device workspace: a list of blocks; coalesced into one block at the next reset when it grew
+    struct Block { char* p; size_t cap; };
+    std::vector<Block> blocks;
+    size_t cur_block = 0, cur_off = 0, high_water = 0, used_total = 0;
+    // pinned host staging
+    char* pin = nullptr;
+    size_t pin_cap = 0;
+    char err[512] = {0};
+    bool timing = false;
+    tdv::TimerSlot timers[TDV_TIMER_COUNT];
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace tdv {
+
+inline int set_err(tdv_ctx* ctx, hipError_t e, const char* what, int line) {
+    if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s failed at line %d: %s", what, line, hipGetErrorString(e));
+    if (e == hipErrorOutOfMemory) return TDV_ERR_OOM;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice) return TDV_ERR_NO_DEVICE;
+    return TDV_ERR_LAUNCH;
+}
+
+#define TDV_HIP(ctx, call)                                              \
+    do {                                                                \
+        hipError_t e__ = (call);                                        \
+        if (e__ != hipSuccess) return tdv::set_err((ctx), e__, #call, __LINE__); \
+    } while (0)
+
+#define TDV_TRY(expr)                    \
+    do {                                 \
+        int s__ = (expr);                \
+        if (s__ != TDV_OK) return s__;   \
+    } while (0)
+
+#define TDV_CHECK_LAUNCH(ctx) TDV_HIP((ctx), hipGetLastError())
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Workspace: reset at the start of every public entry point.
+int ws_reset(tdv_ctx* ctx);
+int ws_alloc_bytes(tdv_ctx* ctx, size_t bytes, void** out);
+template <class T>
+inline int ws_alloc(tdv_ctx* ctx, size_t count, T** out) {
+    void* p = nullptr;
+    int s = ws_alloc_bytes(ctx, count * sizeof(T), &p);
+    *out = static_cast<T*>(p);
+    return s;
+}
+int pin_reserve(tdv_ctx* ctx, size_t bytes);
+
+// Timing helpers: bracket a launch with events when ctx->timing is on.
+struct ScopedTimer {
+    tdv_ctx* ctx; int slot; hipEvent_t a = nullptr, b = nullptr;
+    ScopedTimer(tdv_ctx* c, int s);
+    ~ScopedTimer();
+};
+
+// ------------------------------------------------------------------ device pipelines
+struct IcpOutputs {  // optional per-source outputs of one correspondence pass (device pointers)
+    int* corr = nullptr; float* d2 = nullptr; uint8_t* accepted = nullptr;
+};
+int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
+                const float* T0, float thr, int max_iterations, int point_to_plane, int fixed_iterations,
+                tdv_icp_result* out);
+int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
+                            const float* T, float thr, IcpOutputs outs, int* n_corr);
+int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
+                   const float* d_fs, const float* d_ft, const int* d_corr,
+                   float voxel, int max_iterations, float confidence, uint32_t seed,
+                   tdv_ransac_result* out, int* trace_inliers);
+int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr);
+int depth_preprocess_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, int w, int h, float scale,
+                         int mask_mode, float* d_out);
+int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth_f32, const uint8_t* d_mask,
+                       const uint8_t* d_bgr, int w, int h, float scale, int mask_mode,
+                       float fx, float fy, float cx, float cy, float zmax,
+                       float* d_xyz, float* d_rgb, int capacity, int* n_out);
+int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* d_normals, int* d_knn);
+int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
+                     float* d_desc, int* d_nbr, int* d_nbr_cnt);
+int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
+                         const float* h_xyz_for_reference_order, float* d_out_xyz, float* d_out_rgb, int capacity,
+                         int* n_out);
+
+// host helpers
+void mt19937_lemire_triples(uint32_t seed, uint64_t n, int count, uint64_t* out);
+// largest float f with sqrtf(f) <= thr  (accept  <=>  d2 <= f  <=>  !(sqrtf(d2) > thr))
+float tau_le(float thr);
+// smallest float f with sqrtf(f) >= thr (inlier <=>  d2 < f   <=>  sqrtf(d2) < thr)
+float tau_lt(float thr);
+
+}  // namespace tdv

@@ -1,0 +1,290 @@
+// Voxel-grid downsample on gfx950 (HBM-bound: 24 B in + 24 B out per point, plus the sort).
+//
+// Replaces Registration::voxelDownsample (/root/reference/src/registration.cpp:29-60; key/hash
+// :15-27), which has no GPU entry point in the reference (src/pipeline.cpp:92 calls the CPU static).
+// Semantics kept: key = (int)floor(p * (1/voxel)) per axis; per-voxel mean = f32 sum of the member
+// points IN ASCENDING INPUT INDEX divided by float(count); colours likewise; normals dropped.
+//
+// The reference groups with std::unordered_map and emits voxels in that container's iteration
+// order.  Here grouping is a sort, which is deterministic and needs no atomics:
+//   1. k_voxel_records   : record (kx, ky, kz, idx) per point
+//   2. bitonic sort      : ascending by (kx, ky, kz, idx) as unsigned words — members of a voxel
+//                          become one run, in ascending input index (LDS-tiled local passes,
+//                          global passes only for strides >= the 2048-record tile)
+//   3. k_voxel_heads     : run heads; a run's first record carries the voxel's smallest index
+//   4. exclusive scan    : rank of every leader index = voxel position in FIRST-OCCURRENCE order
+//   5. k_voxel_means     : one lane per run, sequential sum in run order -> mean -> out[rank]
+// TDV_VOXEL_ORDER_FIRST stops here.  TDV_VOXEL_ORDER_REFERENCE additionally replays the
+// reference's container on the host (same key, same hash, std::unordered_map of this libstdc++)
+// to obtain its iteration order as a list of leader indices, and permutes the means on the device.
+#include "tdv_internal.hpp"
+#include <cmath>
+#include <unordered_map>
+#include <vector>
+#include <algorithm>
+
+namespace tdv {
+
+constexpr int BT_TILE = 2048;     // records per LDS tile (32 KB)
+constexpr int BT_THREADS = 1024;  // one compare-exchange per thread per pass
+
+__device__ __forceinline__ bool rec_less(const uint4& a, const uint4& b) {
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.z != b.z) return a.z < b.z;
+    return a.w < b.w;
+}
+
+__global__ void k_voxel_records(const float* __restrict__ xyz, int n, int n_pow2, float inv, uint4* __restrict__ rec) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    uint4 r;
+    if (i < n) {
+        r.x = (unsigned)(int)floorf(xyz[3 * i] * inv);
+        r.y = (unsigned)(int)floorf(xyz[3 * i + 1] * inv);
+        r.z = (unsigned)(int)floorf(xyz[3 * i + 2] * inv);
+        r.w = (unsigned)i;
+    } else {
+        r = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);  // padding sorts last
+    }
+    rec[i] = r;
+}
+
+__device__ __forceinline__ void cmpxchg(uint4& a, uint4& b, bool ascending) {
+    bool sw = ascending ? rec_less(b, a) : rec_less(a, b);
+    if (sw) { uint4 t = a; a = b; b = t; }
+}
+
+// full bitonic sort of each 2048-record tile (all k <= BT_TILE)
+__global__ __launch_bounds__(BT_THREADS)
+void k_bitonic_local_sort(uint4* __restrict__ rec) {
+    __shared__ uint4 s[BT_TILE];
+    const size_t base = (size_t)blockIdx.x * BT_TILE;
+    const int t = threadIdx.x;
+    s[t] = rec[base + t]; s[t + BT_THREADS] = rec[base + t + BT_THREADS];
+    __syncthreads();
+    for (int k = 2; k <= BT_TILE; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            int i = ((t / j) * (j << 1)) + (t % j);
+            bool asc = (((base + i) & (size_t)k) == 0);
+            cmpxchg(s[i], s[i + j], asc);
+            __syncthreads();
+        }
+    }
+    rec[base + t] = s[t]; rec[base + t + BT_THREADS] = s[t + BT_THREADS];
+}
+
+// one global compare-exchange pass (stride j >= BT_TILE)
+__global__ __launch_bounds__(256)
+void k_bitonic_global_step(uint4* __restrict__ rec, size_t n_pairs, unsigned k, unsigned j) {
+    size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_pairs) return;
+    size_t i = ((t / j) * ((size_t)j << 1)) + (t % j);
+    uint4 a = rec[i], b = rec[i + j];
+    bool asc = ((i & (size_t)k) == 0);
+    bool sw = asc ? rec_less(b, a) : rec_less(a, b);
+    if (sw) { rec[i] = b; rec[i + j] = a; }
+}
+
+// all passes with stride < BT_TILE of merge stage k, inside LDS
+__global__ __launch_bounds__(BT_THREADS)
+void k_bitonic_local_merge(uint4* __restrict__ rec, unsigned k) {
+    __shared__ uint4 s[BT_TILE];
+    const size_t base = (size_t)blockIdx.x * BT_TILE;
+    const int t = threadIdx.x;
+    s[t] = rec[base + t]; s[t + BT_THREADS] = rec[base + t + BT_THREADS];
+    __syncthreads();
+    for (int j = BT_TILE >> 1; j > 0; j >>= 1) {
+        int i = ((t / j) * (j << 1)) + (t % j);
+        bool asc = (((base + i) & (size_t)k) == 0);
+        cmpxchg(s[i], s[i + j], asc);
+        __syncthreads();
+    }
+    rec[base + t] = s[t]; rec[base + t + BT_THREADS] = s[t + BT_THREADS];
+}
+
+// leader[idx] = 1 for the smallest input index of each voxel
+__global__ void k_voxel_heads(const uint4* __restrict__ rec, int n, int* __restrict__ leader) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint4 r = rec[p];
+    bool head = true;
+    if (p > 0) { uint4 q = rec[p - 1]; head = !(q.x == r.x && q.y == r.y && q.z == r.z); }
+    if (head) leader[r.w] = 1;
+}
+
+// exclusive scan of n ints: per-block (1024) reduce, single-block scan of the sums, local scan
+__global__ __launch_bounds__(1024)
+void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums) {
+    __shared__ int w[16];
+    int i = blockIdx.x * 1024 + threadIdx.x;
+    int v = i < n ? in[i] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { int s = 0; for (int k = 0; k < 16; ++k) s += w[k]; sums[blockIdx.x] = s; }
+}
+__global__ __launch_bounds__(1024)
+void k_scan_sums(int* __restrict__ sums, int nblocks, int* __restrict__ total) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        int i = b0 + threadIdx.x;
+        int v = i < nblocks ? sums[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        int carry = carry_s;
+        if (i < nblocks) sums[i] = carry + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+__global__ __launch_bounds__(1024)
+void k_scan_local(const int* __restrict__ in, int n, const int* __restrict__ sums, int* __restrict__ out) {
+    __shared__ int wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int i = blockIdx.x * 1024 + threadIdx.x;
+    int v = i < n ? in[i] : 0;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wsum[w];
+    if (i < n) out[i] = sums[blockIdx.x] + wbase + incl - v;
+}
+
+// one lane per run head: sequential sum over the run (ascending input index), mean -> out[rank]
+__global__ __launch_bounds__(256)
+void k_voxel_means(const uint4* __restrict__ rec, int n, const float* __restrict__ xyz, const float* __restrict__ rgb,
+                   const int* __restrict__ rank, int capacity, float* __restrict__ out_xyz, float* __restrict__ out_rgb) {
+    int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    uint4 r = rec[p];
+    if (p > 0) { uint4 q = rec[p - 1]; if (q.x == r.x && q.y == r.y && q.z == r.z) return; }
+    const int slot = rank[r.w];
+    if (slot >= capacity) return;
+    float ax = 0.f, ay = 0.f, az = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    int cnt = 0;
+    for (int e = p; e < n; ++e) {
+        uint4 m = rec[e];
+        if (!(m.x == r.x && m.y == r.y && m.z == r.z)) break;
+        const unsigned idx = m.w;
+        ax += xyz[3 * (size_t)idx]; ay += xyz[3 * (size_t)idx + 1]; az += xyz[3 * (size_t)idx + 2];
+        if (rgb) { cr += rgb[3 * (size_t)idx]; cg += rgb[3 * (size_t)idx + 1]; cb += rgb[3 * (size_t)idx + 2]; }
+        ++cnt;
+    }
+    const float fn = (float)cnt;
+    out_xyz[3 * (size_t)slot] = ax / fn; out_xyz[3 * (size_t)slot + 1] = ay / fn; out_xyz[3 * (size_t)slot + 2] = az / fn;
+    if (rgb && out_rgb) { out_rgb[3 * (size_t)slot] = cr / fn; out_rgb[3 * (size_t)slot + 1] = cg / fn; out_rgb[3 * (size_t)slot + 2] = cb / fn; }
+}
+
+// out[p] = in[rank[order_first[p]]]
+__global__ void k_voxel_permute(const float* __restrict__ in_xyz, const float* __restrict__ in_rgb, const int* __restrict__ rank,
+                                const int* __restrict__ order_first, int v, float* __restrict__ out_xyz, float* __restrict__ out_rgb) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= v) return;
+    int s = rank[order_first[p]];
+    out_xyz[3 * (size_t)p] = in_xyz[3 * (size_t)s]; out_xyz[3 * (size_t)p + 1] = in_xyz[3 * (size_t)s + 1]; out_xyz[3 * (size_t)p + 2] = in_xyz[3 * (size_t)s + 2];
+    if (in_rgb && out_rgb) { out_rgb[3 * (size_t)p] = in_rgb[3 * (size_t)s]; out_rgb[3 * (size_t)p + 1] = in_rgb[3 * (size_t)s + 1]; out_rgb[3 * (size_t)p + 2] = in_rgb[3 * (size_t)s + 2]; }
+}
+
+namespace {
+struct VoxelKey {
+    int x, y, z;
+    bool operator==(const VoxelKey& o) const { return x == o.x && y == o.y && z == o.z; }
+};
+struct VoxelKeyHash {  // the reference's combiner (registration.cpp:20-27)
+    size_t operator()(const VoxelKey& k) const {
+        size_t h = std::hash<int>()(k.x);
+        h ^= std::hash<int>()(k.y) + 0x9e3779b9 + (h << 6) + (h >> 2);
+        h ^= std::hash<int>()(k.z) + 0x9e3779b9 + (h << 6) + (h >> 2);
+        return h;
+    }
+};
+}  // namespace
+
+int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
+                         const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out) {
+    if (!ctx || !n_out || n < 0 || capacity < 0 || !(voxel > 0.f) || (n > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
+    if (order == TDV_VOXEL_ORDER_REFERENCE && n > 0 && !h_xyz) return TDV_ERR_BAD_ARG;
+    *n_out = 0;
+    if (n == 0) return TDV_OK;
+    hipStream_t s = ctx->stream;
+    const float inv = 1.0f / voxel;  // registration.cpp:32
+    size_t n_pow2 = BT_TILE;
+    while (n_pow2 < (size_t)n) n_pow2 <<= 1;
+    uint4* rec; int *leader, *rank, *sums, *d_total;
+    TDV_TRY(ws_alloc(ctx, n_pow2, &rec));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &leader));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &rank));
+    const int sblocks = (n + 1023) / 1024;
+    TDV_TRY(ws_alloc(ctx, (size_t)sblocks, &sums));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_TRY(pin_reserve(ctx, 64));
+    ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
+    k_voxel_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, inv, rec);
+    const unsigned tiles = (unsigned)(n_pow2 / BT_TILE);
+    k_bitonic_local_sort<<<tiles, BT_THREADS, 0, s>>>(rec);
+    for (size_t k = (size_t)BT_TILE << 1; k <= n_pow2; k <<= 1) {
+        for (size_t j = k >> 1; j >= BT_TILE; j >>= 1)
+            k_bitonic_global_step<<<(unsigned)((n_pow2 / 2 + 255) / 256), 256, 0, s>>>(rec, n_pow2 / 2, (unsigned)k, (unsigned)j);
+        k_bitonic_local_merge<<<tiles, BT_THREADS, 0, s>>>(rec, (unsigned)k);
+    }
+    TDV_HIP(ctx, hipMemsetAsync(leader, 0, (size_t)n * 4, s));
+    k_voxel_heads<<<(n + 255) / 256, 256, 0, s>>>(rec, n, leader);
+    k_scan_reduce<<<sblocks, 1024, 0, s>>>(leader, n, sums);
+    k_scan_sums<<<1, 1024, 0, s>>>(sums, sblocks, d_total);
+    k_scan_local<<<sblocks, 1024, 0, s>>>(leader, n, sums, rank);
+    TDV_CHECK_LAUNCH(ctx);
+    int* h_total = reinterpret_cast<int*>(ctx->pin);
+    TDV_HIP(ctx, hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    const int v = *h_total;
+    *n_out = v;
+    if (v > capacity) return TDV_ERR_BAD_ARG;
+    if (order == TDV_VOXEL_ORDER_FIRST) {
+        k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, capacity, d_out_xyz, d_out_rgb);
+        TDV_CHECK_LAUNCH(ctx);
+        return TDV_OK;
+    }
+    // reference order: replay the container on the host to get its iteration order
+    float *tmp_xyz, *tmp_rgb = nullptr; int* d_order;
+    TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_xyz));
+    if (d_rgb && d_out_rgb) TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_rgb));
+    TDV_TRY(ws_alloc(ctx, (size_t)v, &d_order));
+    k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, v, tmp_xyz, tmp_rgb);
+    TDV_CHECK_LAUNCH(ctx);
+    std::unordered_map<VoxelKey, int, VoxelKeyHash> grid;
+    for (int i = 0; i < n; ++i) {
+        VoxelKey key{static_cast<int>(std::floor(h_xyz[3 * (size_t)i] * inv)),
+                     static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 1] * inv)),
+                     static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 2] * inv))};
+        grid.emplace(key, i);  // keeps the first index; inserts in first-occurrence order like grid[key]
+    }
+    if ((int)grid.size() != v) {
+        snprintf(ctx->err, sizeof(ctx->err), "voxel: host replay found %zu voxels, device %d", grid.size(), v);
+        return TDV_ERR_INTERNAL;
+    }
+    std::vector<int> order_first; order_first.reserve(v);
+    for (auto& kv : grid) order_first.push_back(kv.second);
+    TDV_HIP(ctx, hipMemcpyAsync(d_order, order_first.data(), (size_t)v * 4, hipMemcpyHostToDevice, s));
+    k_voxel_permute<<<(v + 255) / 256, 256, 0, s>>>(tmp_xyz, tmp_rgb, rank, d_order, v, d_out_xyz, d_out_rgb);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_HIP(ctx, hipStreamSynchronize(s));  // order_first is a host temporary
+    return TDV_OK;
+}
+
+}  // namespace tdv

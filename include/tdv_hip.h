@@ -1,0 +1,210 @@
+/*
+ * tdv_hip.h — C ABI of the MI355X (gfx950) point-cloud registration backend.
+ *
+ * This is the drop-in boundary: the thin extern "C" dispatch layer that replaces the
+ * reference's CUDA dispatch TU src/gpu_impl.cpp and its launcher set in cuda/ (the .cuh headers)
+ * (launchDepthPreprocess, launchDeproject, launchFindCorrespondences,
+ * launchBuildLinearSystem).  The C++ adapter in 3dvision_amd/host/ defines the reference's
+ * operator API (include/gpu_depth.hpp:9-22, include/gpu_registration.hpp:8-19,
+ * include/registration.hpp:32-60) on top of these entry points; INTEGRATION.md shows the
+ * binding a maintainer adds.
+ *
+ * Conventions
+ *  - Every function returns a tdv_status (0 = ok, negative = error); nothing throws.
+ *  - A tdv_ctx owns one HIP stream, a grow-only device workspace and pinned staging; it is
+ *    NOT thread-safe: use one ctx per host thread (the reference calls its GPU ops from up to
+ *    8 pool threads, include/thread_pool.hpp:17-33 / src/pipeline.cpp:321-327).
+ *  - Host entry points take caller-owned host buffers; "_dev" entry points take device
+ *    pointers valid on the ctx's device and enqueue on the ctx's stream.
+ *  - Clouds are AoS float[n*3] (bit-identical to std::vector<Eigen::Vector3f>::data()),
+ *    FPFH is float[n*33] (std::vector<std::array<float,33>>::data()),
+ *    4x4 transforms are COLUMN-MAJOR float[16] (Eigen::Matrix4f::data()).
+ *  - Results follow the reference's CPU path src/registration.cpp (the parity oracle), not its
+ *    CUDA kernels, where the two differ.
+ */
+#ifndef TDV_HIP_H
+#define TDV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tdv_ctx tdv_ctx;
+
+typedef enum tdv_status {
+    TDV_OK = 0,
+    TDV_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime failure at init                   */
+    TDV_ERR_BAD_ARG = -2,     /* null pointer, negative size, capacity too small               */
+    TDV_ERR_OOM = -3,         /* device or pinned allocation failed                            */
+    TDV_ERR_LAUNCH = -4,      /* kernel launch / stream / copy failure (hipGetLastError)       */
+    TDV_ERR_INTERNAL = -5
+} tdv_status;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* Replaces GPUDepth::isCudaAvailable / GPURegistration::isCudaAvailable (src/gpu_impl.cpp:18-26,
+ * 131-139): *count = number of HIP devices (0 when none; still TDV_OK). */
+int tdv_device_count(int* count);
+int tdv_ctx_create(int device, tdv_ctx** out);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
+int tdv_ctx_set_stream(tdv_ctx* ctx, void* hip_stream);
+void* tdv_ctx_get_stream(tdv_ctx* ctx);
+int tdv_ctx_synchronize(tdv_ctx* ctx);
+void tdv_ctx_destroy(tdv_ctx* ctx);
+const char* tdv_status_string(int status);
+/* Text of the last HIP error seen by this ctx ("" if none). */
+const char* tdv_last_error(tdv_ctx* ctx);
+const char* tdv_version(void);
+
+/* Kernel timing (HIP events on the ctx's stream around the dominant kernels).  Slots:
+ * 0 = ICP nearest-neighbour scan, 1 = RANSAC scoring, 2 = feature match, 3 = kNN scan,
+ * 4 = radius scan, 5 = depth+unproject, 6 = voxel.  Enabling adds one event pair per launch. */
+#define TDV_TIMER_ICP_NN 0
+#define TDV_TIMER_RANSAC_SCORE 1
+#define TDV_TIMER_FEATURE_MATCH 2
+#define TDV_TIMER_KNN 3
+#define TDV_TIMER_RADIUS 4
+#define TDV_TIMER_DEPTH 5
+#define TDV_TIMER_VOXEL 6
+#define TDV_TIMER_COUNT 8
+int tdv_timing_enable(tdv_ctx* ctx, int on);
+/* Synchronizes the stream, then returns accumulated milliseconds and launch count; resets the slot. */
+int tdv_timing_read(tdv_ctx* ctx, int slot, double* total_ms, int* launches);
+
+/* ---- R1: depth scale + mask --------------------------------------------------------------- */
+/* Replaces GPUDepth::preprocess (src/gpu_impl.cpp:28-66, kernel cuda/depth_processing.cu:10-30);
+ * oracle = the CPU branch src/pipeline.cpp:46-54.
+ * out[i] = float(raw[i]) * float(1.0 / scale); zeroed where the mask rejects the pixel.
+ * mask may be NULL (no masking).  mask_mode: 0 = reference CPU semantics (keep mask > 10),
+ * 1 = reference CUDA semantics (keep mask != 0). */
+#define TDV_MASK_THRESHOLD10 0
+#define TDV_MASK_NONZERO 1
+int tdv_depth_preprocess(tdv_ctx* ctx, const uint16_t* raw, const uint8_t* mask, int width, int height,
+                         float scale, int mask_mode, float* out_depth);
+
+/* ---- R2: unprojection --------------------------------------------------------------------- */
+/* Replaces GPUPointCloud::generate (src/gpu_impl.cpp:69-128, kernel cuda/pointcloud.cu:11-51);
+ * oracle = src/pipeline.cpp:61-84.  Keeps 0 < z <= zmax, x = (u-cx)*z/fx, y = (v-cy)*z/fy,
+ * colour = BGR->RGB / 255.  Output order is the CPU's ROW-MAJOR scan order (deterministic; the
+ * reference CUDA kernel's global-atomic order is not reproduced).  bgr / out_rgb may be NULL.
+ * capacity = room in out_xyz/out_rgb in points; *n_out = points produced (TDV_ERR_BAD_ARG and
+ * *n_out set to the needed count if capacity is too small). */
+int tdv_deproject(tdv_ctx* ctx, const float* depth, const uint8_t* bgr, int width, int height,
+                  float fx, float fy, float cx, float cy, float zmax,
+                  float* out_xyz, float* out_rgb, int capacity, int* n_out);
+/* Fused R1+R2 (one pass over the frame, no intermediate depth image on the host). */
+int tdv_depth_to_cloud(tdv_ctx* ctx, const uint16_t* raw, const uint8_t* mask, const uint8_t* bgr,
+                       int width, int height, float scale, int mask_mode,
+                       float fx, float fy, float cx, float cy, float zmax,
+                       float* out_xyz, float* out_rgb, int capacity, int* n_out);
+
+/* ---- R3: voxel downsample ----------------------------------------------------------------- */
+/* Replaces Registration::voxelDownsample (src/registration.cpp:29-60).  Per-voxel mean of points
+ * (and colours) summed in ascending input index, divided by the count; normals are dropped.
+ * order: TDV_VOXEL_ORDER_FIRST = voxels ordered by their smallest input index (deterministic,
+ * computed on the GPU); TDV_VOXEL_ORDER_REFERENCE = libstdc++ std::unordered_map iteration order
+ * of the reference (the slot order is replayed on the host with the reference's hash,
+ * registration.cpp:20-27; the means are still computed on the GPU). */
+#define TDV_VOXEL_ORDER_FIRST 0
+#define TDV_VOXEL_ORDER_REFERENCE 1
+int tdv_voxel_downsample(tdv_ctx* ctx, const float* xyz, const float* rgb, int n, float voxel_size, int order,
+                         float* out_xyz, float* out_rgb, int capacity, int* n_out);
+
+/* ---- R4a: normals ------------------------------------------------------------------------- */
+/* Replaces Registration::estimateNormals (src/registration.cpp:105-130): exact brute-force kNN
+ * ((d2, idx) lexicographic order, self included), PCA normal, flipped towards the origin.
+ * out_knn (optional, int[n*k], -1 padded) receives the neighbour lists. */
+int tdv_estimate_normals(tdv_ctx* ctx, const float* xyz, int n, int k, float* out_normals, int* out_knn);
+
+/* ---- R4b: FPFH ---------------------------------------------------------------------------- */
+/* Replaces Registration::computeFPFH (src/registration.cpp:133-201): radius search d2 <= r^2,
+ * (d2, idx) order, capped at 100 neighbours; SPFH + weighted FPFH, 33 bins. */
+int tdv_compute_fpfh(tdv_ctx* ctx, const float* xyz, const float* normals, int n, float radius,
+                     float* out_desc33, int* out_nbr /* optional int[n*100] */, int* out_nbr_cnt /* optional int[n] */);
+
+/* ---- R5: RANSAC --------------------------------------------------------------------------- */
+/* Feature correspondences of src/registration.cpp:216-232: argmin_j sum_d (fs[i][d]-ft[j][d])^2,
+ * accumulated in d order, strict <, lowest j on ties. */
+int tdv_feature_match(tdv_ctx* ctx, const float* fs, int ns, const float* ft, int nt, int* out_corr);
+
+typedef struct tdv_ransac_result {
+    float T[16];        /* column-major; identity if no hypothesis ever had an inlier            */
+    float fitness;      /* inliers / ns of the winning hypothesis (0 if none)                    */
+    float rmse;
+    int inliers;        /* inlier count of the winning hypothesis                                 */
+    int best_iteration; /* iteration index that produced it (-1 if none)                          */
+    int iterations_run; /* iterations consumed, including skipped (degenerate-triple) ones        */
+} tdv_ransac_result;
+
+/* Replaces Registration::ransacRegistration (src/registration.cpp:204-295).  corr may be NULL
+ * (then fs/ft are matched first) or a precomputed int[ns] (then fs/ft may be NULL).
+ * Index triples come from mt19937(seed) + libstdc++-11 uniform_int_distribution<size_t>
+ * (Lemire), iteration semantics (skip on repeated index, strict-> best, early exit on
+ * fitness > confidence) as the reference.  seed = 42 reproduces registration.cpp:235.
+ * trace_inliers (optional int[max_iterations]): per-iteration inlier count, -1 = skipped. */
+int tdv_ransac(tdv_ctx* ctx, const float* src, int ns, const float* tgt, int nt,
+               const float* fs, const float* ft, const int* corr,
+               float voxel_size, int max_iterations, float confidence, uint32_t seed,
+               tdv_ransac_result* out, int* trace_inliers);
+
+/* ---- R6: ICP ------------------------------------------------------------------------------ */
+typedef struct tdv_icp_result {
+    float T[16];     /* column-major */
+    float fitness;
+    float rmse;
+    int iterations;  /* iterations whose update was applied */
+    int n_corr;      /* accepted correspondences of the last applied iteration */
+} tdv_icp_result;
+
+/* Replaces GPURegistration::icpRefine (src/gpu_impl.cpp:141-260, kernels cuda/icp.cu:14-55,90-142)
+ * and Registration::icpRefine (src/registration.cpp:297-414, the oracle).  tgt_normals may be NULL;
+ * point-to-plane is used iff point_to_plane != 0 and tgt_normals != NULL, else point-to-point
+ * Kabsch (registration.cpp:343,365).  The whole loop runs on the device; the host polls a
+ * convergence flag every few iterations. */
+int tdv_icp(tdv_ctx* ctx, const float* src, int ns, const float* tgt, const float* tgt_normals, int nt,
+            const float* T0, float distance_threshold, int max_iterations, int point_to_plane,
+            tdv_icp_result* out);
+
+/* One correspondence pass for a given T (registration.cpp:325-359): nearest target index per
+ * source (always written), its squared distance, and the accepted flag; n_corr = accepted count.
+ * Exposed for parity tests. */
+int tdv_icp_correspondences(tdv_ctx* ctx, const float* src, int ns, const float* tgt, int nt,
+                            const float* T, float distance_threshold,
+                            int* out_corr, float* out_d2, uint8_t* out_accepted, int* out_n_corr);
+
+/* ---- device-resident entry points (inputs already in HBM; used by bench.py and by batched callers)
+ * All pointers are device pointers on the ctx's device; work is enqueued on the ctx's stream and
+ * the call returns after the stream has been synchronized (results are host structs). ------------ */
+/* fixed_iterations != 0: run exactly max_iterations iterations (convergence and the n_corr<3 break
+ * are still evaluated on the device and reported, but do not stop the loop) — benchmarking only. */
+int tdv_icp_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
+                const float* T0, float distance_threshold, int max_iterations, int point_to_plane,
+                int fixed_iterations, tdv_icp_result* out);
+int tdv_ransac_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
+                   const float* d_fs, const float* d_ft, const int* d_corr,
+                   float voxel_size, int max_iterations, float confidence, uint32_t seed,
+                   tdv_ransac_result* out, int* trace_inliers /* host, optional */);
+int tdv_feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr);
+int tdv_estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* d_normals, int* d_knn);
+int tdv_compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
+                         float* d_desc33, int* d_nbr, int* d_nbr_cnt);
+int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, const uint8_t* d_bgr,
+                           int width, int height, float scale, int mask_mode,
+                           float fx, float fy, float cx, float cy, float zmax,
+                           float* d_xyz, float* d_rgb, int capacity, int* n_out /* host */);
+int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel_size,
+                             float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out /* host */);
+
+/* ---- host-side helpers that are part of the path's semantics -------------------------------- */
+/* The RANSAC index stream: count triples from mt19937(seed) + Lemire uniform over [0, n-1]
+ * (src/registration.cpp:235-239 on libstdc++ 11).  Own implementation, no <random>. */
+int tdv_sample_triples(uint32_t seed, uint64_t n, int count, uint64_t* out_triples);
+/* Pose composition of src/pipeline.cpp:136-137: out = extrinsics * inverse(T). */
+int tdv_pose_compose(const float* extrinsics, const float* T, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDV_HIP_H */

@@ -1,0 +1,42 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def tdv():
+    """The product package (directory name starts with a digit -> importlib)."""
+    return importlib.import_module("3dvision_amd")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("3dvision_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure)."""
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def ctx(tdv):
+    """One backend context on GPU 0.  Fails loudly (no fallback) when the library or GPU is missing."""
+    assert os.path.exists(tdv.LIB_PATH), "lib3dvision_hip.so not built; run __graft_entry__.build()"
+    assert tdv.device_count() > 0, "no HIP device visible"
+    c = tdv.Context(0)
+    yield c
+    c.close()

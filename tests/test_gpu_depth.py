@@ -1,0 +1,84 @@
+"""R1/R2 parity: depth scale+mask and unprojection through the C ABI vs the CPU oracle
+(reference src/pipeline.cpp:46-54, :61-84).  Bar: bit-exact values AND row-major order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_frame(seed, h=97, w=131):
+    rng = np.random.default_rng(seed)
+    raw = rng.integers(0, 3000, (h, w)).astype(np.uint16)
+    raw[rng.random((h, w)) < 0.2] = 0
+    mask = rng.choice(np.array([0, 1, 5, 10, 11, 12, 128, 255], np.uint8), (h, w))
+    bgr = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    return raw, mask, bgr
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_depth_preprocess_bit_exact(ctx, orc, tdv, seed):
+    raw, mask, _ = _random_frame(seed)
+    for scale in (1000.0, 999.0, 4000.0):
+        got = ctx.depth_preprocess(raw, mask, scale)
+        ref = orc.depth_preprocess(raw, mask, scale)
+        assert got.tobytes() == ref.tobytes()
+        got = ctx.depth_preprocess(raw, None, scale)
+        assert got.tobytes() == orc.depth_preprocess(raw, None, scale).tobytes()
+    # reference CUDA semantics (mask != 0) are selectable and differ only for mask values 1..10
+    got = ctx.depth_preprocess(raw, mask, 1000.0, tdv.TDV_MASK_NONZERO)
+    ref = raw.astype(np.float32) * np.float32(1.0 / 1000.0)
+    ref[mask == 0] = 0
+    assert got.tobytes() == ref.tobytes()
+
+
+def test_depth_preprocess_odd_sizes(ctx, orc):
+    for (h, w) in [(1, 1), (1, 3), (7, 5), (33, 1023), (720, 1280)]:
+        rng = np.random.default_rng(h * 10007 + w)
+        raw = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+        mask = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        assert ctx.depth_preprocess(raw, mask, 1000.0).tobytes() == orc.depth_preprocess(raw, mask, 1000.0).tobytes()
+
+
+def test_demo_scene_cloud(ctx, orc):
+    """Config C1 (demo scene, src/pipeline.cpp:211-257): 40,401 points in row-major order."""
+    depth, bgr = orc.demo_scene()
+    mask = orc.demo_mask()
+    d_ref = orc.depth_preprocess(depth, mask, 1000.0)
+    xyz_ref, rgb_ref = orc.unproject(d_ref, bgr, 900, 900, 640, 360, 1.5)
+    assert len(xyz_ref) == 40401
+    d = ctx.depth_preprocess(depth, mask, 1000.0)
+    assert d.tobytes() == d_ref.tobytes()
+    xyz, rgb = ctx.deproject(d, bgr, 900, 900, 640, 360, 1.5)
+    assert xyz.tobytes() == xyz_ref.tobytes() and rgb.tobytes() == rgb_ref.tobytes()
+    xyz2, rgb2 = ctx.depth_to_cloud(depth, mask, bgr, 1000.0, 900, 900, 640, 360, 1.5)
+    assert xyz2.tobytes() == xyz_ref.tobytes() and rgb2.tobytes() == rgb_ref.tobytes()
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_deproject_random(ctx, orc, seed):
+    raw, mask, bgr = _random_frame(seed, 211, 307)
+    d = orc.depth_preprocess(raw, mask, 1000.0)
+    for zmax in (1.5, 10.0, 0.5):
+        ref_xyz, ref_rgb = orc.unproject(d, bgr, 611.5, 609.25, 153.2, 101.7, zmax)
+        xyz, rgb = ctx.deproject(d, bgr, 611.5, 609.25, 153.2, 101.7, zmax)
+        assert xyz.tobytes() == ref_xyz.tobytes() and rgb.tobytes() == ref_rgb.tobytes()
+        xyz, rgb = ctx.depth_to_cloud(raw, mask, bgr, 1000.0, 611.5, 609.25, 153.2, 101.7, zmax)
+        assert xyz.tobytes() == ref_xyz.tobytes() and rgb.tobytes() == ref_rgb.tobytes()
+    # no colour image -> no colours (CPU branch semantics)
+    xyz, rgb = ctx.deproject(d, None, 611.5, 609.25, 153.2, 101.7, 1.5)
+    ref_xyz, _ = orc.unproject(d, None, 611.5, 609.25, 153.2, 101.7, 1.5)
+    assert rgb is None and xyz.tobytes() == ref_xyz.tobytes()
+
+
+def test_deproject_empty_and_capacity(ctx, orc, tdv):
+    d = np.zeros((16, 16), np.float32)
+    xyz, _ = ctx.deproject(d, None, 100, 100, 8, 8, 1.5)
+    assert len(xyz) == 0
+    d[:] = 1.0
+    with pytest.raises(tdv.TdvError):
+        ctx.deproject(d, None, 100, 100, 8, 8, 1.5, capacity=10)
+    # NaN depth is kept by the reference's test (z<=0 || z>max is false for NaN)
+    d[3, 4] = np.nan
+    xyz, _ = ctx.deproject(d, None, 100, 100, 8, 8, 1.5)
+    ref, _ = orc.unproject(d, None, 100, 100, 8, 8, 1.5)
+    assert len(xyz) == 256 and np.array_equal(np.isnan(xyz), np.isnan(ref))

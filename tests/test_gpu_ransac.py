@@ -1,0 +1,106 @@
+"""R5 parity: feature matching, hypothesis generation, inlier scoring and selection through the
+C ABI vs the CPU oracle (reference src/registration.cpp:204-295).
+Bar: correspondences exact; per-iteration inlier counts bit-exact; winner identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(synth, ns, nt, seed=42, good_frac=0.5):
+    """Scene/model pair with correspondences of which good_frac are true nearest matches."""
+    tgt, _ = synth.sample_object(nt, seed)
+    src, T_gt = synth.make_scene(ns, seed, outlier_frac=0.05)
+    rng = np.random.default_rng(seed)
+    p = src.astype(np.float64) @ T_gt[:3, :3].astype(np.float64).T + T_gt[:3, 3]
+    # true nearest target for a subset, random for the rest
+    corr = rng.integers(0, nt, ns).astype(np.int32)
+    good = rng.random(ns) < good_frac
+    idx = np.nonzero(good)[0]
+    for i0 in range(0, len(idx), 512):
+        blk = idx[i0:i0 + 512]
+        d = ((p[blk, None, :] - tgt[None, :, :].astype(np.float64)) ** 2).sum(-1)
+        corr[blk] = d.argmin(1)
+    return src, tgt, corr, T_gt
+
+
+@pytest.mark.parametrize("ns,nt", [(700, 500), (1, 1), (513, 64), (2100, 1111)])
+def test_feature_match_exact(ctx, orc, synth, ns, nt):
+    fs = synth.random_features(ns, 1)
+    ft = synth.random_features(nt, 2)
+    if nt > 10:
+        ft[7] = ft[3]  # duplicate descriptor: lowest index must win
+        fs[0] = ft[7]
+    assert np.array_equal(ctx.feature_match(fs, ft), orc.feature_match(fs, ft))
+
+
+def test_ransac_inlier_counts_bit_exact(ctx, orc, synth):
+    ns, nt = 3000, 2000
+    src, tgt, corr, T_gt = _case(synth, ns, nt)
+    voxel = 0.004
+    iters = 3000
+    ref = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=2.0, trace=True)
+    got = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=2.0, trace=True)
+    assert np.array_equal(got.trace_inliers, ref["inliers"]), np.nonzero(got.trace_inliers != ref["inliers"])[0][:10]
+    assert got.best_iteration == ref["best_iter"] and got.iterations_run == ref["iters_run"] == iters
+    assert got.fitness == ref["fitness"]
+    assert np.abs(got.transformation - ref["T"]).max() <= 1e-6
+    print("T bitwise equal:", got.transformation.tobytes() == ref["T"].tobytes(), "best inliers", got.inliers)
+    assert abs(float(got.rmse) - float(ref["rmse"])) <= 1e-7
+    assert got.inliers > 0.3 * ns  # the synthetic case is solvable
+    assert synth.rotation_angle(T_gt[:3, :3], got.transformation[:3, :3]) < 0.05
+
+
+def test_ransac_early_exit_and_skips(ctx, orc, synth):
+    """fitness > confidence stops the loop; repeated indices consume an iteration (registration.cpp:240,290)."""
+    ns, nt = 40, 30  # tiny cloud: many repeated-index triples
+    src, tgt, corr, T_gt = _case(synth, ns, nt, good_frac=1.0)
+    ref = orc.ransac(src, tgt, corr=corr, voxel=0.01, max_iterations=500, confidence=0.5, trace=True)
+    got = ctx.ransac(src, tgt, corr=corr, voxel=0.01, max_iterations=500, confidence=0.5, trace=True)
+    assert (ref["inliers"][:ref["iters_run"]] == -1).any()
+    assert got.iterations_run == ref["iters_run"] and got.best_iteration == ref["best_iter"]
+    n = ref["iters_run"]
+    assert np.array_equal(got.trace_inliers[:n], ref["inliers"][:n])
+    assert got.fitness == ref["fitness"]
+
+
+def test_ransac_no_inliers_returns_identity(ctx, orc, synth):
+    src, tgt, corr, _ = _case(synth, 300, 200, good_frac=0.0)
+    ref = orc.ransac(src, tgt, corr=corr, voxel=1e-7, max_iterations=50, confidence=0.999)
+    got = ctx.ransac(src, tgt, corr=corr, voxel=1e-7, max_iterations=50, confidence=0.999)
+    # a hypothesis always fits its own 3 sample points unless the threshold is below rounding noise
+    assert got.fitness == ref["fitness"] and got.best_iteration == ref["best_iter"]
+    assert np.abs(got.transformation - ref["T"]).max() <= 1e-6
+
+
+def test_ransac_with_feature_matching(ctx, orc, synth):
+    """Full entry point: features -> correspondences -> hypotheses, as ransacRegistration does."""
+    ns, nt = 900, 800
+    src, tgt, corr, T_gt = _case(synth, ns, nt, good_frac=0.6)
+    ft = synth.random_features(nt, 5)
+    fs = ft[corr].copy()  # descriptors that reproduce `corr` exactly
+    ref = orc.ransac(src, tgt, fs=fs, ft=ft, voxel=0.002, max_iterations=800, confidence=0.999, trace=True)
+    assert np.array_equal(ref["corr"], corr)
+    got = ctx.ransac(src, tgt, fs=fs, ft=ft, voxel=0.002, max_iterations=800, confidence=0.999, trace=True)
+    n = ref["iters_run"]
+    assert got.iterations_run == n and np.array_equal(got.trace_inliers[:n], ref["inliers"][:n])
+    assert got.best_iteration == ref["best_iter"]
+
+
+def test_ransac_full_size_properties(ctx, synth):
+    """BASELINE size (200k points): size-independent properties instead of the O(N^2) oracle:
+    counts are reproducible run to run, bounded by ns, and a hypothesis built from exact
+    correspondences of a noise-free rigid copy makes every point an inlier."""
+    ns = 200000
+    tgt, _ = synth.sample_object(ns, 7)
+    T = synth.gt_transform(7)
+    Tinv = np.linalg.inv(T.astype(np.float64))
+    src = (tgt.astype(np.float64) @ Tinv[:3, :3].T + Tinv[:3, 3]).astype(np.float32)
+    corr = np.arange(ns, dtype=np.int32)
+    a = ctx.ransac(src, tgt, corr=corr, voxel=0.001, max_iterations=2000, confidence=2.0, trace=True)
+    b = ctx.ransac(src, tgt, corr=corr, voxel=0.001, max_iterations=2000, confidence=2.0, trace=True)
+    assert np.array_equal(a.trace_inliers, b.trace_inliers)
+    valid = a.trace_inliers[a.trace_inliers >= 0]
+    assert valid.max() <= ns and valid.min() >= 3
+    assert a.inliers >= 0.99 * ns  # some well-spread triple recovers the rigid motion
+    assert synth.rotation_angle(T[:3, :3], a.transformation[:3, :3]) < 1e-3

@@ -1,0 +1,72 @@
+"""R3 parity: voxel downsample through the C ABI vs the CPU oracle (reference
+src/registration.cpp:29-60).  Bar: voxel count exact; per-voxel means bit-exact; in
+TDV_VOXEL_ORDER_REFERENCE the output ORDER equals the reference's unordered_map iteration order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_demo_cloud_reference_order(ctx, orc, tdv):
+    """Config C1: 40,401 masked pixels -> 32,129 voxels at 1 mm (1,476 at 5 mm), with colours."""
+    depth, bgr = orc.demo_scene()
+    d = orc.depth_preprocess(depth, orc.demo_mask(), 1000.0)
+    xyz, rgb = orc.unproject(d, bgr, 900, 900, 640, 360, 1.5)
+    for voxel, expect in ((0.001, 32129), (0.005, 1476)):
+        ref_xyz, ref_rgb, _ = orc.voxel_downsample(xyz, rgb, voxel)
+        assert len(ref_xyz) == expect
+        got_xyz, got_rgb = ctx.voxel_downsample(xyz, rgb, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
+        assert got_xyz.tobytes() == ref_xyz.tobytes()
+        assert got_rgb.tobytes() == ref_rgb.tobytes()
+
+
+@pytest.mark.parametrize("n,voxel", [(5000, 0.004), (1, 0.01), (2049, 0.5), (4097, 0.0005), (30000, 0.02)])
+def test_first_occurrence_order(ctx, orc, synth, tdv, n, voxel):
+    """TDV_VOXEL_ORDER_FIRST: voxels sorted by their smallest member index; same means."""
+    pts, _ = synth.sample_object(n, 3)
+    pts = pts + np.float32(0.3)  # mixed-sign keys after the shift below
+    pts[: n // 2] -= np.float32(0.45)
+    ref_xyz, _, first = orc.voxel_downsample(pts, None, voxel)
+    order = np.argsort(first, kind="stable")
+    got_xyz, got_rgb = ctx.voxel_downsample(pts, None, voxel, tdv.TDV_VOXEL_ORDER_FIRST)
+    assert got_rgb is None
+    assert len(got_xyz) == len(ref_xyz)
+    assert got_xyz.tobytes() == ref_xyz[order].tobytes()
+    got_ref, _ = ctx.voxel_downsample(pts, None, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
+    assert got_ref.tobytes() == ref_xyz.tobytes()
+
+
+def test_all_points_in_one_voxel_and_idempotence(ctx, orc, synth, tdv):
+    pts, _ = synth.sample_object(3000, 5)
+    got, _ = ctx.voxel_downsample(pts, None, 10.0, tdv.TDV_VOXEL_ORDER_FIRST)
+    ref, _, _ = orc.voxel_downsample(pts, None, 10.0)
+    assert len(ref) <= 8 and got.tobytes() == ref[np.argsort(orc.voxel_downsample(pts, None, 10.0)[2])].tobytes()
+    # downsampling a downsampled cloud with the same voxel cannot increase the count
+    a, _ = ctx.voxel_downsample(pts, None, 0.01, tdv.TDV_VOXEL_ORDER_FIRST)
+    b, _ = ctx.voxel_downsample(a, None, 0.01, tdv.TDV_VOXEL_ORDER_FIRST)
+    assert len(b) <= len(a)
+
+
+def test_voxel_operator_api_drops_normals(tdv, orc, synth):
+    """Registration::voxelDownsample returns points (+ colours), never normals (registration.cpp:42-56)."""
+    pts, nrm = synth.sample_object(2000, 9)
+    cloud = tdv.PointCloud(points=pts, normals=nrm)
+    out = tdv.Registration.voxelDownsample(cloud, 0.01)
+    ref, _, _ = orc.voxel_downsample(pts, None, 0.01)
+    assert not out.hasNormals() and not out.hasColors()
+    assert out.points.tobytes() == ref.tobytes()
+
+
+def test_voxel_full_size_properties(ctx, synth, tdv):
+    """200k points (BASELINE size): count conservation and mean-of-means invariants."""
+    pts, _ = synth.sample_object(200000, 11)
+    out, _ = ctx.voxel_downsample(pts, None, 0.002, tdv.TDV_VOXEL_ORDER_FIRST)
+    keys = np.floor(pts * np.float32(1.0 / np.float32(0.002))).astype(np.int64)
+    uniq, first_idx, counts = np.unique(keys, axis=0, return_index=True, return_counts=True)
+    assert len(out) == len(uniq)
+    # every output point lies inside its voxel (up to rounding of the mean) and the voxels come in first-occurrence order
+    okeys = np.floor(out.astype(np.float64) / 0.002 + 1e-3).astype(np.int64)
+    exp = keys[np.sort(first_idx)]
+    assert (np.abs(okeys - exp) <= 1).all()
+    w = counts[np.argsort(first_idx)][:, None].astype(np.float64)
+    assert np.allclose((out.astype(np.float64) * w).sum(0) / len(pts), pts.astype(np.float64).mean(0), atol=1e-6)
