@@ -108,6 +108,11 @@ def depth_preprocess(raw, mask, scale):
     return out
 
 
+def count_nonzero(depth):
+    d = _f32(depth)
+    return lib().orc_count_nonzero(_p(d), int(d.size))
+
+
 def unproject(depth, bgr, fx, fy, cx, cy, clipping_max):
     depth = _f32(depth)
     h, w = depth.shape
