@@ -1,0 +1,89 @@
+// Drop-in replacement for the reference's CUDA dispatch TU src/gpu_impl.cpp.
+// Compile THIS file instead of src/gpu_impl.cpp inside the reference tree (it includes the
+// reference's own, unmodified headers) and link lib3dvision_hip.so; src/pipeline.cpp is untouched.
+// It defines exactly the symbols gpu_impl.cpp defines (reference file:line in comments):
+//   bool    GPUDepth::isCudaAvailable()                          src/gpu_impl.cpp:18-26
+//   cv::Mat GPUDepth::preprocess(raw_depth, mask, scale)         src/gpu_impl.cpp:28-66
+//   PointCloud GPUPointCloud::generate(depth, rgb, fx,fy,cx,cy)  src/gpu_impl.cpp:69-128
+//   bool    GPURegistration::isCudaAvailable()                   src/gpu_impl.cpp:131-139
+//   RegistrationResult GPURegistration::icpRefine(...)           src/gpu_impl.cpp:141-260
+// NOT COMPILED IN THIS REPOSITORY'S CI: the image has neither Eigen nor OpenCV.  The same calls are
+// exercised through ../tdv_registration.cpp (layout-compatible plain types) on the GPU box.
+#include "gpu_depth.hpp"
+#include "gpu_registration.hpp"
+#include "tdv_hip.h"
+
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+namespace industry_picking {
+
+namespace {
+struct ThreadCtx { tdv_ctx* ctx = nullptr; ~ThreadCtx() { if (ctx) tdv_ctx_destroy(ctx); } };
+thread_local ThreadCtx g_tls;  // one stream + workspace per pool thread (include/thread_pool.hpp:17-33)
+
+bool device_available() { int n = 0; return tdv_device_count(&n) == TDV_OK && n > 0; }
+tdv_ctx* ctx_or_throw() {
+    if (!g_tls.ctx) {
+        if (!device_available()) throw std::runtime_error("CUDA not available");
+        if (tdv_ctx_create(0, &g_tls.ctx) != TDV_OK) throw std::runtime_error("tdv_ctx_create failed");
+    }
+    return g_tls.ctx;
+}
+void check(int st, const char* what) {
+    if (st != TDV_OK) throw std::runtime_error(std::string(what) + ": " + tdv_status_string(st) + " " + tdv_last_error(g_tls.ctx));
+}
+static_assert(sizeof(Eigen::Vector3f) == 12, "points.data() is passed as float[n*3]");
+}  // namespace
+
+bool GPUDepth::isCudaAvailable() { return device_available(); }
+bool GPURegistration::isCudaAvailable() { return device_available(); }
+
+cv::Mat GPUDepth::preprocess(const cv::Mat& raw_depth, const cv::Mat& mask, float scale) {
+    tdv_ctx* c = ctx_or_throw();
+    cv::Mat raw = raw_depth.isContinuous() ? raw_depth : raw_depth.clone();   // the reference assumes continuity (:48)
+    cv::Mat m = (mask.empty() || mask.isContinuous()) ? mask : mask.clone();
+    cv::Mat out(raw.rows, raw.cols, CV_32FC1);
+    check(tdv_depth_preprocess(c, raw.ptr<uint16_t>(), m.empty() ? nullptr : m.ptr<uint8_t>(), raw.cols, raw.rows, scale,
+                               TDV_MASK_THRESHOLD10 /* CPU-branch semantics, src/pipeline.cpp:51-52 */, out.ptr<float>()),
+          "GPUDepth::preprocess");
+    return out;
+}
+
+PointCloud GPUPointCloud::generate(const cv::Mat& depth, const cv::Mat& rgb, float fx, float fy, float cx, float cy) {
+    if (!device_available()) return {};                                       // src/gpu_impl.cpp:126
+    tdv_ctx* c = ctx_or_throw();
+    cv::Mat d = depth.isContinuous() ? depth : depth.clone();
+    cv::Mat col = (rgb.empty() || rgb.isContinuous()) ? rgb : rgb.clone();
+    PointCloud pcd;
+    const int cap = d.rows * d.cols;
+    pcd.points.resize(cap);
+    pcd.colors.resize(cap);
+    int n = 0;
+    const float max_depth = 10.0f;                                            // src/gpu_impl.cpp:97
+    check(tdv_deproject(c, d.ptr<float>(), col.empty() ? nullptr : col.ptr<uint8_t>(), d.cols, d.rows, fx, fy, cx, cy, max_depth,
+                        pcd.points[0].data(), col.empty() ? nullptr : pcd.colors[0].data(), cap, &n), "GPUPointCloud::generate");
+    pcd.points.resize(n);
+    if (col.empty()) pcd.colors.assign(n, Eigen::Vector3f(1.f, 1.f, 1.f));    // white fallback, src/gpu_impl.cpp:92-94
+    else pcd.colors.resize(n);
+    return pcd;
+}
+
+RegistrationResult GPURegistration::icpRefine(const PointCloud& source, const PointCloud& target,
+                                              const Eigen::Matrix4f& initial_transform, float distance_threshold, int max_iterations) {
+    tdv_ctx* c = ctx_or_throw();
+    tdv_icp_result r;
+    check(tdv_icp(c, source.empty() ? nullptr : source.points[0].data(), (int)source.size(),
+                  target.empty() ? nullptr : target.points[0].data(), target.hasNormals() && !target.empty() ? target.normals[0].data() : nullptr,
+                  (int)target.size(), initial_transform.data() /* column-major */, distance_threshold, max_iterations, 1, &r),
+          "GPURegistration::icpRefine");
+    RegistrationResult out;
+    std::memcpy(out.transformation.data(), r.T, 64);
+    out.fitness = r.fitness; out.rmse = r.rmse;
+    std::cout << "GPU ICP result: fitness=" << out.fitness << ", RMSE=" << out.rmse << "\n";  // src/gpu_impl.cpp:255
+    return out;
+}
+
+}  // namespace industry_picking

@@ -98,13 +98,12 @@ def main():
     icp_thr = voxel * 4.0          # accepts the 3 deg / 5 mm perturbed start; the rate does not depend on it
     # --- reference model: generated on rank 0, broadcast to every rank over RCCL (xGMI) ---------
     t_b0 = time.perf_counter()
+    sharding = importlib.import_module("3dvision_amd.sharding")
+    pack = None
     if rank == 0:
         tgt_np, nrm_np = synth.sample_object(n, 42)
-        model = torch.from_numpy(np.concatenate([tgt_np, nrm_np], 1)).to(dev)
-    else:
-        model = torch.empty((n, 6), dtype=torch.float32, device=dev)
-    if distributed:
-        dist.broadcast(model, src=0)
+        pack = sharding.pack_model(tgt_np, nrm_np, synth.random_features(n, 42))  # points | normals | FPFH = 156 B per point
+    model = sharding.broadcast_model(pack, n, dev)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t_b0) * 1e3
     d_tgt = model[:, :3].contiguous(); d_nrm = model[:, 3:].contiguous()

@@ -1,0 +1,91 @@
+"""Config C1 (BASELINE.json configs[0]): the reference's demo-mode run — procedural 1280x720 box scene,
+one 201x201 mask, 40x40 planar model (src/pipeline.cpp:211-282) — pushed through the whole chain of
+Pipeline::processInstance (src/pipeline.cpp:25-150) on the GPU and compared stage by stage with the CPU
+oracle on identical inputs.  The demo geometry is degenerate (plane on plane), so the
+final pose is not a meaningful parity quantity; every stage is."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VOXEL = 0.001
+
+
+@pytest.fixture(scope="module")
+def demo(orc):
+    depth, bgr = orc.demo_scene()
+    mask = orc.demo_mask()
+    model, _ = orc.demo_model()
+    d = orc.depth_preprocess(depth, mask, 1000.0)
+    xyz, rgb = orc.unproject(d, bgr, 900, 900, 640, 360, 1.5)
+    src, src_rgb, _ = orc.voxel_downsample(xyz, rgb, VOXEL)
+    ref, _, _ = orc.voxel_downsample(model, None, VOXEL)
+    return dict(depth=depth, bgr=bgr, mask=mask, model=model, xyz=xyz, rgb=rgb, src=src, src_rgb=src_rgb, ref=ref)
+
+
+def test_c1_cloud_and_voxel(ctx, tdv, demo):
+    xyz, rgb = ctx.depth_to_cloud(demo["depth"], demo["mask"], demo["bgr"], 1000.0, 900, 900, 640, 360, 1.5)
+    assert xyz.tobytes() == demo["xyz"].tobytes() and rgb.tobytes() == demo["rgb"].tobytes()
+    src, src_rgb = ctx.voxel_downsample(xyz, rgb, VOXEL, tdv.TDV_VOXEL_ORDER_REFERENCE)
+    assert len(src) == 32129 and src.tobytes() == demo["src"].tobytes() and src_rgb.tobytes() == demo["src_rgb"].tobytes()
+    ref, _ = ctx.voxel_downsample(demo["model"], None, VOXEL, tdv.TDV_VOXEL_ORDER_REFERENCE)
+    assert len(ref) == 1600 and ref.tobytes() == demo["ref"].tobytes()
+
+
+def test_c1_features_ransac_icp(ctx, orc, demo):
+    src, ref = demo["src"], demo["ref"]
+    # model side (1,600 points): full comparison
+    ref_n_o = orc.estimate_normals(ref, 30)
+    ref_n = ctx.estimate_normals(ref, 30)
+    assert ref_n.tobytes() == ref_n_o.tobytes()
+    ref_f_o = orc.compute_fpfh(ref, ref_n_o, VOXEL * 5.0)
+    ref_f = ctx.compute_fpfh(ref, ref_n, VOXEL * 5.0)
+    assert np.abs(ref_f - ref_f_o).max() < 1e-6
+    # scene side (32,129 points): normals + FPFH on the GPU, the oracle on a 4,000-point prefix sample
+    # would change neighbourhoods, so the oracle runs the full cloud too (O(N^2), ~20 s of host time)
+    src_n_o, knn_o = orc.estimate_normals(src, 30, want_knn=True)
+    src_n, knn = ctx.estimate_normals(src, 30, want_knn=True)
+    assert np.array_equal(knn, knn_o) and src_n.tobytes() == src_n_o.tobytes()
+    src_f_o, nb_o, cnt_o = orc.compute_fpfh(src, src_n_o, VOXEL * 5.0, want_neighbors=True)
+    src_f, nb, cnt = ctx.compute_fpfh(src, src_n, VOXEL * 5.0, want_neighbors=True)
+    assert np.array_equal(cnt, cnt_o) and np.array_equal(nb, nb_o)
+    same = (src_f.view(np.uint32) == src_f_o.view(np.uint32)).all(1)
+    print("C1 scene FPFH rows bitwise equal: %d / %d" % (same.sum(), len(src)))
+    assert same.mean() > 0.995
+    # feature correspondences from identical descriptors
+    corr_o = orc.feature_match(src_f_o, ref_f_o)
+    corr = ctx.feature_match(src_f_o, ref_f_o)
+    assert np.array_equal(corr, corr_o)
+    # RANSAC (shipped threshold 1.5 * voxel), 3,000 iterations with the per-iteration trace
+    rs_o = orc.ransac(src, ref, corr=corr_o, voxel=VOXEL, max_iterations=3000, confidence=0.999, trace=True)
+    rs = ctx.ransac(src, ref, corr=corr_o, voxel=VOXEL, max_iterations=3000, confidence=0.999, trace=True)
+    n = rs_o["iters_run"]
+    assert rs.iterations_run == n and np.array_equal(rs.trace_inliers[:n], rs_o["inliers"][:n])
+    assert rs.best_iteration == rs_o["best_iter"] and rs.transformation.tobytes() == rs_o["T"].tobytes()
+    # ICP from the coarse pose, shipped threshold voxel * 0.4 (pipeline.cpp:104), planar model with normals
+    icp_o = orc.icp(src, ref, ref_n_o, rs_o["T"], VOXEL * 0.4, 30, True, trace=True)
+    icp = ctx.icp(src, ref, ref_n_o, rs_o["T"], VOXEL * 0.4, 30, True)
+    print("C1 ICP: oracle iters %d fitness %.5f | gpu iters %d fitness %.5f" % (icp_o["iterations"], icp_o["fitness"], icp.iterations, icp.fitness))
+    assert abs(icp.iterations - icp_o["iterations"]) <= 1
+    if icp_o["iterations"] > 0:
+        assert abs(float(icp.fitness) - float(icp_o["fitness"])) < 5e-3
+
+
+def test_c1_demo_driver_binary():
+    """The C++ demo driver (3dvision_amd/host/demo_pipeline.cpp) reproduces the reference's demo run
+    over the host mirror of the operator API; exit code 0 and the reference's stage lines."""
+    exe = os.path.join(ROOT, "3dvision_amd", "host", "demo_pipeline")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "0.001", "3000", "30"], capture_output=True, text=True, timeout=300)
+    out = r.stdout
+    print(out[-1500:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Instance 0: 40401 points" in out
+    assert "Voxel downsample: 40401 → 32129 points" in out and "Voxel downsample: 1600 → 1600 points" in out
+    assert "Estimated normals for 32129 points" in out and "Computed FPFH features for 1600 points" in out
+    assert "RANSAC registration (threshold=0.0015, max_iter=3000)" in out
+    assert "ICP refinement (threshold=0.0004, max_iter=30, mode=point-to-plane)" in out
+    assert "=== Pipeline complete:" in out
