@@ -46,6 +46,7 @@ ABI_SYMBOLS = [
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
+    "tdv_register_batch_dev", "tdv_prepare_model_dev",
 ]
 
 
@@ -56,6 +57,20 @@ class TdvError(RuntimeError):
 class RansacResultC(C.Structure):
     _fields_ = [("T", C.c_float * 16), ("fitness", C.c_float), ("rmse", C.c_float), ("inliers", C.c_int),
                 ("best_iteration", C.c_int), ("iterations_run", C.c_int)]
+
+
+class BatchParamsC(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("scale_to_meters", C.c_float), ("mask_mode", C.c_int),
+                ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("zmax", C.c_float),
+                ("voxel_size", C.c_float), ("normals_k", C.c_int), ("fpfh_radius_factor", C.c_float),
+                ("ransac_max_iterations", C.c_int), ("ransac_confidence", C.c_float), ("icp_distance_factor", C.c_float),
+                ("icp_max_iterations", C.c_int), ("point_to_plane", C.c_int), ("seed", C.c_uint32)]
+
+
+class InstanceResultC(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("fitness", C.c_float), ("rmse", C.c_float), ("coarse_fitness", C.c_float),
+                ("coarse_inliers", C.c_int), ("icp_iterations", C.c_int), ("n_points", C.c_int), ("n_voxels", C.c_int),
+                ("status", C.c_int)]
 
 
 class IcpResultC(C.Structure):
@@ -338,6 +353,40 @@ class Context:
         _check(self._h, lib().tdv_voxel_downsample_dev(self._h, _ptr(d_xyz), _ptr(d_rgb), n, C.c_float(voxel), _ptr(d_out_xyz),
                                                        _ptr(d_out_rgb), capacity, C.byref(m)), "tdv_voxel_downsample_dev")
         return m.value
+
+
+def batch_params(width=1280, height=720, scale_to_meters=1000.0, mask_mode=TDV_MASK_THRESHOLD10, fx=900.0, fy=900.0, cx=640.0,
+                 cy=360.0, zmax=1.5, voxel_size=0.001, normals_k=30, fpfh_radius_factor=5.0, ransac_max_iterations=100000,
+                 ransac_confidence=0.999, icp_distance_factor=0.4, icp_max_iterations=200, point_to_plane=True, seed=42):
+    """Defaults = include/pipeline_config.hpp + config/pipeline_config.yaml of the reference."""
+    return BatchParamsC(width, height, scale_to_meters, mask_mode, fx, fy, cx, cy, zmax, voxel_size, normals_k, fpfh_radius_factor,
+                        ransac_max_iterations, ransac_confidence, icp_distance_factor, icp_max_iterations, int(point_to_plane), seed)
+
+
+def _register_batch_dev(self, d_raw, d_bgr, d_masks, n_instances, params, d_model_xyz, d_model_normals, d_model_fpfh, n_model):
+    """Batched device-resident Pipeline::processInstance; returns a list of dicts (one per instance)."""
+    res = (InstanceResultC * max(n_instances, 1))()
+    _check(self._h, lib().tdv_register_batch_dev(self._h, _ptr(d_raw), _ptr(d_bgr), _ptr(d_masks), n_instances, C.byref(params),
+                                                 _ptr(d_model_xyz), _ptr(d_model_normals), _ptr(d_model_fpfh), n_model, res),
+           "tdv_register_batch_dev")
+    out = []
+    for i in range(n_instances):
+        r = res[i]
+        out.append(dict(T=from_colmajor16(r.T), fitness=np.float32(r.fitness), rmse=np.float32(r.rmse), coarse_fitness=np.float32(r.coarse_fitness),
+                        coarse_inliers=r.coarse_inliers, icp_iterations=r.icp_iterations, n_points=r.n_points, n_voxels=r.n_voxels,
+                        status=r.status))
+    return out
+
+
+def _prepare_model_dev(self, d_xyz, n, voxel, k, radius_factor, d_out_xyz, d_out_normals, d_out_fpfh):
+    m = C.c_int()
+    _check(self._h, lib().tdv_prepare_model_dev(self._h, _ptr(d_xyz), n, C.c_float(voxel), k, C.c_float(radius_factor), _ptr(d_out_xyz),
+                                                _ptr(d_out_normals), _ptr(d_out_fpfh), C.byref(m)), "tdv_prepare_model_dev")
+    return m.value
+
+
+Context.register_batch_dev = _register_batch_dev
+Context.prepare_model_dev = _prepare_model_dev
 
 
 def sample_triples(n, count, seed=42):

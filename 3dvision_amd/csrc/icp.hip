@@ -8,12 +8,12 @@
 //
 // Kernel design (VALU-bound, not HBM- and not MFMA-bound: 8 f32 ops per pair, K=3):
 //  * icp_nn_scan: each lane keeps NN_SPL transformed source points in VGPRs; the target cloud
-//    is read as structure-of-arrays through the SCALAR data path (wave-uniform s_load_dwordx8
-//    of 8 x, 8 y, 8 z), so every distance op is one VALU instruction with an SGPR operand and
+//    is read as structure-of-arrays through the SCALAR data path (wave-uniform s_load_dwordx16
+//    of 16 x, 16 y, 16 z), so every distance op is one VALU instruction with an SGPR operand and
 //    neither LDS nor vector-memory instructions sit in the inner loop.  Argmin is two-level:
-//    the loop tracks min d2 and the first CHUNK of 8 targets that reached it (strict <),
-//    8 + 0.5 + 0.4 VALU ops per pair; the exact index inside the chunk is recovered later by
-//    re-evaluating 8 distances.  d2 = dx*dx + (dy*dy + dz*dz) with no FMA contraction, so the
+//    the loop tracks min d2 and the first CHUNK of 16 targets that reached it (strict <),
+//    8 + 0.5 + 0.3 VALU ops per pair; the exact index inside the chunk is recovered later by
+//    re-evaluating 16 distances.  d2 = dx*dx + (dy*dy + dz*dz) with no FMA contraction, so the
 //    argmin is bit-identical to the CPU scan (lowest index wins ties).
 //    The grid is (source blocks) x (target splits) so that >> 256 workgroups are in flight;
 //    splits are combined in split order with strict <, which preserves the tie rule.
@@ -31,8 +31,8 @@
 
 namespace tdv {
 
-constexpr int NN_SPL = 4;      // source points per lane
-constexpr int NN_CH = 8;       // targets per chunk (one s_load_dwordx8 per coordinate)
+constexpr int NN_SPL = 2;      // source points per lane
+constexpr int NN_CH = 16;      // targets per chunk (one s_load_dwordx16 per coordinate)
 constexpr int NN_BLOCK = 256;
 constexpr int NN_SRC_PER_BLOCK = NN_SPL * NN_BLOCK;
 constexpr int ACC_NV = 32;     // reduction slots per block (29 used p2plane, 17 p2point)
@@ -288,9 +288,9 @@ NnPlan make_plan(int ns, int nt) {
     p.nt_pad = (int)align_up((size_t)nt, NN_CH);
     p.n_chunks = p.nt_pad / NN_CH;
     p.blocks_x = p.ns_pad / NN_SRC_PER_BLOCK;
-    // aim for ~6k workgroups (24 per CU) but keep at least 32 chunks (256 targets) per split
-    int want = (6144 + p.blocks_x - 1) / p.blocks_x;
-    int max_split = std::max(1, p.n_chunks / 32);
+    // aim for ~12k workgroups (48 per CU: measured best at 200k x 200k) but keep >= 16 chunks (256 targets) per split
+    int want = (12288 + p.blocks_x - 1) / p.blocks_x;
+    int max_split = std::max(1, p.n_chunks / 16);
     p.nsplit = std::max(1, std::min(std::min(want, max_split), 64));
     p.chunks_per_split = (p.n_chunks + p.nsplit - 1) / p.nsplit;
     p.nsplit = (p.n_chunks + p.chunks_per_split - 1) / p.chunks_per_split;

@@ -126,24 +126,20 @@ void k_topk_scan(const float* __restrict__ q_aos, int nq, int nq_pad,
     for (int c = c0; c < c1; ++c) {
         const int j = c * KN_CH;
         float d2[KN_CH];
-        bool any_lane = false;
+        int nacc = 0;
 #pragma unroll
         for (int t = 0; t < KN_CH; ++t) {
             float dx = tx[j + t] - qx, dy = ty[j + t] - qy, dz = tz[j + t] - qz;  // (points[i] - query)
             d2[t] = dx * dx + (dy * dy + dz * dz);
-            any_lane |= d2[t] <= bound;
         }
-        if (!__any(any_lane)) continue;
+        float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
+        if (!__any(m <= bound)) continue;
+#pragma unroll
+        for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
+        if (__any(pcnt + nacc > KN_PB)) topk_merge<LDSLIST>(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
 #pragma unroll
         for (int t = 0; t < KN_CH; ++t) {
-            bool acc = d2[t] <= bound;
-            if (__any(acc)) {
-                if (__any(acc && pcnt == KN_PB)) {
-                    topk_merge<LDSLIST>(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
-                    acc = d2[t] <= bound;
-                }
-                if (acc) { s_pd[pcnt][tid] = d2[t]; s_pi[pcnt][tid] = j + t; pcnt++; }
-            }
+            if (d2[t] <= bound) { s_pd[pcnt][tid] = d2[t]; s_pi[pcnt][tid] = j + t; pcnt++; }
         }
     }
     if (__any(pcnt > 0)) topk_merge<LDSLIST>(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
@@ -153,6 +149,117 @@ void k_topk_scan(const float* __restrict__ q_aos, int nq, int nq_pad,
             for (int e = 0; e < cnt_list; ++e) {
                 out_d[((size_t)split * k + e) * nq_pad + qi] = s_ld[e][tid];
                 out_i[((size_t)split * k + e) * nq_pad + qi] = s_li[e][tid];
+            }
+        }
+    }
+}
+
+// Register-resident variant for small k (normals: k = 30): the sorted list (K entries) and an
+// 8-entry pending queue live in VGPRs with static indexing only, so the kernel uses no LDS and runs
+// at 4-5 waves per SIMD.  Fast path per chunk of 8 targets: 64 distance ops + a min3 tree + one
+// compare.  Accepted candidates are pushed into the pending queue by predicated shifts; when a
+// lane's queue is full the wave inserts the queued entries, oldest (lowest index) first, into the
+// sorted list by a compare-and-shift sweep.  Because targets are scanned in ascending index, a new
+// entry never precedes an equal-d2 entry already in the list, so `nd < Ld[e]` IS the (d2, idx)
+// lexicographic test.
+template <int K>
+__device__ __forceinline__ void reg_insert(float (&Ld)[K], int (&Li)[K], float nd, int ni) {
+    bool lt_cur = nd < Ld[K - 1];
+#pragma unroll
+    for (int e = K - 1; e >= 1; --e) {
+        bool lt_prev = nd < Ld[e - 1];
+        float d_keep = lt_cur ? nd : Ld[e];
+        int i_keep = lt_cur ? ni : Li[e];
+        Ld[e] = lt_prev ? Ld[e - 1] : d_keep;
+        Li[e] = lt_prev ? Li[e - 1] : i_keep;
+        lt_cur = lt_prev;
+    }
+    Ld[0] = lt_cur ? nd : Ld[0];
+    Li[0] = lt_cur ? ni : Li[0];
+}
+
+template <int K>
+__device__ __forceinline__ void reg_merge(float (&Ld)[K], int (&Li)[K], float (&pd)[KN_PB], int (&pi)[KN_PB],
+                                          int k, int& cnt, int& pcnt, float bound0, float& bound) {
+    int maxp = pcnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxp = max(maxp, __shfl_xor(maxp, off, 64));
+#pragma unroll
+    for (int s = KN_PB - 1; s >= 0; --s) {   // oldest (smallest target index) first
+        if (s < maxp) {                      // wave-uniform
+            float nd = s < pcnt ? pd[s] : INFINITY;
+            reg_insert<K>(Ld, Li, nd, pi[s]);
+        }
+    }
+    cnt = min(k, cnt + pcnt);
+    pcnt = 0;
+    if (k < K) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) if (e >= k) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
+    }
+    float kth = Ld[K - 1];
+    if (k < K) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) if (e == k - 1) kth = Ld[e];
+    }
+    bound = (cnt == k) ? fminf(bound0, float_pred(kth)) : bound0;
+}
+
+template <int K>
+__global__ __launch_bounds__(KN_BLOCK, 4)   // 4 waves per SIMD: keeps the K = 30 instance within 128 VGPRs
+void k_topk_scan_reg(const float* __restrict__ q_aos, int nq, int nq_pad,
+                     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                     int n_chunks, int chunks_per_split, int k, float bound0,
+                     float* __restrict__ out_d, int* __restrict__ out_i, int* __restrict__ out_cnt) {
+    const int split = blockIdx.y;
+    const int c0 = split * chunks_per_split;
+    const int c1 = min(n_chunks, c0 + chunks_per_split);
+    const int qi = blockIdx.x * KN_BLOCK + threadIdx.x;
+    const int qc = min(qi, nq - 1);
+    const float qx = q_aos[3 * qc], qy = q_aos[3 * qc + 1], qz = q_aos[3 * qc + 2];
+    float Ld[K]; int Li[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
+    float pd[KN_PB]; int pi[KN_PB];
+#pragma unroll
+    for (int s = 0; s < KN_PB; ++s) { pd[s] = INFINITY; pi[s] = INT_MAX; }
+    int cnt = 0, pcnt = 0;
+    float bound = bound0;
+    for (int c = c0; c < c1; ++c) {
+        const int j = c * KN_CH;
+        float d2[KN_CH];
+#pragma unroll
+        for (int t = 0; t < KN_CH; ++t) {
+            float dx = tx[j + t] - qx, dy = ty[j + t] - qy, dz = tz[j + t] - qz;
+            d2[t] = dx * dx + (dy * dy + dz * dz);
+        }
+        float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
+        if (!__any(m <= bound)) continue;
+        // slow path: make room ONCE per chunk (single merge site keeps the 8 appends statically indexed)
+        int nacc = 0;
+#pragma unroll
+        for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
+        if (__any(pcnt + nacc > KN_PB)) reg_merge<K>(Ld, Li, pd, pi, k, cnt, pcnt, bound0, bound);
+#pragma unroll
+        for (int t = 0; t < KN_CH; ++t) {
+            const bool acc = d2[t] <= bound;   // bound only tightens: entries refused now could never enter the list
+            if (__any(acc)) {
+#pragma unroll
+                for (int s = KN_PB - 1; s >= 1; --s) { pd[s] = acc ? pd[s - 1] : pd[s]; pi[s] = acc ? pi[s - 1] : pi[s]; }
+                pd[0] = acc ? d2[t] : pd[0];
+                pi[0] = acc ? (j + t) : pi[0];
+                pcnt += acc ? 1 : 0;
+            }
+        }
+    }
+    if (__any(pcnt > 0)) reg_merge<K>(Ld, Li, pd, pi, k, cnt, pcnt, bound0, bound);
+    if (qi < nq_pad) {
+        out_cnt[(size_t)split * nq_pad + qi] = cnt;
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            if (e < k) {
+                out_d[((size_t)split * k + e) * nq_pad + qi] = Ld[e];
+                out_i[((size_t)split * k + e) * nq_pad + qi] = Li[e];
             }
         }
     }
@@ -345,9 +452,13 @@ int run_scan(tdv_ctx* ctx, const float* d_xyz, int n, int k, float bound0, int t
     {
         ScopedTimer tm(ctx, timer);
         dim3 grid(p.blocks_x, p.nsplit);
-        if (k <= KN_KCAP_LDS)
-            k_topk_scan<true><<<grid, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, soa, soa + p.nt_pad, soa + 2 * (size_t)p.nt_pad,
-                                                        p.n_chunks, p.chunks_per_split, k, bound0, *pd, *pi, *pc);
+#define TDV_REG_SCAN(KK) k_topk_scan_reg<KK><<<grid, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, soa, soa + p.nt_pad, soa + 2 * (size_t)p.nt_pad, \
+                                                                     p.n_chunks, p.chunks_per_split, k, bound0, *pd, *pi, *pc)
+        if (k <= 8) TDV_REG_SCAN(8);
+        else if (k <= 16) TDV_REG_SCAN(16);
+        else if (k <= 30) TDV_REG_SCAN(30);
+        else if (k <= 32) TDV_REG_SCAN(32);
+#undef TDV_REG_SCAN
         else
             k_topk_scan<false><<<grid, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, soa, soa + p.nt_pad, soa + 2 * (size_t)p.nt_pad,
                                                          p.n_chunks, p.chunks_per_split, k, bound0, *pd, *pi, *pc);

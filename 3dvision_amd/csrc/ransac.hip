@@ -175,10 +175,10 @@ __global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __
 }
 
 // ------------------------------------------------------------------ scoring
-constexpr int RS_HPL = 2;       // hypotheses per lane
+constexpr int RS_HPL = 1;       // hypotheses per lane (1 measured best: 12 VGPRs of R,t, highest occupancy)
 constexpr int RS_BLOCK = 256;
 constexpr int RS_HYP_PER_BLOCK = RS_HPL * RS_BLOCK;
-constexpr int RS_PCH = 2;       // points per scalar chunk (2 x 8 floats = one s_load_dwordx16)
+constexpr int RS_PCH = 4;       // points per scalar chunk (4 x 8 floats = two s_load_dwordx16)
 
 __global__ __launch_bounds__(RS_BLOCK)
 void k_ransac_score(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq,
@@ -288,12 +288,12 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     TDV_CHECK_LAUNCH(ctx);
 
     // batch size: enough hypotheses to fill the chip, bounded for early exit granularity
-    const int batch = std::min(std::max(max_iterations, 1), 16384);
+    const int batch = std::min(std::max(max_iterations, 1), 65536);  // per-batch host sync is ~0.3 ms: amortise it
     const int h_pad = (int)align_up((size_t)batch, RS_HYP_PER_BLOCK);
     const int hblocks = h_pad / RS_HYP_PER_BLOCK;
     const int n_pchunks = ns_pad / RS_PCH;
-    int want = (4096 + hblocks - 1) / hblocks;
-    int psplit = std::max(1, std::min(std::min(want, std::max(1, n_pchunks / 64)), 256));
+    int want = (6144 + hblocks - 1) / hblocks;
+    int psplit = std::max(1, std::min(std::min(want, std::max(1, n_pchunks / 32)), 512));
     int pchunks_per_split = (n_pchunks + psplit - 1) / psplit;
     psplit = (n_pchunks + pchunks_per_split - 1) / pchunks_per_split;
 

@@ -72,6 +72,10 @@ inline int ws_alloc(tdv_ctx* ctx, size_t count, T** out) {
     return s;
 }
 int pin_reserve(tdv_ctx* ctx, size_t bytes);
+// mark / rewind: a batched caller frees everything one instance allocated while keeping what came before
+struct WsMark { size_t block, off, used; };
+inline WsMark ws_mark(tdv_ctx* ctx) { return WsMark{ctx->cur_block, ctx->cur_off, ctx->used_total}; }
+inline void ws_rewind(tdv_ctx* ctx, const WsMark& m) { ctx->cur_block = m.block; ctx->cur_off = m.off; ctx->used_total = m.used; }
 
 // Timing helpers: bracket a launch with events when ctx->timing is on.
 struct ScopedTimer {
@@ -106,6 +110,10 @@ int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, i
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
                          const float* h_xyz_for_reference_order, float* d_out_xyz, float* d_out_rgb, int capacity,
                          int* n_out);
+
+int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr, const uint8_t* d_masks, int n_instances,
+                       const tdv_batch_params* prm, const float* d_model_xyz, const float* d_model_normals,
+                       const float* d_model_fpfh, int n_model, tdv_instance_result* results);
 
 // host helpers
 void mt19937_lemire_triples(uint32_t seed, uint64_t n, int count, uint64_t* out);

@@ -197,6 +197,56 @@ int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d
 int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel_size,
                              float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out /* host */);
 
+/* ---- batched, device-resident Pipeline::processInstance ------------------------
+ * One call runs the whole per-instance chain of src/pipeline.cpp:25-150 for n_instances masks that
+ * share one depth/colour frame and one prepared reference model, without returning to the host
+ * between stages (the reference's operator API crosses PCIe at every op boundary):
+ *   mask -> depth scale+mask -> unproject -> voxelDownsample -> estimateNormals(k) ->
+ *   computeFPFH(voxel * fpfh_radius_factor) -> feature match + RANSAC -> ICP(threshold = voxel *
+ *   icp_distance_factor) -> refined transform.
+ * All pointers are device pointers; d_masks holds n_instances full-frame uint8 masks back to back;
+ * the model (points, normals, FPFH) is what Pipeline::run prepares once (src/pipeline.cpp:291-294);
+ * results is a HOST array of n_instances entries.  Instances whose mask leaves no depth / no points
+ * get status 1 / 2 (the reference returns nullopt there, src/pipeline.cpp:57-60, :86-89).
+ * Voxel order is first-occurrence (TDV_VOXEL_ORDER_FIRST): the reference's container order would
+ * need the cloud on the host.  The RANSAC index stream is seeded per instance exactly as the
+ * reference does (mt19937(42) restarted for every ransacRegistration call). */
+typedef struct tdv_batch_params {
+    int width, height;
+    float scale_to_meters;      /* depth.scale_to_meters      (include/pipeline_config.hpp:18) */
+    int mask_mode;              /* TDV_MASK_THRESHOLD10 / TDV_MASK_NONZERO                        */
+    float fx, fy, cx, cy, zmax; /* intrinsics; zmax = depth.clipping_max                          */
+    float voxel_size;           /* registration.voxel_size                                        */
+    int normals_k;              /* 30                        (src/pipeline.cpp:93)                */
+    float fpfh_radius_factor;   /* 5.0                       (src/pipeline.cpp:95)                */
+    int ransac_max_iterations;  /* registration.ransac_max_iterations                             */
+    float ransac_confidence;    /* 0.999                                                          */
+    float icp_distance_factor;  /* 0.4                       (src/pipeline.cpp:104)               */
+    int icp_max_iterations;     /* registration.icp_max_iterations                                */
+    int point_to_plane;         /* registration.use_point_to_plane                                */
+    uint32_t seed;              /* 42                        (src/registration.cpp:235)           */
+} tdv_batch_params;
+
+typedef struct tdv_instance_result {
+    float T[16];            /* refined.transformation, column-major */
+    float fitness, rmse;    /* of the ICP result */
+    float coarse_fitness;   /* of the RANSAC result */
+    int coarse_inliers;
+    int icp_iterations;
+    int n_points;           /* unprojected points */
+    int n_voxels;           /* after voxelDownsample */
+    int status;             /* 0 ok, 1 empty depth after masking, 2 empty cloud */
+} tdv_instance_result;
+
+int tdv_register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw_depth, const uint8_t* d_bgr /* may be NULL */,
+                           const uint8_t* d_masks, int n_instances, const tdv_batch_params* params,
+                           const float* d_model_xyz, const float* d_model_normals, const float* d_model_fpfh, int n_model,
+                           tdv_instance_result* results);
+/* Model preparation of src/pipeline.cpp:291-294 on device buffers: voxelDownsample(first-occurrence
+ * order) -> estimateNormals(k) -> computeFPFH(voxel * radius_factor).  Outputs have capacity n. */
+int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_size, int normals_k, float fpfh_radius_factor,
+                          float* d_out_xyz, float* d_out_normals, float* d_out_fpfh, int* n_out /* host */);
+
 /* ---- host-side helpers that are part of the path's semantics -------------------------------- */
 /* The RANSAC index stream: count triples from mt19937(seed) + Lemire uniform over [0, n-1]
  * (src/registration.cpp:235-239 on libstdc++ 11).  Own implementation, no <random>. */

@@ -1,0 +1,82 @@
+"""the batched, device-resident Pipeline::processInstance (tdv_register_batch_dev) must return
+exactly what the same chain gives when each operator is called on its own through the host-buffer ABI
+(which the other test modules pin against the oracle), instance by instance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(synth, orc, n_inst=3, w=640, h=480):
+    """A depth frame showing n_inst copies of the synthetic object at different poses, one mask each."""
+    f = 600.0
+    cx, cy = w / 2.0, h / 2.0
+    depth = np.zeros((h, w), np.uint16)
+    masks = np.zeros((n_inst, h, w), np.uint8)
+    model, _ = synth.sample_object(60000, 42)
+    for b in range(n_inst):
+        T = synth.make_transform([0.3 + 0.2 * b, 1.0, 0.4 - 0.3 * b], 25.0 + 10 * b, (-0.15 + 0.15 * b, 0.02 * b, 0.55 + 0.03 * b))
+        p = model.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3]  # object pose in the camera frame
+        u = np.round(p[:, 0] / p[:, 2] * f + cx).astype(int); v = np.round(p[:, 1] / p[:, 2] * f + cy).astype(int)
+        ok = (u >= 0) & (u < w) & (v >= 0) & (v < h) & (p[:, 2] > 0)
+        z = np.full((h, w), np.inf)
+        np.minimum.at(z, (v[ok], u[ok]), p[ok, 2])  # z-buffer: nearest surface per pixel
+        hit = np.isfinite(z)
+        depth[hit] = np.round(z[hit] * 1000.0).astype(np.uint16)
+        masks[b][hit] = 255
+    return depth, masks, dict(fx=f, fy=f, cx=cx, cy=cy, width=w, height=h)
+
+
+def test_batch_equals_stagewise_chain(ctx, tdv, synth, orc):
+    depth, masks, intr = _scene(synth, orc)
+    voxel = 0.004
+    prm = tdv.batch_params(voxel_size=voxel, zmax=1.5, ransac_max_iterations=4000, icp_max_iterations=30, **intr)
+    dev = torch.device("cuda", 0)
+    # model: prepared once on the device (voxel -> normals -> FPFH), as Pipeline::run does
+    model_raw, _ = synth.sample_object(20000, 7)
+    d_model_raw = torch.from_numpy(model_raw).to(dev)
+    d_mx = torch.empty_like(d_model_raw); d_mn = torch.empty_like(d_model_raw)
+    d_mf = torch.empty((len(model_raw), 33), dtype=torch.float32, device=dev)
+    nm = ctx.prepare_model_dev(d_model_raw.data_ptr(), len(model_raw), voxel, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr())
+    mx = d_mx[:nm].cpu().numpy(); mn = d_mn[:nm].cpu().numpy(); mf = d_mf[:nm].cpu().numpy()
+    # the model prep itself equals the stagewise ops
+    ex, _ = ctx.voxel_downsample(model_raw, None, voxel, tdv.TDV_VOXEL_ORDER_FIRST)
+    assert nm == len(ex) and mx.tobytes() == ex.tobytes()
+    en = ctx.estimate_normals(ex, 30)
+    assert mn.tobytes() == en.tobytes()
+    assert mf.tobytes() == ctx.compute_fpfh(ex, en, voxel * 5.0).tobytes()
+
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    d_masks = torch.from_numpy(masks).to(dev)
+    res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), len(masks), prm,
+                                 d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+    assert len(res) == len(masks)
+    for b, r in enumerate(res):
+        xyz, _ = ctx.depth_to_cloud(depth, masks[b], None, 1000.0, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 1.5)
+        assert r["status"] == 0 and r["n_points"] == len(xyz) > 1000
+        src, _ = ctx.voxel_downsample(xyz, None, voxel, tdv.TDV_VOXEL_ORDER_FIRST)
+        assert r["n_voxels"] == len(src)
+        nrm = ctx.estimate_normals(src, 30)
+        fp = ctx.compute_fpfh(src, nrm, voxel * 5.0)
+        coarse = ctx.ransac(src, mx, fs=fp, ft=mf, voxel=voxel, max_iterations=4000, confidence=0.999)
+        assert r["coarse_inliers"] == coarse.inliers and r["coarse_fitness"] == coarse.fitness
+        fine = ctx.icp(src, mx, mn, coarse.transformation, voxel * 0.4, 30, True)
+        assert r["icp_iterations"] == fine.iterations
+        assert r["T"].tobytes() == fine.transformation.tobytes() and r["fitness"] == fine.fitness and r["rmse"] == fine.rmse
+        print("instance %d: %d px -> %d voxels, coarse inliers %d, icp fitness %.3f" % (b, r["n_points"], r["n_voxels"], r["coarse_inliers"], r["fitness"]))
+
+
+def test_batch_empty_mask(ctx, tdv, synth, orc):
+    depth, masks, intr = _scene(synth, orc, n_inst=1)
+    masks = np.concatenate([np.zeros_like(masks), masks], 0)  # first instance: empty mask
+    dev = torch.device("cuda", 0)
+    model, nrm = synth.sample_object(3000, 7)
+    d_mx = torch.from_numpy(model).to(dev); d_mn = torch.from_numpy(nrm).to(dev)
+    d_mf = torch.from_numpy(synth.random_features(3000, 1)).to(dev)
+    prm = tdv.batch_params(voxel_size=0.006, ransac_max_iterations=500, icp_max_iterations=5, **intr)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)  # keep alive across the call
+    d_masks = torch.from_numpy(masks).to(dev)
+    res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 2, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), 3000)
+    assert res[0]["status"] == 2 and res[0]["n_points"] == 0 and np.array_equal(res[0]["T"], np.eye(4, dtype=np.float32))
+    assert res[1]["status"] == 0 and res[1]["n_voxels"] > 100
