@@ -34,6 +34,7 @@ LIB_PATH = os.path.join(_HERE, "lib3dvision_hip.so")
 
 TDV_MASK_THRESHOLD10 = 0
 TDV_MASK_NONZERO = 1
+TDV_MASK_LABEL_BASE = 256
 TDV_VOXEL_ORDER_FIRST = 0
 TDV_VOXEL_ORDER_REFERENCE = 1
 TIMER_ICP_NN, TIMER_RANSAC_SCORE, TIMER_FEATURE_MATCH, TIMER_KNN, TIMER_RADIUS, TIMER_DEPTH, TIMER_VOXEL = range(7)
@@ -46,7 +47,7 @@ ABI_SYMBOLS = [
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
-    "tdv_register_batch_dev", "tdv_prepare_model_dev",
+    "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii",
 ]
 
 
@@ -221,6 +222,13 @@ class Context:
                "tdv_depth_preprocess")
         return out
 
+    def bilateral_filter(self, depth, sigma_spatial, sigma_range):
+        d = _f32(depth); h, w = d.shape
+        out = np.empty_like(d)
+        _check(self._h, lib().tdv_bilateral_filter(self._h, _ptr(d), w, h, C.c_float(sigma_spatial), C.c_float(sigma_range), _ptr(out)),
+               "tdv_bilateral_filter")
+        return out
+
     def deproject(self, depth, bgr, fx, fy, cx, cy, zmax, capacity=None):
         depth = _f32(depth)
         h, w = depth.shape
@@ -393,6 +401,24 @@ def sample_triples(n, count, seed=42):
     out = np.empty((count, 3), np.uint64)
     _check(None, lib().tdv_sample_triples(C.c_uint32(seed), C.c_uint64(n), count, _ptr(out)), "tdv_sample_triples")
     return out
+
+
+def filter_duplicates(poses, min_distance=0.1):
+    """Pipeline::filterDuplicates (src/pipeline.cpp:153-180); poses: [n,4,4]."""
+    poses = np.asarray(poses, np.float32).reshape(-1, 4, 4)
+    cm = np.ascontiguousarray(np.transpose(poses, (0, 2, 1))).reshape(-1, 16)
+    out = np.empty_like(cm); m = C.c_int()
+    _check(None, lib().tdv_filter_duplicates(_ptr(cm), len(cm), C.c_float(min_distance), _ptr(out), C.byref(m)), "tdv_filter_duplicates")
+    return np.transpose(out[:m.value].reshape(-1, 4, 4), (0, 2, 1)).copy()
+
+
+def load_reference_model(path, capacity=1 << 20):
+    """Registration::loadReferenceModel (src/registration.cpp:416-461): returns a PointCloud (empty if the file is missing)."""
+    xyz = np.zeros((capacity, 3), np.float32); rgb = np.zeros((capacity, 3), np.float32); n = C.c_int(); hc = C.c_int()
+    st = lib().tdv_load_ply_ascii(path.encode(), _ptr(xyz), _ptr(rgb), capacity, C.byref(n), C.byref(hc))
+    if st != 0:
+        return PointCloud()
+    return PointCloud(points=xyz[:n.value].copy(), colors=(rgb[:n.value].copy() if hc.value else None))
 
 
 def pose_compose(extrinsics, T):

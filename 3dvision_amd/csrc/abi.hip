@@ -54,6 +54,20 @@ int tdv_depth_preprocess(tdv_ctx* ctx, const uint16_t* raw, const uint8_t* mask,
     return finish(ctx);
 }
 
+int tdv_bilateral_filter(tdv_ctx* ctx, const float* depth, int width, int height, float sigma_spatial, float sigma_range,
+                         float* out_depth) {
+    if (!depth || !out_depth || width < 0 || height < 0) return TDV_ERR_BAD_ARG;
+    TDV_TRY(begin(ctx));
+    const size_t n = (size_t)width * height;
+    if (n == 0) return TDV_OK;
+    float *d_in, *d_out;
+    TDV_TRY(upload(ctx, depth, n, &d_in));
+    TDV_TRY(ws_alloc(ctx, n, &d_out));
+    TDV_TRY(bilateral_filter_dev(ctx, d_in, d_out, width, height, sigma_spatial, sigma_range));
+    TDV_TRY(download(ctx, out_depth, d_out, n));
+    return finish(ctx);
+}
+
 int tdv_deproject(tdv_ctx* ctx, const float* depth, const uint8_t* bgr, int width, int height,
                   float fx, float fy, float cx, float cy, float zmax,
                   float* out_xyz, float* out_rgb, int capacity, int* n_out) {

@@ -22,14 +22,18 @@ constexpr int DP_BLOCK = 256;
 constexpr int DP_PX_PER_THREAD = 4;
 constexpr int DP_PX_PER_BLOCK = DP_BLOCK * DP_PX_PER_THREAD;
 
+// mask rule: reference CPU (> 10, src/pipeline.cpp:51), reference CUDA (!= 0, cuda/depth_processing.cu:22), or
+// label image (pixel value == instance label; SURVEY.md 8f N2: one u8 image instead of B full-frame masks)
+__device__ __forceinline__ bool mask_keeps(uint8_t m, int mask_mode) {
+    if (mask_mode == TDV_MASK_THRESHOLD10) return m > 10;
+    if (mask_mode == TDV_MASK_NONZERO) return m != 0;
+    return (int)m == mask_mode - TDV_MASK_LABEL_BASE;
+}
+
 __device__ __forceinline__ float scaled_depth(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ mask,
                                               size_t i, float inv_scale, int mask_mode) {
     float v = (float)raw[i] * inv_scale;
-    if (mask) {
-        uint8_t m = mask[i];
-        bool keep = mask_mode == TDV_MASK_THRESHOLD10 ? (m > 10) : (m != 0);
-        if (!keep) v = 0.f;
-    }
+    if (mask && !mask_keeps(mask[i], mask_mode)) v = 0.f;
     return v;
 }
 
@@ -43,11 +47,10 @@ void k_depth_preprocess(const uint16_t* __restrict__ raw, const uint8_t* __restr
         float4 o = make_float4((float)r.x * inv_scale, (float)r.y * inv_scale, (float)r.z * inv_scale, (float)r.w * inv_scale);
         if (mask) {
             uchar4 m = *reinterpret_cast<const uchar4*>(mask + i4);
-            if (mask_mode == TDV_MASK_THRESHOLD10) {
-                if (!(m.x > 10)) o.x = 0.f; if (!(m.y > 10)) o.y = 0.f; if (!(m.z > 10)) o.z = 0.f; if (!(m.w > 10)) o.w = 0.f;
-            } else {
-                if (m.x == 0) o.x = 0.f; if (m.y == 0) o.y = 0.f; if (m.z == 0) o.z = 0.f; if (m.w == 0) o.w = 0.f;
-            }
+            if (!mask_keeps(m.x, mask_mode)) o.x = 0.f;
+            if (!mask_keeps(m.y, mask_mode)) o.y = 0.f;
+            if (!mask_keeps(m.z, mask_mode)) o.z = 0.f;
+            if (!mask_keeps(m.w, mask_mode)) o.w = 0.f;
         }
         *reinterpret_cast<float4*>(out + i4) = o;
     } else {
@@ -158,6 +161,61 @@ void k_emit(const uint16_t* __restrict__ raw, const float* __restrict__ depth, c
         }
         run += (wcnt[k][0] + wcnt[k][1]) + (wcnt[k][2] + wcnt[k][3]);
     }
+}
+
+// ------------------------------------------------------------------ bilateral depth filter
+// Restates the reference's (never-called) CUDA kernel cuda/depth_processing.cu:62-122 and its launcher :124-155:
+// radius = int(2*sigma_s + 0.5) clamped to 5; weight = expf(d2 * (-0.5/sigma_s^2) + dr^2 * (-0.5/sigma_r^2));
+// zero depths are skipped and stay zero; taps outside the image read 0 (skipped); sums run row-major over the window.
+// Tile: 64 x 4 pixels per 256-thread workgroup (one wave = one image row segment: coalesced 256 B rows),
+// halo staged in LDS.
+constexpr int BF_TW = 64, BF_TH = 4, BF_MAXR = 5;
+
+__global__ __launch_bounds__(BF_TW * BF_TH)
+void k_bilateral(const float* __restrict__ in, float* __restrict__ out, int width, int height, int radius,
+                 float inv_spatial2, float inv_range2) {
+    __shared__ float tile[BF_TH + 2 * BF_MAXR][BF_TW + 2 * BF_MAXR + 2];
+    const int tx = threadIdx.x & (BF_TW - 1), ty = threadIdx.x / BF_TW;
+    const int gx0 = blockIdx.x * BF_TW - radius, gy0 = blockIdx.y * BF_TH - radius;
+    const int sw = BF_TW + 2 * radius, sh = BF_TH + 2 * radius;
+    for (int sy = ty; sy < sh; sy += BF_TH)
+        for (int sx = tx; sx < sw; sx += BF_TW) {
+            int gx = gx0 + sx, gy = gy0 + sy;
+            float v = 0.f;
+            if (gx >= 0 && gx < width && gy >= 0 && gy < height) v = in[(size_t)gy * width + gx];
+            tile[sy][sx] = v;
+        }
+    __syncthreads();
+    const int x = blockIdx.x * BF_TW + tx, y = blockIdx.y * BF_TH + ty;
+    if (x >= width || y >= height) return;
+    const int scx = tx + radius, scy = ty + radius;
+    const float center = tile[scy][scx];
+    if (center <= 0.f) { out[(size_t)y * width + x] = 0.f; return; }
+    float sum_w = 0.f, sum_v = 0.f;
+    for (int dy = -radius; dy <= radius; ++dy)
+        for (int dx = -radius; dx <= radius; ++dx) {
+            float nb = tile[scy + dy][scx + dx];
+            if (nb <= 0.f) continue;
+            float rd = nb - center;
+            float w = expf((float)(dx * dx + dy * dy) * inv_spatial2 + rd * rd * inv_range2);
+            sum_w += w;
+            sum_v += w * nb;
+        }
+    out[(size_t)y * width + x] = (sum_w > 0.f) ? (sum_v / sum_w) : center;
+}
+
+int bilateral_filter_dev(tdv_ctx* ctx, const float* d_in, float* d_out, int w, int h, float sigma_spatial, float sigma_range) {
+    if (!ctx || !d_in || !d_out || w < 0 || h < 0 || !(sigma_spatial > 0.f) || !(sigma_range > 0.f)) return TDV_ERR_BAD_ARG;
+    if ((size_t)w * h == 0) return TDV_OK;
+    int radius = static_cast<int>(2.0f * sigma_spatial + 0.5f);   // depth_processing.cu:131
+    if (radius > BF_MAXR) radius = BF_MAXR;                        // :132-136 (clamped; the reference also prints a warning)
+    const float inv_spatial2 = -0.5f / (sigma_spatial * sigma_spatial);
+    const float inv_range2 = -0.5f / (sigma_range * sigma_range);
+    dim3 grid((w + BF_TW - 1) / BF_TW, (h + BF_TH - 1) / BF_TH);
+    ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
+    k_bilateral<<<grid, BF_TW * BF_TH, 0, ctx->stream>>>(d_in, d_out, w, h, radius, inv_spatial2, inv_range2);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
 }
 
 int depth_preprocess_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, int w, int h, float scale,

@@ -100,6 +100,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
 int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr);
 int depth_preprocess_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, int w, int h, float scale,
                          int mask_mode, float* d_out);
+int bilateral_filter_dev(tdv_ctx* ctx, const float* d_in, float* d_out, int w, int h, float sigma_spatial, float sigma_range);
 int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth_f32, const uint8_t* d_mask,
                        const uint8_t* d_bgr, int w, int h, float scale, int mask_mode,
                        float fx, float fy, float cx, float cy, float zmax,

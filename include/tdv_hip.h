@@ -81,8 +81,18 @@ int tdv_timing_read(tdv_ctx* ctx, int slot, double* total_ms, int* launches);
  * 1 = reference CUDA semantics (keep mask != 0). */
 #define TDV_MASK_THRESHOLD10 0
 #define TDV_MASK_NONZERO 1
+/* label image: keep pixels whose mask value equals `label` (1..255): pass
+ * TDV_MASK_LABEL_BASE + label.  One u8 image then serves every instance of a scene instead of one
+ * full-frame mask per instance (src/pipeline.cpp:251-257, src/segmentation.cpp:12-42 produce those). */
+#define TDV_MASK_LABEL_BASE 256
 int tdv_depth_preprocess(tdv_ctx* ctx, const uint16_t* raw, const uint8_t* mask, int width, int height,
                          float scale, int mask_mode, float* out_depth);
+
+/* Bilateral depth filter: the reference's kernel cuda/depth_processing.cu:62-122 /
+ * launcher :124-155, which its dispatch never calls (config flag depth.bilateral_filter is parsed at
+ * src/main.cpp:24 and never read).  in/out: float depth images; zero depths stay zero. */
+int tdv_bilateral_filter(tdv_ctx* ctx, const float* depth, int width, int height, float sigma_spatial, float sigma_range,
+                         float* out_depth);
 
 /* ---- R2: unprojection --------------------------------------------------------------------- */
 /* Replaces GPUPointCloud::generate (src/gpu_impl.cpp:69-128, kernel cuda/pointcloud.cu:11-51);
@@ -253,6 +263,19 @@ int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_s
 int tdv_sample_triples(uint32_t seed, uint64_t n, int count, uint64_t* out_triples);
 /* Pose composition of src/pipeline.cpp:136-137: out = extrinsics * inverse(T). */
 int tdv_pose_compose(const float* extrinsics, const float* T, float* out);
+/* Pipeline::filterDuplicates (src/pipeline.cpp:153-180): greedy pass over n column-major 4x4 poses; a pose
+ * within min_distance of a kept one is a duplicate and replaces it only if it is closer to the origin.
+ * out_poses has room for n poses; *n_out = kept count. */
+int tdv_filter_duplicates(const float* poses, int n, float min_distance, float* out_poses, int* n_out);
+/* Registration::loadReferenceModel (src/registration.cpp:416-461): ASCII PLY, x y z [r g b] per vertex.
+ * Keeps the reference's behaviour: colours are detected by "red" appearing in any header line and are
+ * divided by 255 when r > 1; the header loop consumes the line AFTER end_header, so the first vertex is
+ * skipped and the last read fails — the reference then pushes x = 0 and unspecified y, z (and colour);
+ * here that last point is (0,0,0) with colour (0,0,0).  out_xyz / out_rgb (either may be NULL) have room
+ * for `capacity` points; *n_out = points the reference would return (= the header's vertex count);
+ * *has_color = 1 if colours are present.  Returns TDV_ERR_BAD_ARG if the file cannot be opened
+ * (the reference returns an empty cloud there). */
+int tdv_load_ply_ascii(const char* path, float* out_xyz, float* out_rgb, int capacity, int* n_out, int* has_color);
 
 #ifdef __cplusplus
 }

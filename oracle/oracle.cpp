@@ -38,6 +38,8 @@
 #include <numeric>
 #include <limits>
 #include <cmath>
+#include <fstream>
+#include <string>
 
 using namespace orc;
 
@@ -532,6 +534,86 @@ int orc_icp(const float* src, int ns, const float* tgt, const float* tgt_normals
     std::memcpy(T_out, res_T, 64);
     *fitness_out = res_fitness; *rmse_out = res_rmse;
     return applied;
+}
+
+// ---------------------------------------------------------------- neighbours of the path
+// cuda/depth_processing.cu:62-155 (bilateral filter; the reference has no CPU version and never calls it).
+void orc_bilateral_filter(const float* in, float* out, int width, int height, float sigma_spatial, float sigma_range) {
+    int radius = static_cast<int>(2.0f * sigma_spatial + 0.5f);
+    if (radius > 5) radius = 5;
+    const float inv_spatial2 = -0.5f / (sigma_spatial * sigma_spatial);
+    const float inv_range2 = -0.5f / (sigma_range * sigma_range);
+    auto at = [&](int x, int y) -> float { return (x >= 0 && x < width && y >= 0 && y < height) ? in[(size_t)y * width + x] : 0.0f; };
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            float center = at(x, y);
+            if (center <= 0.0f) { out[(size_t)y * width + x] = 0.0f; continue; }
+            float sum_w = 0.0f, sum_v = 0.0f;
+            for (int dy = -radius; dy <= radius; ++dy)
+                for (int dx = -radius; dx <= radius; ++dx) {
+                    float nb = at(x + dx, y + dy);
+                    if (nb <= 0.0f) continue;
+                    float rd = nb - center;
+                    float w = expf(static_cast<float>(dx * dx + dy * dy) * inv_spatial2 + rd * rd * inv_range2);
+                    sum_w += w; sum_v += w * nb;
+                }
+            out[(size_t)y * width + x] = (sum_w > 0.0f) ? (sum_v / sum_w) : center;
+        }
+}
+
+// pipeline.cpp:153-180.  poses: n column-major 4x4.  Returns the kept count.
+int orc_filter_duplicates(const float* poses, int n, float min_distance, float* out) {
+    std::vector<std::array<float, 16>> filtered;
+    auto norm3 = [](float x, float y, float z) { return std::sqrt(sum3(x * x, y * y, z * z)); };
+    for (int w = 0; w < n; ++w) {
+        const float* wp = poses + (size_t)w * 16;
+        bool is_dup = false;
+        for (size_t i = 0; i < filtered.size(); ++i) {
+            float dist = norm3(wp[12] - filtered[i][12], wp[13] - filtered[i][13], wp[14] - filtered[i][14]);
+            if (dist < min_distance) {
+                is_dup = true;
+                float existing_dist = norm3(filtered[i][12], filtered[i][13], filtered[i][14]);
+                float current_dist = norm3(wp[12], wp[13], wp[14]);
+                if (current_dist < existing_dist) std::memcpy(filtered[i].data(), wp, 64);
+                break;
+            }
+        }
+        if (!is_dup) { std::array<float, 16> a; std::memcpy(a.data(), wp, 64); filtered.push_back(a); }
+    }
+    for (size_t i = 0; i < filtered.size(); ++i) std::memcpy(out + i * 16, filtered[i].data(), 64);
+    return (int)filtered.size();
+}
+
+// registration.cpp:416-461.  The reference's float x, y, z are uninitialised when the last read fails
+// (C++11 stores 0 in x; y, z keep indeterminate values): this restatement zero-initialises them.
+// Returns the number of points (-1 if the file cannot be opened); *has_color_out as detected.
+int orc_load_ply(const char* path, float* xyz, float* rgb, int capacity, int* has_color_out) {
+    std::ifstream file(path);
+    if (!file.is_open()) return -1;
+    std::string line;
+    int vertex_count = 0;
+    bool has_color = false, in_header = true;
+    while (std::getline(file, line) && in_header) {
+        if (line.find("element vertex") != std::string::npos) sscanf(line.c_str(), "element vertex %d", &vertex_count);
+        if (line.find("red") != std::string::npos || line.find("diffuse_red") != std::string::npos) has_color = true;
+        if (line == "end_header") in_header = false;
+    }
+    *has_color_out = has_color;
+    int n = 0;
+    for (int i = 0; i < vertex_count; ++i) {
+        float x = 0, y = 0, z = 0;
+        file >> x >> y >> z;
+        if (n < capacity) { xyz[3 * n] = x; xyz[3 * n + 1] = y; xyz[3 * n + 2] = z; }
+        if (has_color) {
+            float r = 0, g = 0, b = 0;
+            file >> r >> g >> b;
+            if (r > 1.0f) { r /= 255.0f; g /= 255.0f; b /= 255.0f; }
+            if (n < capacity && rgb) { rgb[3 * n] = r; rgb[3 * n + 1] = g; rgb[3 * n + 2] = b; }
+        }
+        ++n;
+        std::getline(file, line);
+    }
+    return n;
 }
 
 // ---------------------------------------------------------------- pose composition

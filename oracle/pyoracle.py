@@ -38,6 +38,8 @@ def lib():
         _LIB.orc_voxel_downsample.restype = C.c_int
         _LIB.orc_self_adjoint_eig3.restype = C.c_int
         _LIB.orc_icp.restype = C.c_int
+        _LIB.orc_filter_duplicates.restype = C.c_int
+        _LIB.orc_load_ply.restype = C.c_int
     return _LIB
 
 
@@ -230,3 +232,27 @@ def pose_compose(extrinsics, T):
     e = to_colmajor16(extrinsics); t = to_colmajor16(T); o = np.zeros(16, np.float32)
     lib().orc_pose_compose(_p(e), _p(t), _p(o))
     return from_colmajor16(o)
+
+
+def bilateral_filter(depth, sigma_spatial, sigma_range):
+    d = _f32(depth); h, w = d.shape
+    out = np.empty_like(d)
+    lib().orc_bilateral_filter(_p(d), _p(out), w, h, C.c_float(sigma_spatial), C.c_float(sigma_range))
+    return out
+
+
+def filter_duplicates(poses, min_distance):
+    """poses: [n,4,4] ordinary matrices."""
+    poses = np.asarray(poses, np.float32).reshape(-1, 4, 4)
+    cm = np.ascontiguousarray(np.transpose(poses, (0, 2, 1))).reshape(-1, 16)
+    out = np.empty_like(cm)
+    m = lib().orc_filter_duplicates(_p(cm), len(cm), C.c_float(min_distance), _p(out))
+    return np.transpose(out[:m].reshape(-1, 4, 4), (0, 2, 1)).copy()
+
+
+def load_ply(path, capacity=1 << 20):
+    xyz = np.zeros((capacity, 3), np.float32); rgb = np.zeros((capacity, 3), np.float32); hc = C.c_int()
+    n = lib().orc_load_ply(path.encode(), _p(xyz), _p(rgb), capacity, C.byref(hc))
+    if n < 0:
+        return None, None
+    return xyz[:n].copy(), (rgb[:n].copy() if hc.value else None)

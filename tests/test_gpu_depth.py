@@ -82,3 +82,27 @@ def test_deproject_empty_and_capacity(ctx, orc, tdv):
     xyz, _ = ctx.deproject(d, None, 100, 100, 8, 8, 1.5)
     ref, _ = orc.unproject(d, None, 100, 100, 8, 8, 1.5)
     assert len(xyz) == 256 and np.array_equal(np.isnan(xyz), np.isnan(ref))
+
+
+def test_bilateral_filter(ctx, orc):
+    """cuda/depth_processing.cu:62-155 restated; only expf may differ in the last bits."""
+    rng = np.random.default_rng(5)
+    d = (0.8 + 0.05 * rng.random((123, 211))).astype(np.float32)
+    d[rng.random(d.shape) < 0.15] = 0.0
+    for ss, sr in ((1.5, 0.02), (0.6, 0.01), (4.0, 0.05)):  # radius 3, 1, clamped 5
+        got = ctx.bilateral_filter(d, ss, sr)
+        ref = orc.bilateral_filter(d, ss, sr)
+        assert np.array_equal(got == 0, ref == 0) and np.array_equal(got == 0, d == 0)
+        assert np.abs(got - ref).max() <= 2e-6
+
+
+def test_label_image_masks(ctx, orc, tdv):
+    """one u8 label image instead of one full-frame mask per instance."""
+    raw, _, bgr = _random_frame(9, 97, 131)
+    labels = np.random.default_rng(1).integers(0, 4, raw.shape).astype(np.uint8)
+    for lab in (1, 2, 3):
+        binmask = np.where(labels == lab, 255, 0).astype(np.uint8)
+        ref_xyz, ref_rgb = ctx.depth_to_cloud(raw, binmask, bgr, 1000.0, 600, 600, 65, 48, 10.0)
+        xyz, rgb = ctx.depth_to_cloud(raw, labels, bgr, 1000.0, 600, 600, 65, 48, 10.0, tdv.TDV_MASK_LABEL_BASE + lab)
+        assert xyz.tobytes() == ref_xyz.tobytes() and rgb.tobytes() == ref_rgb.tobytes()
+        assert ctx.depth_preprocess(raw, labels, 1000.0, tdv.TDV_MASK_LABEL_BASE + lab).tobytes() == orc.depth_preprocess(raw, binmask, 1000.0).tobytes()

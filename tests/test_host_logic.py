@@ -70,3 +70,40 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "liboracle" not in text and "oracle/" not in text.replace("# oracle/", ""), f
+
+
+def test_filter_duplicates_matches_reference_semantics(tdv, orc):
+    """src/pipeline.cpp:153-180: greedy, order-dependent; a duplicate replaces the kept pose only if it is
+    closer to the origin; comparison is against the CURRENT kept pose."""
+    rng = np.random.default_rng(3)
+    poses = np.tile(np.eye(4, dtype=np.float32), (60, 1, 1))
+    centers = rng.random((8, 3)).astype(np.float32) * 2
+    poses[:, :3, 3] = centers[rng.integers(0, 8, 60)] + (rng.random((60, 3)).astype(np.float32) - 0.5) * 0.08
+    got = tdv.filter_duplicates(poses, 0.1)
+    ref = orc.filter_duplicates(poses, 0.1)
+    assert got.shape == ref.shape and np.array_equal(got, ref) and 8 <= len(got) <= 20
+    assert len(tdv.filter_duplicates(poses[:0], 0.1)) == 0
+    two = poses[:2].copy(); two[0, :3, 3] = [1, 0, 0]; two[1, :3, 3] = [0.95, 0, 0]
+    out = tdv.filter_duplicates(two, 0.1)
+    assert len(out) == 1 and out[0, 0, 3] == np.float32(0.95)  # the closer one replaces the first
+
+
+def test_ply_loader_keeps_the_reference_quirk(tdv, orc, tmp_path):
+    """src/registration.cpp:430-440: the header loop swallows the first vertex line; the last read fails."""
+    p = tmp_path / "model.ply"
+    verts = [(0.1 * i, 0.2 * i, 0.3 * i, 10 * i, 20 * i, 30 * i) for i in range(1, 6)]
+    p.write_text("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 5\nproperty float x\nproperty float y\nproperty float z\n"
+                 "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n"
+                 + "".join("%g %g %g %d %d %d\n" % v for v in verts))
+    cloud = tdv.load_reference_model(str(p))
+    ref_xyz, ref_rgb = orc.load_ply(str(p))
+    assert cloud.size() == 5 and cloud.hasColors()
+    assert np.array_equal(cloud.points, ref_xyz) and np.array_equal(cloud.colors, ref_rgb)
+    assert np.allclose(cloud.points[0], [0.2, 0.4, 0.6])          # vertex 0 was skipped
+    assert np.array_equal(cloud.points[4], [0, 0, 0])             # the failed last read
+    assert np.allclose(cloud.colors[0], np.array([20, 40, 60]) / 255.0)
+    q = tmp_path / "nocolor.ply"
+    q.write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n4 5 6\n7 8 9\n")
+    c2 = tdv.load_reference_model(str(q))
+    assert c2.size() == 3 and not c2.hasColors() and np.array_equal(c2.points[:2], [[4, 5, 6], [7, 8, 9]])
+    assert tdv.load_reference_model(str(tmp_path / "missing.ply")).empty()
