@@ -112,6 +112,9 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
                          const float* h_xyz_for_reference_order, float* d_out_xyz, float* d_out_rgb, int capacity,
                          int* n_out);
 
+int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
+size_t sort_pow2(size_t n);                                      // padded record count for sort_records_dev
+
 int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr, const uint8_t* d_masks, int n_instances,
                        const tdv_batch_params* prm, const float* d_model_xyz, const float* d_model_normals,
                        const float* d_model_fpfh, int n_model, tdv_instance_result* results);

@@ -103,6 +103,20 @@ void k_bitonic_local_merge(uint4* __restrict__ rec, unsigned k) {
     rec[base + t] = s[t]; rec[base + t + BT_THREADS] = s[t + BT_THREADS];
 }
 
+// ascending bitonic sort of n_pow2 (power of two, >= BT_TILE) uint4 records by (x, y, z, w); also used by knn.hip
+int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2) {
+    hipStream_t s = ctx->stream;
+    const unsigned tiles = (unsigned)(n_pow2 / BT_TILE);
+    k_bitonic_local_sort<<<tiles, BT_THREADS, 0, s>>>(rec);
+    for (size_t k = (size_t)BT_TILE << 1; k <= n_pow2; k <<= 1) {
+        for (size_t j = k >> 1; j >= BT_TILE; j >>= 1)
+            k_bitonic_global_step<<<(unsigned)((n_pow2 / 2 + 255) / 256), 256, 0, s>>>(rec, n_pow2 / 2, (unsigned)k, (unsigned)j);
+        k_bitonic_local_merge<<<tiles, BT_THREADS, 0, s>>>(rec, (unsigned)k);
+    }
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
 // leader[idx] = 1 for the smallest input index of each voxel
 __global__ void k_voxel_heads(const uint4* __restrict__ rec, int n, int* __restrict__ leader) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -216,6 +230,8 @@ struct VoxelKeyHash {  // the reference's combiner (registration.cpp:20-27)
 };
 }  // namespace
 
+size_t sort_pow2(size_t n) { size_t p = BT_TILE; while (p < n) p <<= 1; return p; }
+
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
                          const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out) {
     if (!ctx || !n_out || n < 0 || capacity < 0 || !(voxel > 0.f) || (n > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
@@ -236,13 +252,7 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     TDV_TRY(pin_reserve(ctx, 64));
     ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
     k_voxel_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, inv, rec);
-    const unsigned tiles = (unsigned)(n_pow2 / BT_TILE);
-    k_bitonic_local_sort<<<tiles, BT_THREADS, 0, s>>>(rec);
-    for (size_t k = (size_t)BT_TILE << 1; k <= n_pow2; k <<= 1) {
-        for (size_t j = k >> 1; j >= BT_TILE; j >>= 1)
-            k_bitonic_global_step<<<(unsigned)((n_pow2 / 2 + 255) / 256), 256, 0, s>>>(rec, n_pow2 / 2, (unsigned)k, (unsigned)j);
-        k_bitonic_local_merge<<<tiles, BT_THREADS, 0, s>>>(rec, (unsigned)k);
-    }
+    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
     TDV_HIP(ctx, hipMemsetAsync(leader, 0, (size_t)n * 4, s));
     k_voxel_heads<<<(n + 255) / 256, 256, 0, s>>>(rec, n, leader);
     k_scan_reduce<<<sblocks, 1024, 0, s>>>(leader, n, sums);
