@@ -162,6 +162,15 @@ def main():
         # algorithmic HBM bytes of one ICP iteration: 12*N_s + 24*N_t + 124
         icp_bytes = 12.0 * n + 24.0 * n + 124
         sc_avg_ms = sc_ms / max(sc_launches, 1)
+        # HBM traffic of the dominant kernel from the PMC passes (rocprofv3 --pmc cannot run inside this process):
+        # taken from the committed summary of the same command when it covers this workload, else null
+        traffic, traffic_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")))
+            if pm["workload"]["n_src"] == n and pm["workload"]["n_tgt"] == n:
+                traffic = pm["dominant_kernel_bytes_per_launch"]; traffic_src = "profiles/r1/pmc_summary.json (separate rocprofv3 --pmc passes)"
+        except Exception:
+            pass
         out = {
             "metric": "RANSAC hyps/s + ICP iters/s @ 200k-pt clouds",
             "value": steps_total / elapsed,
@@ -184,7 +193,7 @@ def main():
                 "avg_launch_ms": nn_avg_ms, "launches": nn_launches,
                 "hbm": {"algorithmic_bytes_per_launch": icp_bytes, "achieved": icp_bytes / (nn_avg_ms * 1e-3) / 1e9,
                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": icp_bytes / (nn_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                "traffic": None,
+                "traffic": traffic, "traffic_unit": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                 "second_kernel": {"kernel": "k_ransac_score", "avg_launch_ms": sc_avg_ms, "launches": sc_launches,
                                   "achieved": 28.0 * float(n) * args.steps * HYPS_PER_STEP / max(sc_ms * 1e-3, 1e-12) / 1e12,
                                   "peak": VALU_PEAK_TOPS, "unit": "Tops/s (28 VALU ops per hypothesis-point)"},
