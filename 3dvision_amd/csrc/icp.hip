@@ -33,7 +33,8 @@ namespace tdv {
 
 constexpr int NN_SPL = 2;      // source points per lane
 constexpr int NN_CH = 16;      // targets per chunk (one s_load_dwordx16 per coordinate)
-constexpr int NN_BLOCK = 256;
+constexpr int NN_BLOCK = 128;    // two waves per workgroup (no LDS, no barrier): many workgroups with few target splits,
+                                 // so the per-split partials (8 B per source per split) stay small
 constexpr int NN_SRC_PER_BLOCK = NN_SPL * NN_BLOCK;
 constexpr int ACC_NV = 32;     // reduction slots per block (29 used p2plane, 17 p2point)
 
