@@ -39,8 +39,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &nrm));
         TDV_TRY(ws_alloc(ctx, (size_t)v * 33, &fpfh));
         TDV_TRY(ws_alloc(ctx, (size_t)v, &corr));
-        TDV_TRY(estimate_normals_dev(ctx, vx, v, prm->normals_k, nrm, nullptr));
-        TDV_TRY(compute_fpfh_dev(ctx, vx, nrm, v, prm->voxel_size * prm->fpfh_radius_factor, fpfh, nullptr, nullptr));
+        TDV_TRY(normals_fpfh_dev(ctx, vx, v, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor, nrm, fpfh));
         tdv_ransac_result coarse;
         TDV_TRY(feature_match_dev(ctx, fpfh, v, d_model_fpfh, n_model, corr));
         TDV_TRY(ransac_run_dev(ctx, vx, v, d_model_xyz, n_model, nullptr, nullptr, corr, prm->voxel_size, prm->ransac_max_iterations,
@@ -83,8 +82,7 @@ int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_s
     if (n == 0) return TDV_OK;
     int v = 0;
     TDV_TRY(voxel_downsample_dev(ctx, d_xyz, nullptr, n, voxel_size, TDV_VOXEL_ORDER_FIRST, nullptr, d_out_xyz, nullptr, n, &v));
-    TDV_TRY(estimate_normals_dev(ctx, d_out_xyz, v, normals_k, d_out_normals, nullptr));
-    TDV_TRY(compute_fpfh_dev(ctx, d_out_xyz, d_out_normals, v, voxel_size * fpfh_radius_factor, d_out_fpfh, nullptr, nullptr));
+    TDV_TRY(normals_fpfh_dev(ctx, d_out_xyz, v, normals_k, voxel_size * fpfh_radius_factor, d_out_normals, d_out_fpfh));
     TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = v;
     return TDV_OK;

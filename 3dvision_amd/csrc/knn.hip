@@ -63,12 +63,20 @@ void k_bbox_partial(const float* __restrict__ xyz, int n, float* __restrict__ pa
         part[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
-__global__ void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ bbox /* min xyz, max xyz */) {
-    int c = threadIdx.x;
-    if (c >= 6) return;
-    float v = part[c];
-    for (int b = 1; b < nblocks; ++b) v = c < 3 ? fminf(v, part[b * 6 + c]) : fmaxf(v, part[b * 6 + c]);
-    bbox[c] = v;
+__global__ __launch_bounds__(64)
+void k_bbox_final(const float* __restrict__ part, int nblocks, float* __restrict__ bbox /* min xyz, max xyz */) {
+    // one wave: lane l folds partials l, l+64, ... for all 6 components, then a shuffle reduction
+    float v[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[c] = c < 3 ? INFINITY : -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += 64)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] = c < 3 ? fminf(v[c], part[b * 6 + c]) : fmaxf(v[c], part[b * 6 + c]);
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { float o = __shfl_down(v[c], off, 64); v[c] = c < 3 ? fminf(v[c], o) : fmaxf(v[c], o); }
+    if (threadIdx.x == 0) for (int c = 0; c < 6; ++c) bbox[c] = v[c];
 }
 __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
     v &= 0x3ffu;
@@ -163,12 +171,16 @@ template <int K>
 __global__ __launch_bounds__(KN_BLOCK, 4)   // 4 waves per SIMD: keeps the K = 30 instance within 128 VGPRs
 void k_topk_scan_reg(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
                      const int* __restrict__ orig, int nq, int nq_pad, int n_chunks, int nsplit, int k, float bound0,
+                     const int* __restrict__ qsel, int nsel,   // optional: the queries are sorted positions qsel[0..nsel)
                      float* __restrict__ out_d, int* __restrict__ out_i, int* __restrict__ out_cnt) {
     const int split = blockIdx.y;
     const int qi = blockIdx.x * KN_BLOCK + threadIdx.x;
-    const int qc = min(qi, nq - 1);
+    const int nqq = qsel ? nsel : nq;                       // number of queries of this launch
+    const int qslot = min(qi, nqq - 1);
+    const int qc = qsel ? qsel[qslot] : qslot;               // sorted position of this lane's query
     const float qx = sx[qc], qy = sy[qc], qz = sz[qc];
-    const int cc = min((blockIdx.x * KN_BLOCK + KN_BLOCK / 2) / KN_CH, n_chunks - 1);
+    const int mid = min(blockIdx.x * KN_BLOCK + KN_BLOCK / 2, nqq - 1);
+    const int cc = min((qsel ? qsel[mid] : mid) / KN_CH, n_chunks - 1);
     float Ld[K]; int Li[K];
 #pragma unroll
     for (int e = 0; e < K; ++e) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
@@ -218,6 +230,156 @@ void k_topk_scan_reg(const float* __restrict__ sx, const float* __restrict__ sy,
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ two-phase kNN: window bound -> collect scan -> select
+// Phase A: an upper bound on each query's k-th neighbour distance from a small window around its own position
+// on the Morton curve (a subset of the cloud, so its k-th smallest distance can only be >= the true one).
+// One lane per query, per-lane (vector) loads, a register-resident sorted list of distances only.
+template <int K>
+__global__ __launch_bounds__(KN_BLOCK)
+void k_window_bound(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                    int n, const int* __restrict__ qsel, int nqq, int k, int half_window, float* __restrict__ bound) {
+    const int slot = blockIdx.x * KN_BLOCK + threadIdx.x;
+    const int sl = min(slot, nqq - 1);
+    const int sp = qsel ? qsel[sl] : sl;
+    const float qx = sx[sp], qy = sy[sp], qz = sz[sp];
+    int lo = max(0, sp - half_window), hi = min(n, sp + half_window);
+    if (hi - lo < 2 * half_window) { if (lo == 0) hi = min(n, 2 * half_window); else lo = max(0, n - 2 * half_window); }
+    float Ld[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) Ld[e] = INFINITY;
+    const int len = hi - lo;
+    int maxlen = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    for (int it = 0; it < maxlen; ++it) {
+        const bool in = it < len;
+        const int p = in ? lo + it : sp;
+        float dx = sx[p] - qx, dy = sy[p] - qy, dz = sz[p] - qz;
+        float d2 = dx * dx + (dy * dy + dz * dz);
+        if (!in) d2 = INFINITY;
+        if (__any(d2 < Ld[K - 1])) {   // compare-and-shift insertion of a distance (indices are irrelevant for a bound)
+            bool lt_cur = d2 < Ld[K - 1];
+#pragma unroll
+            for (int e = K - 1; e >= 1; --e) {
+                bool lt_prev = d2 < Ld[e - 1];
+                Ld[e] = lt_prev ? Ld[e - 1] : (lt_cur ? d2 : Ld[e]);
+                lt_cur = lt_prev;
+            }
+            Ld[0] = lt_cur ? d2 : Ld[0];
+        }
+    }
+    float kth = Ld[K - 1];
+    if (k < K) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) if (e == k - 1) kth = Ld[e];
+    }
+    if (slot < nqq) bound[slot] = kth;   // +inf when the window holds fewer than k points
+}
+
+// Phase B: the full brute-force scan with a FIXED per-query bound and no selection state in the loop:
+// two queries per lane, 16 targets per scalar-load step (the ICP scan's shape).  Every target with d2 <= bound is
+// appended to the query's candidate row (64-bit key = d2 bits : original index; order in the row is irrelevant).
+constexpr int CS_SPL = 2;
+constexpr int CS_CH = 16;
+__global__ __launch_bounds__(KN_BLOCK)
+void k_collect_scan(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                    const int* __restrict__ orig, int n, int n_chunks, int chunks_per_split,
+                    const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, int cap,
+                    int* __restrict__ cnt, unsigned long long* __restrict__ cand) {
+    const int split = blockIdx.y;
+    const int c0 = split * chunks_per_split, c1 = min(n_chunks, c0 + chunks_per_split);
+    float qx[CS_SPL], qy[CS_SPL], qz[CS_SPL], B[CS_SPL];
+    int slot[CS_SPL];
+#pragma unroll
+    for (int s = 0; s < CS_SPL; ++s) {
+        slot[s] = blockIdx.x * (KN_BLOCK * CS_SPL) + s * KN_BLOCK + threadIdx.x;
+        const int sl = min(slot[s], nqq - 1);
+        const int sp = qsel ? qsel[sl] : sl;
+        qx[s] = sx[sp]; qy[s] = sy[sp]; qz[s] = sz[sp];
+        B[s] = slot[s] < nqq ? bound[sl] : -1.f;   // padding lanes never accept
+    }
+    for (int c = c0; c < c1; ++c) {
+        const int j = c * CS_CH;
+        float tx[CS_CH], ty[CS_CH], tz[CS_CH];   // wave-uniform: three s_load_dwordx16
+#pragma unroll
+        for (int t = 0; t < CS_CH; ++t) { tx[t] = sx[j + t]; ty[t] = sy[j + t]; tz[t] = sz[j + t]; }
+        bool hit = false;
+#pragma unroll
+        for (int s = 0; s < CS_SPL; ++s) {
+            float m = INFINITY;
+#pragma unroll
+            for (int t = 0; t < CS_CH; ++t) {
+                float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];   // (points[i] - query)
+                float d2 = dx * dx + (dy * dy + dz * dz);
+                m = fminf(m, d2);
+            }
+            hit |= m <= B[s];
+        }
+        if (!__any(hit)) continue;
+#pragma unroll
+        for (int s = 0; s < CS_SPL; ++s) {
+#pragma unroll
+            for (int t = 0; t < CS_CH; ++t) {
+                float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];
+                float d2 = dx * dx + (dy * dy + dz * dz);
+                const bool acc = (j + t < n) && d2 <= B[s];
+                if (__any(acc)) {
+                    const int oi = orig[j + t];
+                    if (acc) {
+                        int at = atomicAdd(&cnt[slot[s]], 1);
+                        if (at < cap) cand[(size_t)slot[s] * cap + at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)oi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Phase C: exact top-k of a query's candidates in (d2, idx) order; the final list goes to lists[r*n_pad + i], cnt_out[i]
+// (by original index).  overflow[slot] = 1 when the row was too small (the caller re-runs those queries by streaming).
+template <int K>
+__global__ __launch_bounds__(KN_BLOCK)
+void k_select_topk(const int* __restrict__ orig, const int* __restrict__ qsel, int nqq, int k, int cap, int n_pad,
+                   const int* __restrict__ cnt, const unsigned long long* __restrict__ cand,
+                   int* __restrict__ lists, int* __restrict__ cnt_out, int* __restrict__ overflow, float* __restrict__ bound_next) {
+    const int slot = blockIdx.x * KN_BLOCK + threadIdx.x;
+    const bool live = slot < nqq;
+    const int sl = min(slot, nqq - 1);
+    const int m_all = live ? cnt[sl] : 0;
+    const int m = min(m_all, cap);
+    float Ld[K]; int Li[K];
+#pragma unroll
+    for (int e = 0; e < K; ++e) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
+    int maxm = m;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxm = max(maxm, __shfl_xor(maxm, off, 64));
+    for (int e = 0; e < maxm; ++e) {
+        unsigned long long key = e < m ? cand[(size_t)sl * cap + e] : ~0ull;
+        float d = e < m ? __uint_as_float((unsigned)(key >> 32)) : INFINITY;
+        int i = e < m ? (int)(unsigned)key : INT_MAX;
+        reg_insert<K>(Ld, Li, d, i);
+    }
+    if (!live) return;
+    const int i0 = orig[qsel ? qsel[sl] : sl];
+    const int c = min(k, m);
+#pragma unroll
+    for (int e = 0; e < K; ++e) if (e < c) lists[(size_t)e * n_pad + i0] = Li[e];
+    cnt_out[i0] = c;
+    overflow[slot] = m_all > cap ? 1 : 0;
+    // an overflowed row still holds cap >= k real candidates: their k-th smallest distance is a valid, tighter bound
+    float kth = Ld[K - 1];
+    if (k < K) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) if (e == k - 1) kth = Ld[e];
+    }
+    bound_next[slot] = kth;
+}
+__global__ void k_compact_overflow(const int* __restrict__ flag, const int* __restrict__ pos, const int* __restrict__ qsel, int nqq,
+                                   const float* __restrict__ bound_next, int* __restrict__ qsel2, float* __restrict__ bound2) {
+    int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot < nqq && flag[slot]) { qsel2[pos[slot]] = qsel ? qsel[slot] : slot; bound2[pos[slot]] = bound_next[slot]; }  // ascending sorted positions
 }
 
 // ------------------------------------------------------------------ global-list top-k (any k; FPFH radius search)
@@ -343,28 +505,44 @@ __device__ __forceinline__ int merge_splits(const float* __restrict__ pd, const 
     return out;
 }
 
-// ------------------------------------------------------------------ normals (registration.cpp:105-130)
-// one lane per SORTED position sp; everything is written at the point's original index
+// ------------------------------------------------------------------ list finishing (shared by kNN and radius)
+// k-way merge of the per-split lists of each query of the launch (all sorted positions, or the subset qsel);
+// the final list is stored BY ORIGINAL POINT INDEX: lists[r * n_pad + i], cnt[i].
 __global__ __launch_bounds__(KN_BLOCK)
-void k_normals_finish(const float* __restrict__ xyz, const int* __restrict__ orig, int n, int n_pad, int k, int nsplit,
-                      const float* __restrict__ pd, const int* __restrict__ pi, const int* __restrict__ pc,
-                      int* __restrict__ nbr /* [k][n_pad] scratch, by sorted position */, float* __restrict__ normals,
-                      int* __restrict__ knn_out, int knn_stride) {
-    const int sp = blockIdx.x * KN_BLOCK + threadIdx.x;
-    if (sp >= n) return;
-    const int i = orig[sp];
-    int cnt = merge_splits(pd, pi, pc, nsplit, k, n_pad, sp, [&](int r, float, int idx) { nbr[(size_t)r * n_pad + sp] = idx; });
-    if (knn_out) for (int r = 0; r < knn_stride; ++r) knn_out[(size_t)i * knn_stride + r] = r < cnt ? nbr[(size_t)r * n_pad + sp] : -1;
+void k_lists_finish(const int* __restrict__ orig, const int* __restrict__ qsel, int nqq, int nq_pad, int n_pad, int k, int nsplit,
+                    const float* __restrict__ pd, const int* __restrict__ pi, const int* __restrict__ pc,
+                    int* __restrict__ lists, int* __restrict__ cnt) {
+    const int slot = blockIdx.x * KN_BLOCK + threadIdx.x;
+    if (slot >= nqq) return;
+    const int i = orig[qsel ? qsel[slot] : slot];
+    int c = merge_splits(pd, pi, pc, nsplit, k, nq_pad, slot, [&](int r, float, int idx) { lists[(size_t)r * n_pad + i] = idx; });
+    cnt[i] = c;
+}
+
+// ------------------------------------------------------------------ normals (registration.cpp:105-130)
+// One lane per point (original index).  The k nearest neighbours come from listsA when it holds at least k
+// entries (FPFH's radius list: sorted by (d2, idx), so its first k ARE the k nearest), else from listsB (kNN scan).
+__global__ __launch_bounds__(KN_BLOCK)
+void k_normals_from_lists(const float* __restrict__ xyz, int n, int n_pad, int k,
+                          const int* __restrict__ listsA, const int* __restrict__ cntA,
+                          const int* __restrict__ listsB, const int* __restrict__ cntB,
+                          float* __restrict__ normals, int* __restrict__ knn_out, int knn_stride) {
+    const int i = blockIdx.x * KN_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const bool useA = listsA && cntA[i] >= k;
+    const int* __restrict__ L = useA ? listsA : listsB;
+    const int cnt = useA ? k : cntB[i];
+    if (knn_out) for (int r = 0; r < knn_stride; ++r) knn_out[(size_t)i * knn_stride + r] = r < cnt ? L[(size_t)r * n_pad + i] : -1;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     for (int r = 0; r < cnt; ++r) {
-        int j = nbr[(size_t)r * n_pad + sp];
+        int j = L[(size_t)r * n_pad + i];
         cx += xyz[3 * (size_t)j]; cy += xyz[3 * (size_t)j + 1]; cz += xyz[3 * (size_t)j + 2];
     }
     const float fc = (float)cnt;
     cx /= fc; cy /= fc; cz /= fc;
     float c00 = 0.f, c10 = 0.f, c20 = 0.f, c11 = 0.f, c21 = 0.f, c22 = 0.f;
     for (int r = 0; r < cnt; ++r) {
-        int j = nbr[(size_t)r * n_pad + sp];
+        int j = L[(size_t)r * n_pad + i];
         float dx = xyz[3 * (size_t)j] - cx, dy = xyz[3 * (size_t)j + 1] - cy, dz = xyz[3 * (size_t)j + 2] - cz;
         c00 += dx * dx; c10 += dy * dx; c20 += dz * dx; c11 += dy * dy; c21 += dz * dy; c22 += dz * dz;
     }
@@ -377,19 +555,18 @@ void k_normals_finish(const float* __restrict__ xyz, const int* __restrict__ ori
     normals[3 * (size_t)i] = nx; normals[3 * (size_t)i + 1] = ny; normals[3 * (size_t)i + 2] = nz;
 }
 
+// deficient[sp] = 1 if the radius list of the point at sorted position sp has fewer than k entries
+__global__ void k_flag_deficient(const int* __restrict__ orig, const int* __restrict__ cntA, int n, int k, int* __restrict__ flag) {
+    int sp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sp < n) flag[sp] = cntA[orig[sp]] < k ? 1 : 0;
+}
+__global__ void k_compact_flagged(const int* __restrict__ flag, const int* __restrict__ pos, int n, int* __restrict__ qsel) {
+    int sp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sp < n && flag[sp]) qsel[pos[sp]] = sp;   // ascending sorted positions: the subset stays spatially coherent
+}
+
 // ------------------------------------------------------------------ FPFH (registration.cpp:133-201)
 constexpr int FP_MAXNN = 100;
-
-// lists are re-indexed by ORIGINAL point index here so that the SPFH / FPFH passes run in input order
-__global__ __launch_bounds__(KN_BLOCK)
-void k_radius_finish(const int* __restrict__ orig, int n, int n_pad, int nsplit, const float* __restrict__ pd, const int* __restrict__ pi,
-                     const int* __restrict__ pc, int* __restrict__ nbr /* [100][n_pad] by original index */, int* __restrict__ nbr_cnt) {
-    const int sp = blockIdx.x * KN_BLOCK + threadIdx.x;
-    if (sp >= n) return;
-    const int i = orig[sp];
-    int cnt = merge_splits(pd, pi, pc, nsplit, FP_MAXNN, n_pad, sp, [&](int r, float, int idx) { nbr[(size_t)r * n_pad + i] = idx; });
-    nbr_cnt[i] = cnt;
-}
 
 __global__ __launch_bounds__(KN_BLOCK)
 void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, int n_pad,
@@ -474,17 +651,22 @@ namespace {
 
 struct ScanPlan { int n_pad, nt_pad, n_chunks, blocks_x, nsplit; };
 
+int pick_nsplit(int blocks_x, int n_chunks) {
+    // interleaved splits: enough workgroups for a short tail (>= ~6k), each split keeping >= 64 chunks
+    int want = (6144 + blocks_x - 1) / blocks_x;
+    int max_split = std::max(1, n_chunks / 64);
+    int nsplit = std::max(1, std::min(std::min(want, max_split), KN_MAXSPLIT));
+    if (const char* e = getenv("TDV_KNN_NSPLIT")) nsplit = std::max(1, std::min(std::min(atoi(e), max_split), KN_MAXSPLIT));  // tuning knob
+    return nsplit;
+}
+
 ScanPlan make_scan_plan(int n) {
     ScanPlan p;
     p.n_pad = (int)align_up((size_t)n, KN_BLOCK);
     p.nt_pad = (int)align_up((size_t)n, KN_CH);
     p.n_chunks = p.nt_pad / KN_CH;
     p.blocks_x = p.n_pad / KN_BLOCK;
-    // interleaved splits: enough workgroups for a short tail (>= ~6k), each split keeping >= 64 chunks
-    int want = (6144 + p.blocks_x - 1) / p.blocks_x;
-    int max_split = std::max(1, p.n_chunks / 64);
-    p.nsplit = std::max(1, std::min(std::min(want, max_split), KN_MAXSPLIT));
-    if (const char* e = getenv("TDV_KNN_NSPLIT")) p.nsplit = std::max(1, std::min(std::min(atoi(e), max_split), KN_MAXSPLIT));  // tuning knob
+    p.nsplit = pick_nsplit(p.blocks_x, p.n_chunks);
     return p;
 }
 
@@ -494,7 +676,7 @@ struct Sorted { float *sx, *sy, *sz; int* orig; };
 int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sorted& so) {
     hipStream_t s = ctx->stream;
     const size_t n_pow2 = sort_pow2((size_t)n);
-    const int pad = std::max(p.n_pad, p.nt_pad);
+    const int pad = std::max(p.n_pad, (int)align_up((size_t)p.nt_pad, 16));   // multiple of 256 >= n: covers 8- and 16-target chunks
     float* soa; uint4* rec; float *part, *bbox;
     TDV_TRY(ws_alloc(ctx, (size_t)3 * pad, &soa));
     TDV_TRY(ws_alloc(ctx, (size_t)pad, &so.orig));
@@ -512,25 +694,107 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     return TDV_OK;
 }
 
-int run_scan(tdv_ctx* ctx, const float* d_xyz, int n, int k, float bound0, int timer, const ScanPlan& p, Sorted& so,
-             float** pd, int** pi, int** pc) {
-    TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
-    TDV_TRY(ws_alloc(ctx, (size_t)p.nsplit * k * p.n_pad, pd));
-    TDV_TRY(ws_alloc(ctx, (size_t)p.nsplit * k * p.n_pad, pi));
-    TDV_TRY(ws_alloc(ctx, (size_t)p.nsplit * p.n_pad, pc));
+// Scan + per-split lists + merge into lists[r * p.n_pad + original index] / cnt[original index].
+// qsel == nullptr: all n queries; else the nsel sorted positions in qsel (device).
+int scan_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, float bound0, int timer,
+                  const int* qsel, int nsel, int* lists, int* cnt) {
+    const int nqq = qsel ? nsel : n;
+    if (nqq <= 0) return TDV_OK;
+    const int nq_pad = (int)align_up((size_t)nqq, KN_BLOCK);
+    const int blocks_x = nq_pad / KN_BLOCK;
+    const int nsplit = qsel ? pick_nsplit(blocks_x, p.n_chunks) : p.nsplit;
+    float* pd; int *pi, *pc;
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * k * nq_pad, &pd));
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * k * nq_pad, &pi));
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * nq_pad, &pc));
     hipStream_t s = ctx->stream;
     {
         ScopedTimer tm(ctx, timer);
-        dim3 grid(p.blocks_x, p.nsplit);
-#define TDV_REG_SCAN(KK) k_topk_scan_reg<KK><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, p.n_pad, p.n_chunks, p.nsplit, k, bound0, *pd, *pi, *pc)
+        dim3 grid(blocks_x, nsplit);
+#define TDV_REG_SCAN(KK) k_topk_scan_reg<KK><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, p.n_chunks, nsplit, k, bound0, qsel, nsel, pd, pi, pc)
         if (k <= 8) TDV_REG_SCAN(8);
         else if (k <= 16) TDV_REG_SCAN(16);
         else if (k <= 30) TDV_REG_SCAN(30);
         else if (k <= 32) TDV_REG_SCAN(32);
-        else k_topk_scan_glob<<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, p.n_pad, p.n_chunks, p.nsplit, k, bound0, *pd, *pi, *pc);
+        else {
+            if (qsel) return TDV_ERR_INTERNAL;  // subset scans are only issued for k <= 32
+            k_topk_scan_glob<<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, p.n_chunks, nsplit, k, bound0, pd, pi, pc);
+        }
 #undef TDV_REG_SCAN
     }
+    k_lists_finish<<<blocks_x, KN_BLOCK, 0, s>>>(so.orig, qsel, nqq, nq_pad, p.n_pad, k, nsplit, pd, pi, pc, lists, cnt);
     TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+}  // namespace
+
+namespace {
+
+constexpr int CS_CAP = 128;       // candidate row per query (k <= 32): typical fill 30-70
+constexpr int CS_HALF_WINDOW = 384;
+
+// exact kNN lists (k <= 32) of all queries (qsel == nullptr) or of the subset qsel, by the two-phase scheme;
+// queries whose candidate row overflows (or whose window gave no finite bound) are redone by the streaming scan.
+int knn_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, const int* qsel, int nsel, int* lists, int* cnt) {
+    int nqq = qsel ? nsel : n;
+    if (nqq <= 0) return TDV_OK;
+    hipStream_t s = ctx->stream;
+    const int nq_pad = (int)align_up((size_t)nqq, KN_BLOCK * CS_SPL);
+    float *bound, *bnext, *bound2; int *ccnt, *ovf, *pos, *qselA, *qselB, *d_total; unsigned long long* cand;
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &bound));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &bnext));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &bound2));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &ccnt));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &ovf));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &pos));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &qselA));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &qselB));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad * CS_CAP, &cand));
+    TDV_TRY(pin_reserve(ctx, 64));
+    int* h_total = reinterpret_cast<int*>(ctx->pin);
+    const int n_chunks16 = (int)(align_up((size_t)n, CS_CH) / CS_CH);   // the sorted arrays are padded to >= this (spatial_sort)
+    const int* cur_q = qsel;
+    float* cur_b = bound;
+    int* next_q = qselA;
+    {   // phase A: bounds from the local window
+        ScopedTimer tm(ctx, TDV_TIMER_KNN);
+        const int qblocks = (nqq + KN_BLOCK - 1) / KN_BLOCK;
+#define TDV_WB(KK) k_window_bound<KK><<<qblocks, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, n, cur_q, nqq, k, CS_HALF_WINDOW, cur_b)
+        if (k <= 8) TDV_WB(8); else if (k <= 16) TDV_WB(16); else if (k <= 30) TDV_WB(30); else TDV_WB(32);
+#undef TDV_WB
+    }
+    for (int round = 0; round < 8 && nqq > 0; ++round) {
+        const int qblocks = (nqq + KN_BLOCK - 1) / KN_BLOCK;
+        const int cblocks = (nqq + KN_BLOCK * CS_SPL - 1) / (KN_BLOCK * CS_SPL);
+        int want = (8192 + cblocks - 1) / cblocks;
+        int csplit = std::max(1, std::min(want, std::max(1, n_chunks16 / 16)));
+        int cps = (n_chunks16 + csplit - 1) / csplit;
+        csplit = (n_chunks16 + cps - 1) / cps;
+        TDV_HIP(ctx, hipMemsetAsync(ccnt, 0, (size_t)nqq * 4, s));
+        {
+            ScopedTimer tm(ctx, TDV_TIMER_KNN);
+            k_collect_scan<<<dim3(cblocks, csplit), KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, n_chunks16, cps, cur_q, nqq, cur_b, CS_CAP, ccnt, cand);
+#define TDV_SEL(KK) k_select_topk<KK><<<qblocks, KN_BLOCK, 0, s>>>(so.orig, cur_q, nqq, k, CS_CAP, p.n_pad, ccnt, cand, lists, cnt, ovf, bnext)
+            if (k <= 8) TDV_SEL(8); else if (k <= 16) TDV_SEL(16); else if (k <= 30) TDV_SEL(30); else TDV_SEL(32);
+#undef TDV_SEL
+        }
+        TDV_CHECK_LAUNCH(ctx);
+        // queries whose candidate row overflowed go another round with the tightened bound
+        TDV_TRY(exclusive_scan_dev(ctx, ovf, nqq, pos, d_total));
+        float* nb = (cur_b == bound2) ? bound : bound2;
+        k_compact_overflow<<<qblocks, KN_BLOCK, 0, s>>>(ovf, pos, cur_q, nqq, bnext, next_q, nb);
+        TDV_CHECK_LAUNCH(ctx);
+        TDV_HIP(ctx, hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        if (getenv("TDV_DEBUG")) fprintf(stderr, "[tdv] knn_to_lists: round %d queries=%d overflow=%d (k=%d)\n", round, nqq, *h_total, k);
+        nqq = *h_total;
+        cur_q = next_q; next_q = (next_q == qselA) ? qselB : qselA;
+        cur_b = nb;
+    }
+    // pathological leftovers (e.g. more than CS_CAP points at exactly the k-th distance): streaming scan
+    if (nqq > 0) TDV_TRY(scan_to_lists(ctx, so, n, p, k, INFINITY, TDV_TIMER_KNN, cur_q, nqq, lists, cnt));
     return TDV_OK;
 }
 
@@ -541,13 +805,31 @@ int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* 
     if (n == 0) return TDV_OK;
     const int kk = std::min(k, n);  // std::min(k, dists.size()), registration.cpp:74
     const ScanPlan p = make_scan_plan(n);
-    Sorted so; float* pd; int *pi, *pc, *nbr;
-    TDV_TRY(run_scan(ctx, d_xyz, n, kk, INFINITY, TDV_TIMER_KNN, p, so, &pd, &pi, &pc));
-    TDV_TRY(ws_alloc(ctx, (size_t)kk * p.n_pad, &nbr));
-    k_normals_finish<<<p.blocks_x, KN_BLOCK, 0, ctx->stream>>>(d_xyz, so.orig, n, p.n_pad, kk, p.nsplit, pd, pi, pc, nbr, d_normals, d_knn, k);
+    Sorted so; int *lists, *cnt;
+    TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
+    TDV_TRY(ws_alloc(ctx, (size_t)kk * p.n_pad, &lists));
+    TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
+    static const bool streaming_only = getenv("TDV_KNN_STREAMING") != nullptr;  // tuning / A-B knob
+    if (kk <= 32 && !streaming_only) TDV_TRY(knn_to_lists(ctx, so, n, p, kk, nullptr, 0, lists, cnt));
+    else TDV_TRY(scan_to_lists(ctx, so, n, p, kk, INFINITY, TDV_TIMER_KNN, nullptr, 0, lists, cnt));
+    k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, ctx->stream>>>(d_xyz, n, p.n_pad, kk, nullptr, nullptr, lists, cnt, d_normals, d_knn, k);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
+
+namespace {
+int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, const ScanPlan& p, const int* nbr, const int* cnt,
+                    float* d_desc, int* d_nbr, int* d_nbr_cnt) {
+    float* spfh;
+    TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
+    hipStream_t s = ctx->stream;
+    k_spfh<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, d_normals, n, p.n_pad, nbr, cnt, spfh);
+    k_fpfh<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, nbr, cnt, spfh, d_desc, d_nbr);
+    TDV_CHECK_LAUNCH(ctx);
+    if (d_nbr_cnt) TDV_HIP(ctx, hipMemcpyAsync(d_nbr_cnt, cnt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return TDV_OK;
+}
+}  // namespace
 
 int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
                      float* d_desc, int* d_nbr, int* d_nbr_cnt) {
@@ -555,18 +837,54 @@ int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, i
     if (n == 0) return TDV_OK;
     const float r2 = radius * radius;  // registration.cpp:89
     const ScanPlan p = make_scan_plan(n);
-    Sorted so; float* pd; int *pi, *pc, *nbr, *cnt; float* spfh;
-    TDV_TRY(run_scan(ctx, d_xyz, n, FP_MAXNN, r2, TDV_TIMER_RADIUS, p, so, &pd, &pi, &pc));
+    Sorted so; int *nbr, *cnt;
+    TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
     TDV_TRY(ws_alloc(ctx, (size_t)FP_MAXNN * p.n_pad, &nbr));
     TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
-    TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
+    TDV_TRY(scan_to_lists(ctx, so, n, p, FP_MAXNN, r2, TDV_TIMER_RADIUS, nullptr, 0, nbr, cnt));
+    return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, nbr, cnt, d_desc, d_nbr, d_nbr_cnt);
+}
+
+// estimateNormals(k) followed by computeFPFH(radius) on the same cloud (src/pipeline.cpp:93-95), sharing one
+// spatial sort and ONE full scan: the radius lists are sorted by (d2, idx), so wherever a point has >= k
+// neighbours in radius its k nearest neighbours are the first k entries; only the deficient points (isolated
+// points, silhouette edges) go through a kNN scan, as a subset.  Results are identical to the two separate calls.
+int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc) {
+    if (!ctx || n < 0 || k <= 0 || k > 255 || (n > 0 && (!d_xyz || !d_normals || !d_desc))) return TDV_ERR_BAD_ARG;
+    if (n == 0) return TDV_OK;
+    const int kk = std::min(k, n);
+    if (kk > 32 || kk > FP_MAXNN) {  // subset scans use the register kernel (k <= 32): otherwise the two plain calls
+        TDV_TRY(estimate_normals_dev(ctx, d_xyz, n, k, d_normals, nullptr));
+        return compute_fpfh_dev(ctx, d_xyz, d_normals, n, radius, d_desc, nullptr, nullptr);
+    }
+    const float r2 = radius * radius;
+    const ScanPlan p = make_scan_plan(n);
     hipStream_t s = ctx->stream;
-    k_radius_finish<<<p.blocks_x, KN_BLOCK, 0, s>>>(so.orig, n, p.n_pad, p.nsplit, pd, pi, pc, nbr, cnt);
-    k_spfh<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, d_normals, n, p.n_pad, nbr, cnt, spfh);
-    k_fpfh<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, nbr, cnt, spfh, d_desc, d_nbr);
+    Sorted so; int *nbr, *cnt, *flag, *pos, *qsel, *d_total, *listsK, *cntK;
+    TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
+    TDV_TRY(ws_alloc(ctx, (size_t)FP_MAXNN * p.n_pad, &nbr));
+    TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
+    TDV_TRY(scan_to_lists(ctx, so, n, p, FP_MAXNN, r2, TDV_TIMER_RADIUS, nullptr, 0, nbr, cnt));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &flag));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &pos));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &qsel));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_TRY(ws_alloc(ctx, (size_t)kk * p.n_pad, &listsK));
+    TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cntK));
+    k_flag_deficient<<<(n + 255) / 256, 256, 0, s>>>(so.orig, cnt, n, kk, flag);
+    TDV_TRY(exclusive_scan_dev(ctx, flag, n, pos, d_total));
+    k_compact_flagged<<<(n + 255) / 256, 256, 0, s>>>(flag, pos, n, qsel);
     TDV_CHECK_LAUNCH(ctx);
-    if (d_nbr_cnt) TDV_HIP(ctx, hipMemcpyAsync(d_nbr_cnt, cnt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-    return TDV_OK;
+    TDV_TRY(pin_reserve(ctx, 64));
+    int* h_total = reinterpret_cast<int*>(ctx->pin);
+    TDV_HIP(ctx, hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    const int nsel = *h_total;
+    if (getenv("TDV_DEBUG")) fprintf(stderr, "[tdv] normals_fpfh: n=%d deficient=%d (k=%d)\n", n, nsel, kk);
+    TDV_TRY(knn_to_lists(ctx, so, n, p, kk, qsel, nsel, listsK, cntK));
+    k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, kk, nbr, cnt, listsK, cntK, d_normals, nullptr, 0);
+    TDV_CHECK_LAUNCH(ctx);
+    return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, nbr, cnt, d_desc, nullptr, nullptr);
 }
 
 }  // namespace tdv

@@ -113,7 +113,10 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
                          int* n_out);
 
 int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
-size_t sort_pow2(size_t n);                                      // padded record count for sort_records_dev
+size_t sort_pow2(size_t n);
+int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_total);  // voxel.hip
+// normals + FPFH in one go, sharing one spatial sort and one radius scan (batch path; identical results)
+int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc);                                      // padded record count for sort_records_dev
 
 int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr, const uint8_t* d_masks, int n_instances,
                        const tdv_batch_params* prm, const float* d_model_xyz, const float* d_model_normals,

@@ -230,6 +230,20 @@ struct VoxelKeyHash {  // the reference's combiner (registration.cpp:20-27)
 };
 }  // namespace
 
+// exclusive scan of n ints on the ctx stream; *d_total receives the sum (device pointer)
+int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_total) {
+    if (n <= 0) return TDV_OK;
+    const int sblocks = (n + 1023) / 1024;
+    int* sums;
+    TDV_TRY(ws_alloc(ctx, (size_t)sblocks, &sums));
+    hipStream_t s = ctx->stream;
+    k_scan_reduce<<<sblocks, 1024, 0, s>>>(d_in, n, sums);
+    k_scan_sums<<<1, 1024, 0, s>>>(sums, sblocks, d_total);
+    k_scan_local<<<sblocks, 1024, 0, s>>>(d_in, n, sums, d_out);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
 size_t sort_pow2(size_t n) { size_t p = BT_TILE; while (p < n) p <<= 1; return p; }
 
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
