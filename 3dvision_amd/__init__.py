@@ -48,6 +48,7 @@ ABI_SYMBOLS = [
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
     "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii",
+    "tdv_depth_to_cloud_batch_dev",
 ]
 
 
@@ -393,6 +394,18 @@ def _prepare_model_dev(self, d_xyz, n, voxel, k, radius_factor, d_out_xyz, d_out
     return m.value
 
 
+def _depth_to_cloud_batch_dev(self, d_raw, d_masks, d_bgr, n_instances, w, h, scale, fx, fy, cx, cy, zmax, d_xyz, d_rgb, capacity,
+                              mask_format=0, mask_mode=TDV_MASK_THRESHOLD10):
+    """All instances of one frame -> clouds back to back; returns the offsets array (n_instances + 1)."""
+    off = np.zeros(n_instances + 1, np.int32)
+    st = lib().tdv_depth_to_cloud_batch_dev(self._h, _ptr(d_raw), _ptr(d_masks), _ptr(d_bgr), n_instances, mask_format, w, h,
+                                            C.c_float(scale), mask_mode, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                            C.c_float(zmax), _ptr(d_xyz), _ptr(d_rgb), C.c_longlong(capacity), _ptr(off))
+    _check(self._h, st, "tdv_depth_to_cloud_batch_dev")
+    return off
+
+
+Context.depth_to_cloud_batch_dev = _depth_to_cloud_batch_dev
 Context.register_batch_dev = _register_batch_dev
 Context.prepare_model_dev = _prepare_model_dev
 

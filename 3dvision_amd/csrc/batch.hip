@@ -4,6 +4,7 @@
 // the host only reads three scalars (point count, voxel count, results).  SURVEY.md 8f N1.
 #include "tdv_internal.hpp"
 #include <cstring>
+#include <vector>
 
 namespace tdv {
 
@@ -12,25 +13,28 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
                        const float* d_model_fpfh, int n_model, tdv_instance_result* results) {
     if (!ctx || !d_raw || !d_masks || !prm || !results || n_instances < 0 || n_model < 0) return TDV_ERR_BAD_ARG;
     if (n_model > 0 && (!d_model_xyz || !d_model_fpfh)) return TDV_ERR_BAD_ARG;
-    const size_t npx = (size_t)prm->width * prm->height;
+    if (n_instances == 0) return TDV_OK;
+    // all clouds of the frame in two launches (count + emit), back to back in one buffer
+    std::vector<int> off((size_t)n_instances + 1, 0);
+    int* d_off = nullptr;
+    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_masks, n_instances, 1, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
+                                       prm->zmax, &d_off, off.data()));
+    float *all_xyz = nullptr;
+    if (off[n_instances] > 0) {
+        TDV_TRY(ws_alloc(ctx, (size_t)off[n_instances] * 3, &all_xyz));
+        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_masks, nullptr, n_instances, 1, prm->width, prm->height, prm->scale_to_meters,
+                                          prm->mask_mode, prm->fx, prm->fy, prm->cx, prm->cy, prm->zmax, d_off, all_xyz, nullptr));
+    }
+    (void)d_bgr;  // colours do not enter the registration chain (voxelDownsample keeps them, nothing downstream reads them)
     for (int b = 0; b < n_instances; ++b) {
         tdv_instance_result& r = results[b];
         std::memset(&r, 0, sizeof(r));
         for (int i = 0; i < 16; ++i) r.T[i] = (i % 5 == 0) ? 1.f : 0.f;
         const WsMark mark = ws_mark(ctx);
-        const uint8_t* mask = d_masks + (size_t)b * npx;
-        // pass 1: count (capacity 0) so that the cloud buffer is sized to the instance, not the frame
-        int n = 0;
-        int st = depth_to_cloud_dev(ctx, d_raw, nullptr, mask, nullptr, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
-                                    prm->fx, prm->fy, prm->cx, prm->cy, prm->zmax, nullptr, nullptr, 0, &n);
-        if (st != TDV_OK && st != TDV_ERR_BAD_ARG) return st;  // BAD_ARG here only means "capacity 0 < n"
+        int n = off[b + 1] - off[b];
         r.n_points = n;
         if (n == 0) { r.status = 2; ws_rewind(ctx, mark); continue; }
-        float *xyz, *rgb = nullptr;
-        TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &xyz));
-        if (d_bgr) TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &rgb));
-        TDV_TRY(depth_to_cloud_dev(ctx, d_raw, nullptr, mask, d_bgr, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
-                                   prm->fx, prm->fy, prm->cx, prm->cy, prm->zmax, xyz, rgb, n, &n));
+        float* xyz = all_xyz + (size_t)off[b] * 3;
         float* vx; int v = 0;
         TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &vx));
         TDV_TRY(voxel_downsample_dev(ctx, xyz, nullptr, n, prm->voxel_size, TDV_VOXEL_ORDER_FIRST, nullptr, vx, nullptr, n, &v));
@@ -70,6 +74,26 @@ int tdv_register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d
     ctx->err[0] = 0;
     TDV_TRY(ws_reset(ctx));
     return register_batch_dev(ctx, d_raw, d_bgr, d_masks, n_instances, prm, d_model_xyz, d_model_normals, d_model_fpfh, n_model, results);
+}
+
+int tdv_depth_to_cloud_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr,
+                                 int n_instances, int mask_format, int width, int height, float scale, int mask_mode,
+                                 float fx, float fy, float cx, float cy, float zmax,
+                                 float* d_xyz, float* d_rgb, long long capacity, int* h_offsets) {
+    if (!ctx || !d_raw || !d_masks || !h_offsets || n_instances < 0 || width < 0 || height < 0 || capacity < 0) return TDV_ERR_BAD_ARG;
+    TDV_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->err[0] = 0;
+    TDV_TRY(ws_reset(ctx));
+    h_offsets[0] = 0;
+    if (n_instances == 0 || (size_t)width * height == 0) { for (int b = 0; b <= n_instances; ++b) h_offsets[b] = 0; return TDV_OK; }
+    int* d_off = nullptr;
+    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_masks, n_instances, mask_format == 0, width, height, scale, mask_mode, zmax, &d_off, h_offsets));
+    if ((long long)h_offsets[n_instances] > capacity || (h_offsets[n_instances] > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
+    if (h_offsets[n_instances] > 0)
+        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_masks, d_bgr, n_instances, mask_format == 0, width, height, scale, mask_mode,
+                                          fx, fy, cx, cy, zmax, d_off, d_xyz, d_rgb));
+    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TDV_OK;
 }
 
 int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_size, int normals_k, float fpfh_radius_factor,

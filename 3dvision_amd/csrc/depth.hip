@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <cmath>
 #include <algorithm>
+#include <cstring>
 
 namespace tdv {
 
@@ -214,6 +215,129 @@ int bilateral_filter_dev(tdv_ctx* ctx, const float* d_in, float* d_out, int w, i
     dim3 grid((w + BF_TW - 1) / BF_TW, (h + BF_TH - 1) / BF_TH);
     ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
     k_bilateral<<<grid, BF_TW * BF_TH, 0, ctx->stream>>>(d_in, d_out, w, h, radius, inv_spatial2, inv_range2);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+// ------------------------------------------------------------------ all instances of a frame in one pass
+// B masks (stacked u8 images, or one label image with label = b + 1) of ONE depth/colour frame -> B clouds stored
+// back to back, each in row-major pixel order.  Grid = (pixel blocks, instances); the depth image is re-read from
+// L2 / Infinity Cache by every instance, the masks and the output stream through HBM once.
+__global__ __launch_bounds__(DP_BLOCK)
+void k_valid_count_batch(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ masks, size_t n, int stacked,
+                         float inv_scale, int mask_mode, float zmax, int* __restrict__ block_counts) {
+    const int b = blockIdx.y;
+    const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
+    const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
+    const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        size_t i = base + k * DP_BLOCK + threadIdx.x;
+        if (i < n) {
+            float z = scaled_depth(raw, mask, i, inv_scale, mode);
+            c += !(z <= 0.f || z > zmax);
+        }
+    }
+    __shared__ int red[DP_BLOCK / 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(DP_BLOCK)
+void k_emit_batch(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ masks, const uint8_t* __restrict__ bgr,
+                  int width, size_t n, int stacked, float inv_scale, int mask_mode,
+                  float fx, float fy, float cx, float cy, float zmax,
+                  const int* __restrict__ offsets, float* __restrict__ xyz, float* __restrict__ rgb) {
+    const int b = blockIdx.y;
+    const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
+    const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
+    const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wcnt[DP_PX_PER_THREAD][DP_BLOCK / 64];
+    float zs[DP_PX_PER_THREAD]; bool ok[DP_PX_PER_THREAD]; int rank[DP_PX_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        size_t i = base + k * DP_BLOCK + threadIdx.x;
+        float z = 0.f;
+        if (i < n) z = scaled_depth(raw, mask, i, inv_scale, mode);
+        ok[k] = (i < n) && !(z <= 0.f || z > zmax);
+        zs[k] = z;
+        unsigned long long bal = __ballot(ok[k]);
+        rank[k] = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcnt[k][wave] = __popcll(bal);
+    }
+    __syncthreads();
+    size_t run = (size_t)offsets[(size_t)b * gridDim.x + blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        int before = 0;
+#pragma unroll
+        for (int w = 0; w < DP_BLOCK / 64; ++w) before += (w < wave) ? wcnt[k][w] : 0;
+        if (ok[k]) {
+            const size_t slot = run + before + rank[k];
+            const size_t i = base + k * DP_BLOCK + threadIdx.x;
+            const int v = (int)(i / width), u = (int)(i - (size_t)v * width);
+            const float z = zs[k];
+            xyz[3 * slot] = ((float)u - cx) * z / fx;
+            xyz[3 * slot + 1] = ((float)v - cy) * z / fy;
+            xyz[3 * slot + 2] = z;
+            if (rgb && bgr) {
+                const uint8_t* p = bgr + i * 3;
+                rgb[3 * slot] = (float)p[2] / 255.0f; rgb[3 * slot + 1] = (float)p[1] / 255.0f; rgb[3 * slot + 2] = (float)p[0] / 255.0f;
+            }
+        }
+        run += (wcnt[k][0] + wcnt[k][1]) + (wcnt[k][2] + wcnt[k][3]);
+    }
+}
+
+__global__ void k_gather_instance_offsets(const int* __restrict__ offsets, const int* __restrict__ total, int blocks, int n_inst, int* __restrict__ out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_inst) out[b] = offsets[(size_t)b * blocks];
+    if (b == n_inst) out[b] = *total;
+}
+
+// pass 1 (count + scan): returns the per-instance start offsets (host, n_inst + 1 entries) and keeps the device scan
+int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, int n_inst, int stacked, int w, int h,
+                               float scale, int mask_mode, float zmax, int** d_offsets_out, int* h_offsets) {
+    const size_t n = (size_t)w * h;
+    const float inv_scale = (float)(1.0 / (double)scale);
+    const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
+    int *counts, *offsets, *d_total, *d_inst;
+    TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &counts));
+    TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &offsets));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_inst + 1, &d_inst));
+    hipStream_t s = ctx->stream;
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
+        k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
+    }
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_TRY(exclusive_scan_dev(ctx, counts, blocks * n_inst, offsets, d_total));
+    k_gather_instance_offsets<<<(n_inst + 256) / 256, 256, 0, s>>>(offsets, d_total, blocks, n_inst, d_inst);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_TRY(pin_reserve(ctx, ((size_t)n_inst + 1) * 4));
+    TDV_HIP(ctx, hipMemcpyAsync(ctx->pin, d_inst, ((size_t)n_inst + 1) * 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    std::memcpy(h_offsets, ctx->pin, ((size_t)n_inst + 1) * 4);
+    *d_offsets_out = offsets;
+    return TDV_OK;
+}
+
+// pass 2 (emit) into buffers sized from pass 1
+int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr, int n_inst, int stacked,
+                              int w, int h, float scale, int mask_mode, float fx, float fy, float cx, float cy, float zmax,
+                              const int* d_offsets, float* d_xyz, float* d_rgb) {
+    const size_t n = (size_t)w * h;
+    const float inv_scale = (float)(1.0 / (double)scale);
+    const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
+    ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
+    k_emit_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
+                                                                     fx, fy, cx, cy, zmax, d_offsets, d_xyz, d_rgb);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }

@@ -4,27 +4,33 @@
 //   findKNN + Registration::estimateNormals   /root/reference/src/registration.cpp:63-81, :105-130
 //   findRadiusNN + Registration::computeFPFH  /root/reference/src/registration.cpp:83-102, :133-201
 //
-// Every query still evaluates its distance to EVERY point (the reference's O(N^2) scan, 8 VALU ops per
-// pair, no FMA: d2 = dx*dx + (dy*dy + dz*dz)); what is engineered is the ORDER of the scan, so that the
-// selection work around it nearly vanishes:
-//   1. the cloud is sorted along a 30-bit Morton curve (bitonic sort shared with voxel.hip), so the 64
-//      queries of a wave are spatial neighbours and so are the 8 targets of a chunk;
-//   2. each workgroup scans the chunks INSIDE-OUT, starting at its own position on the curve and
-//      alternating right/left; the true neighbours arrive within the first few hundred chunks, the
-//      per-lane bound (radius^2, or the k-th best distance so far) is tight almost immediately, and
-//      the remaining >99 % of the chunks take the fast path: 64 distance ops + a min3 tree + one
-//      compare per chunk, targets broadcast through the scalar data path (wave-uniform s_load);
-//   3. target splits (more workgroups, shorter tail) take INTERLEAVED positions of that visit order,
-//      so every split sees near chunks first; per-split sorted lists are k-way merged afterwards.
-// Selection keeps the reference's (d2, original index) lexicographic order of std::partial_sort /
-// std::sort on pair<float,size_t>: candidates with d2 <= bound are queued (8 per lane), and when a
-// lane's queue would overflow the wave inserts the queued entries into its sorted per-lane list —
-// in VGPRs with static indexing for k <= 32 (normals, k = 30), in global memory (the output buffer
-// itself, rank-merge without dependent chains) for larger k (FPFH: cap 100).
-// Results are independent of the scan order; lists, normals and descriptors are bit-identical to the
-// CPU code's (see tests/test_gpu_features.py).
-// Per-point estimators run one lane per point with sequential sums in neighbour order, i.e. the same
-// f32 expression trees as the CPU loops; atan2 is evaluated in f64 and rounded once.
+// Every query still evaluates its distance to EVERY point (the reference's O(N^2) scan, 8 VALU ops per pair,
+// no FMA: d2 = dx*dx + (dy*dy + dz*dz)); what is engineered is what surrounds the scan, so that selection work
+// nearly vanishes and the scan itself has the shape of the ICP nearest-neighbour kernel:
+//   0. the cloud is sorted along a 30-bit Morton curve (bitonic sort shared with voxel.hip): the 64 queries of
+//      a wave are spatial neighbours, and so are the targets of a chunk;
+//   kNN (normals, k <= 32) — two phases, no selection state inside the scan:
+//   A. k_window_bound : an upper bound on each query's k-th neighbour distance from a 768-point window around
+//                       its own curve position (a subset of the cloud, so the bound can only be too large);
+//   B. k_collect_scan : the full scan with that FIXED bound — two queries per lane in VGPRs, 16 targets per
+//                       wave-uniform s_load step, min3 tree + one compare per chunk; the rare hits are appended
+//                       to the query's candidate row (integer atomic slot counter; row order is irrelevant);
+//   C. k_select_topk  : exact top-k of the row in the reference's (d2, index) order.  A row that overflowed still
+//                       holds >= k real candidates, whose k-th distance is a tighter valid bound: those few
+//                       queries repeat B/C as a subset until none overflows; exact ties beyond the row size end
+//                       in the streaming kernel below.
+//   radius search (FPFH, cap 100) and the kNN fallback — streaming selection: chunks are visited INSIDE-OUT from
+//   the workgroup's own curve position (splits take interleaved positions), so the per-lane bound is tight almost
+//   immediately and >99 % of chunks take the 70-instruction fast path; candidates queue per lane (8 entries) and
+//   are merged into a sorted per-lane list — in VGPRs with static indexing (k <= 32) or in global memory by a
+//   rank-merge (larger k).
+// Results are independent of the scan order and of the atomic arrival order; lists, normals and descriptors are
+// bit-identical to the CPU code's (tests/test_gpu_features.py, incl. massive exact ties).
+// In the batched chain normals_fpfh_dev shares ONE radius scan between normals and FPFH: a radius list is sorted by
+// (d2, idx), so its first k entries are the k nearest neighbours wherever it holds >= k; only the deficient points
+// go through A-C as a subset.
+// Per-point estimators run one lane per point with sequential sums in neighbour order, i.e. the same f32
+// expression trees as the CPU loops; atan2 is evaluated in f64 and rounded once.
 #include "tdv_internal.hpp"
 #include "device_linalg.hpp"
 #include <cfloat>

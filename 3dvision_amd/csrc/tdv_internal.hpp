@@ -105,6 +105,11 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
                        const uint8_t* d_bgr, int w, int h, float scale, int mask_mode,
                        float fx, float fy, float cx, float cy, float zmax,
                        float* d_xyz, float* d_rgb, int capacity, int* n_out);
+int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, int n_inst, int stacked, int w, int h,
+                               float scale, int mask_mode, float zmax, int** d_offsets_out, int* h_offsets);
+int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr, int n_inst, int stacked,
+                              int w, int h, float scale, int mask_mode, float fx, float fy, float cx, float cy, float zmax,
+                              const int* d_offsets, float* d_xyz, float* d_rgb);
 int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* d_normals, int* d_knn);
 int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
                      float* d_desc, int* d_nbr, int* d_nbr_cnt);

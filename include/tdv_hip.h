@@ -110,6 +110,17 @@ int tdv_depth_to_cloud(tdv_ctx* ctx, const uint16_t* raw, const uint8_t* mask, c
                        float fx, float fy, float cx, float cy, float zmax,
                        float* out_xyz, float* out_rgb, int capacity, int* n_out);
 
+/* All instances of one frame in two launches: n_instances masks — stacked u8 images
+ * (mask_format 0, mask_mode as above) or ONE u8 label image with label b+1 for instance b (mask_format 1) — of the
+ * same depth/colour frame give n_instances clouds stored back to back, each in row-major pixel order.
+ * All pointers are device pointers except h_offsets (host, n_instances + 1 entries): instance b occupies points
+ * [h_offsets[b], h_offsets[b+1]).  capacity = room in d_xyz/d_rgb in points; if the total exceeds it the call
+ * returns TDV_ERR_BAD_ARG with h_offsets filled (so the caller can size the buffers and call again). */
+int tdv_depth_to_cloud_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr,
+                                 int n_instances, int mask_format, int width, int height, float scale, int mask_mode,
+                                 float fx, float fy, float cx, float cy, float zmax,
+                                 float* d_xyz, float* d_rgb, long long capacity, int* h_offsets);
+
 /* ---- R3: voxel downsample ----------------------------------------------------------------- */
 /* Replaces Registration::voxelDownsample (src/registration.cpp:29-60).  Per-voxel mean of points
  * (and colours) summed in ascending input index, divided by the count; normals are dropped.

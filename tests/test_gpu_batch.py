@@ -80,3 +80,37 @@ def test_batch_empty_mask(ctx, tdv, synth, orc):
     res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 2, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), 3000)
     assert res[0]["status"] == 2 and res[0]["n_points"] == 0 and np.array_equal(res[0]["T"], np.eye(4, dtype=np.float32))
     assert res[1]["status"] == 0 and res[1]["n_voxels"] > 100
+
+
+def test_all_instance_clouds_in_one_pass(ctx, tdv, synth, orc):
+    """tdv_depth_to_cloud_batch_dev: stacked masks and the label-image format give, per instance, exactly the
+    cloud (values and row-major order) of the single-instance entry point."""
+    depth, masks, intr = _scene(synth, orc, n_inst=3)
+    h, w = depth.shape
+    rng = np.random.default_rng(0)
+    bgr = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev); d_bgr = torch.from_numpy(bgr).to(dev)
+    cap = int(sum((m > 0).sum() for m in masks))
+    d_xyz = torch.zeros((cap, 3), dtype=torch.float32, device=dev); d_rgb = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+    off = ctx.depth_to_cloud_batch_dev(d_depth.data_ptr(), d_masks.data_ptr(), d_bgr.data_ptr(), 3, w, h, 1000.0, intr["fx"], intr["fy"],
+                                       intr["cx"], intr["cy"], 1.5, d_xyz.data_ptr(), d_rgb.data_ptr(), cap)
+    xyz = d_xyz.cpu().numpy(); rgb = d_rgb.cpu().numpy()
+    label = np.zeros((h, w), np.uint8)
+    for b in range(3):
+        ref_xyz, ref_rgb = ctx.depth_to_cloud(depth, masks[b], bgr, 1000.0, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 1.5)
+        assert off[b + 1] - off[b] == len(ref_xyz) > 0
+        assert xyz[off[b]:off[b + 1]].tobytes() == ref_xyz.tobytes() and rgb[off[b]:off[b + 1]].tobytes() == ref_rgb.tobytes()
+        label[(masks[b] > 0) & (label == 0)] = b + 1
+    # label image: instance b = pixels with value b + 1 (overlaps resolved towards the lower label above)
+    d_label = torch.from_numpy(label).to(dev)
+    off2 = ctx.depth_to_cloud_batch_dev(d_depth.data_ptr(), d_label.data_ptr(), None, 3, w, h, 1000.0, intr["fx"], intr["fy"],
+                                        intr["cx"], intr["cy"], 1.5, d_xyz.data_ptr(), None, cap, mask_format=1)
+    xyz2 = d_xyz.cpu().numpy()
+    for b in range(3):
+        ref_xyz, _ = ctx.depth_to_cloud(depth, np.where(label == b + 1, 255, 0).astype(np.uint8), None, 1000.0, intr["fx"], intr["fy"],
+                                        intr["cx"], intr["cy"], 1.5)
+        assert off2[b + 1] - off2[b] == len(ref_xyz) and xyz2[off2[b]:off2[b + 1]].tobytes() == ref_xyz.tobytes()
+    with pytest.raises(tdv.TdvError):
+        ctx.depth_to_cloud_batch_dev(d_depth.data_ptr(), d_masks.data_ptr(), None, 3, w, h, 1000.0, intr["fx"], intr["fy"], intr["cx"], intr["cy"],
+                                     1.5, d_xyz.data_ptr(), None, 10)

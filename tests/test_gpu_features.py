@@ -89,3 +89,23 @@ def test_registration_operator_api_chain(tdv, orc, synth):
     assert np.abs(feats - ref_f).max() < 0.05
     sums = feats.sum(1)  # isolated points keep an all-zero histogram (sum > 0 guard, registration.cpp:194)
     assert np.allclose(sums[sums > 0], 1.0, atol=1e-5) and (sums > 0).mean() > 0.9
+
+
+def test_knn_massive_ties_exercise_the_fallbacks(ctx, orc, synth):
+    """More candidates at exactly the k-th distance than a candidate row holds (128): the collect scan overflows,
+    bound tightening cannot make progress on an exact tie, and the streaming scan must finish those queries.
+    (d2, idx) order still decides: the lowest indices win."""
+    pts = _cloud(synth, 1200)
+    dup = np.tile(pts[7], (300, 1))                       # 300 exact copies of point 7 (indices 1200..1499)
+    pts = np.concatenate([pts, dup], 0).astype(np.float32)
+    ref_n, ref_knn = orc.estimate_normals(pts, 30, want_knn=True)
+    got_n, got_knn = ctx.estimate_normals(pts, 30, want_knn=True)
+    assert np.array_equal(got_knn, ref_knn)
+    assert list(got_knn[7][:5]) == [7, 1200, 1201, 1202, 1203]   # d2 = 0 ties broken by index
+    assert np.array_equal(got_knn[1400][:3], [7, 1200, 1201])
+    same = (got_n.view(np.uint32) == ref_n.view(np.uint32)).all(1) | (np.isnan(got_n).any(1) & np.isnan(ref_n).any(1))
+    assert same.all()
+    # the radius search sees the same pile-up: cap of 100 by (d2, idx)
+    ref_d, ref_nb, ref_cnt = orc.compute_fpfh(pts, np.nan_to_num(ref_n), 0.01, want_neighbors=True)
+    got_d, got_nb, got_cnt = ctx.compute_fpfh(pts, np.nan_to_num(ref_n), 0.01, want_neighbors=True)
+    assert np.array_equal(got_cnt, ref_cnt) and np.array_equal(got_nb, ref_nb) and got_cnt.max() == 100

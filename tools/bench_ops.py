@@ -72,6 +72,33 @@ def main():
         emit(op="depth_to_cloud", frame="1280x720", points=cnt[0], wall_ms=t * 1e3, kernels_ms=ms / max(launches, 1),
              algorithmic_bytes=nbytes, hbm_GBps=nbytes / (ms / max(launches, 1) * 1e-3) / 1e9)
 
+    # ---------------- R1+R2 at C4 scale: 64 stacked masks (448x448 px each) of one frame, one count + one emit launch
+    if want("depthbatch"):
+        h, w, B = 720, 1280, 64
+        rng = np.random.default_rng(0)
+        raw = (800 + rng.integers(0, 200, (h, w))).astype(np.uint16)
+        masks = np.zeros((B, h, w), np.uint8)
+        for b in range(B):
+            y0 = (b * 37) % (h - 448); x0 = (b * 101) % (w - 448)
+            masks[b, y0:y0 + 448, x0:x0 + 448] = 255
+        d_raw = torch.from_numpy(raw.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev)
+        cap = B * 448 * 448
+        d_xyz = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+        off = [None]
+
+        def f():
+            off[0] = ctx.depth_to_cloud_batch_dev(d_raw.data_ptr(), d_masks.data_ptr(), None, B, w, h, 1000.0, 900, 900, 640, 360, 1.5, d_xyz.data_ptr(), None, cap)
+        ctx.timing_read(tdv.TIMER_DEPTH)
+        t = timed(f, reps=10, warm=2)
+        ms, launches = ctx.timing_read(tdv.TIMER_DEPTH)
+        per_call_ms = ms / 10
+        npts = int(off[0][-1])
+        # two passes read depth (L2/MALL-resident after the first instance) + mask; emit writes 12 B per point
+        nbytes = 2 * B * h * w * 1 + 2 * h * w * 2 + 12 * npts
+        emit(op="depth_to_cloud_batch", instances=B, frame="1280x720", points=npts, wall_ms=t * 1e3, kernels_ms=per_call_ms,
+             algorithmic_bytes=nbytes, hbm_GBps=nbytes / (per_call_ms * 1e-3) / 1e9,
+             bytes_incl_depth_rereads=2 * B * h * w * 3 + 12 * npts)
+
     sizes = [50000] if args.quick else [50000, 100000, 200000]
     for n in sizes:
         cam, mdl, mnrm = cloud(n, 42)
