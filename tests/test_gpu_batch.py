@@ -114,3 +114,22 @@ def test_all_instance_clouds_in_one_pass(ctx, tdv, synth, orc):
     with pytest.raises(tdv.TdvError):
         ctx.depth_to_cloud_batch_dev(d_depth.data_ptr(), d_masks.data_ptr(), None, 3, w, h, 1000.0, intr["fx"], intr["fy"], intr["cx"], intr["cy"],
                                      1.5, d_xyz.data_ptr(), None, 10)
+
+
+def test_all_instance_clouds_odd_frame_scalar_path(ctx, orc):
+    """A frame whose pixel count is not a multiple of 16 takes the non-vectorised kernels; same results."""
+    rng = np.random.default_rng(4)
+    h, w, B = 97, 131, 4
+    raw = rng.integers(300, 1400, (h, w)).astype(np.uint16)
+    masks = (rng.random((B, h, w)) < 0.4).astype(np.uint8) * 255
+    bgr = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    dev = torch.device("cuda", 0)
+    d_raw = torch.from_numpy(raw.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev); d_bgr = torch.from_numpy(bgr).to(dev)
+    cap = B * h * w
+    d_xyz = torch.zeros((cap, 3), dtype=torch.float32, device=dev); d_rgb = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+    off = ctx.depth_to_cloud_batch_dev(d_raw.data_ptr(), d_masks.data_ptr(), d_bgr.data_ptr(), B, w, h, 1000.0, 500, 500, 65, 48, 1.2,
+                                       d_xyz.data_ptr(), d_rgb.data_ptr(), cap)
+    xyz = d_xyz.cpu().numpy(); rgb = d_rgb.cpu().numpy()
+    for b in range(B):
+        ref_xyz, ref_rgb = orc.unproject(orc.depth_preprocess(raw, masks[b], 1000.0), bgr, 500, 500, 65, 48, 1.2)
+        assert xyz[off[b]:off[b + 1]].tobytes() == ref_xyz.tobytes() and rgb[off[b]:off[b + 1]].tobytes() == ref_rgb.tobytes()
