@@ -111,13 +111,20 @@ inline uint32_t lemire(Mt19937& g, uint32_t range) {  // uniform in [0, range)
 }  // namespace
 
 void mt19937_lemire_triples(uint32_t seed, uint64_t n, int count, uint64_t* out) {
-    Mt19937 g(seed);
-    if (n == ((uint64_t)1 << 32)) {  // urange == urng range: one raw draw each
-        for (int i = 0; i < 3 * count; ++i) out[i] = g.next();
+    TripleStream ts(seed, n);
+    for (int i = 0; i < count; ++i) ts.next(out + 3 * (size_t)i);
+}
+
+struct TripleStream::Impl { Mt19937 g; explicit Impl(uint32_t seed) : g(seed) {} };
+TripleStream::TripleStream(uint32_t seed, uint64_t n) : impl_(new Impl(seed)), n_(n) {}
+TripleStream::~TripleStream() { delete impl_; }
+void TripleStream::next(uint64_t* out3) {
+    if (n_ == ((uint64_t)1 << 32)) {  // urange == urng range: one raw draw each
+        for (int k = 0; k < 3; ++k) out3[k] = impl_->g.next();
         return;
     }
-    uint32_t range = (uint32_t)n;
-    for (int i = 0; i < 3 * count; ++i) out[i] = lemire(g, range);
+    const uint32_t range = (uint32_t)n_;
+    for (int k = 0; k < 3; ++k) out3[k] = lemire(impl_->g, range);
 }
 
 float tau_le(float thr) {  // largest f with sqrtf(f) <= thr ; returns -1 if none (thr < 0 or NaN)

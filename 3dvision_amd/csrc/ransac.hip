@@ -297,61 +297,91 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     int pchunks_per_split = (n_pchunks + psplit - 1) / psplit;
     psplit = (n_pchunks + pchunks_per_split - 1) / pchunks_per_split;
 
-    float* hyp = nullptr; int* counts = nullptr; int4* d_tri = nullptr; double* slabs = nullptr; double* d_out2 = nullptr; float* d_best12 = nullptr;
-    TDV_TRY(ws_alloc(ctx, (size_t)12 * h_pad, &hyp));
-    TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &counts));
-    TDV_TRY(ws_alloc(ctx, (size_t)batch, &d_tri));
+    // two sets of batch buffers: batch k+1 is prepared on the host (index stream, triple packing) and enqueued while
+    // the GPU scores batch k; results are consumed in iteration order, so the outcome is that of the sequential loop
+    float* hyp[2] = {nullptr, nullptr}; int* counts[2] = {nullptr, nullptr}; int4* d_tri[2] = {nullptr, nullptr};
+    double* slabs = nullptr; double* d_out2 = nullptr; float* d_best12 = nullptr;
+    for (int q = 0; q < 2; ++q) {
+        TDV_TRY(ws_alloc(ctx, (size_t)12 * h_pad, &hyp[q]));
+        TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &counts[q]));
+        TDV_TRY(ws_alloc(ctx, (size_t)batch, &d_tri[q]));
+    }
     const int rblocks = (ns + 255) / 256;
     TDV_TRY(ws_alloc(ctx, (size_t)2 * rblocks, &slabs));
     TDV_TRY(ws_alloc(ctx, 2, &d_out2));
     TDV_TRY(ws_alloc(ctx, 12, &d_best12));
-    // pinned: triples (int4 * batch) | counts (int * batch) | best12 (12 floats) | out2 (2 doubles)
-    const size_t pin_tri = 0, pin_cnt = align_up((size_t)batch * 16, 64), pin_b12 = pin_cnt + align_up((size_t)batch * 4, 64),
-                 pin_o2 = pin_b12 + 64, pin_total = pin_o2 + 64;
+    // pinned: 2 x triples (int4 * batch) | 2 x counts (int * batch) | best12 (12 floats) | out2 (2 doubles)
+    const size_t sz_tri = align_up((size_t)batch * 16, 64), sz_cnt = align_up((size_t)batch * 4, 64);
+    const size_t pin_b12 = 2 * sz_tri + 2 * sz_cnt, pin_o2 = pin_b12 + 64, pin_total = pin_o2 + 64;
     TDV_TRY(pin_reserve(ctx, pin_total));
-    int4* h_tri = reinterpret_cast<int4*>(ctx->pin + pin_tri);
-    int* h_cnt = reinterpret_cast<int*>(ctx->pin + pin_cnt);
+    int4* h_tri[2] = {reinterpret_cast<int4*>(ctx->pin), reinterpret_cast<int4*>(ctx->pin + sz_tri)};
+    int* h_cnt[2] = {reinterpret_cast<int*>(ctx->pin + 2 * sz_tri), reinterpret_cast<int*>(ctx->pin + 2 * sz_tri + sz_cnt)};
     float* h_b12 = reinterpret_cast<float*>(ctx->pin + pin_b12);
     double* h_o2 = reinterpret_cast<double*>(ctx->pin + pin_o2);
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int q = 0; q < 2; ++q) TDV_HIP(ctx, hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
 
-    // the index stream is sequential over the whole run: generate all draws up front (3 per iteration)
-    std::vector<uint64_t> draws((size_t)max_iterations * 3);
-    mt19937_lemire_triples(seed, (uint64_t)ns, max_iterations, draws.data());
-
-    float best_fitness = 0.f; int best_iter = -1, best_inliers = 0; bool stop = false;
-    int done_iters = 0;
-    for (int it0 = 0; it0 < max_iterations && !stop; it0 += batch) {
+    TripleStream stream_idx(seed, (uint64_t)ns);   // sequential over the whole run (registration.cpp:235-239)
+    auto prepare = [&](int q, int it0) -> int {    // host: draw + pack the triples of one batch
         const int cnt = std::min(batch, max_iterations - it0);
+        uint64_t d[3];
         for (int k = 0; k < cnt; ++k) {
-            uint64_t a = draws[3 * (size_t)(it0 + k)], b = draws[3 * (size_t)(it0 + k) + 1], c = draws[3 * (size_t)(it0 + k) + 2];
-            int valid = !(a == b || b == c || a == c);  // registration.cpp:240
-            h_tri[k] = make_int4((int)a, (int)b, (int)c, valid);
+            stream_idx.next(d);
+            int valid = !(d[0] == d[1] || d[1] == d[2] || d[0] == d[2]);  // registration.cpp:240
+            h_tri[q][k] = make_int4((int)d[0], (int)d[1], (int)d[2], valid);
         }
-        TDV_HIP(ctx, hipMemcpyAsync(d_tri, h_tri, (size_t)cnt * 16, hipMemcpyHostToDevice, s));
-        TDV_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)h_pad * 4, s));
-        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri, cnt, h_pad, hyp);
+        return cnt;
+    };
+    auto enqueue = [&](int q, int cnt) -> int {     // device: hypotheses + scoring + counts back to the host
+        TDV_HIP(ctx, hipMemcpyAsync(d_tri[q], h_tri[q], (size_t)cnt * 16, hipMemcpyHostToDevice, s));
+        TDV_HIP(ctx, hipMemsetAsync(counts[q], 0, (size_t)h_pad * 4, s));
+        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q]);
         const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
         {
             ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
-            k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp, h_pad, pq, n_pchunks, pchunks_per_split, tau, counts);
+            k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq, n_pchunks, pchunks_per_split, tau, counts[q]);
         }
         TDV_CHECK_LAUNCH(ctx);
-        TDV_HIP(ctx, hipMemcpyAsync(h_cnt, counts, (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
-        TDV_HIP(ctx, hipStreamSynchronize(s));
+        TDV_HIP(ctx, hipMemcpyAsync(h_cnt[q], counts[q], (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipEventRecord(ev[q], s));
+        return TDV_OK;
+    };
+
+    float best_fitness = 0.f; int best_iter = -1, best_inliers = 0; bool stop = false;
+    int done_iters = 0;
+    int status = TDV_OK;
+    int cur = 0, it0 = 0;
+    int cnt_cur = prepare(cur, it0);
+    status = enqueue(cur, cnt_cur);
+    while (status == TDV_OK && cnt_cur > 0 && !stop) {
+        const int nxt = cur ^ 1;
+        const int it_next = it0 + cnt_cur;
+        int cnt_next = 0;
+        if (it_next < max_iterations) {             // overlap: prepare and enqueue the next batch behind the current one
+            cnt_next = prepare(nxt, it_next);
+            status = enqueue(nxt, cnt_next);
+            if (status != TDV_OK) break;
+        }
+        if (hipEventSynchronize(ev[cur]) != hipSuccess) { status = TDV_ERR_LAUNCH; break; }
         int batch_best = -1;
-        for (int k = 0; k < cnt; ++k) {
+        for (int k = 0; k < cnt_cur; ++k) {
             done_iters = it0 + k + 1;
-            if (!h_tri[k].w) { if (trace_inliers) trace_inliers[it0 + k] = -1; continue; }
-            int inl = h_cnt[k];
+            if (!h_tri[cur][k].w) { if (trace_inliers) trace_inliers[it0 + k] = -1; continue; }
+            int inl = h_cnt[cur][k];
             if (trace_inliers) trace_inliers[it0 + k] = inl;
             float fitness = static_cast<float>(inl) / static_cast<float>((size_t)ns);  // registration.cpp:281
             if (fitness > best_fitness) { best_fitness = fitness; best_iter = it0 + k; best_inliers = inl; batch_best = k; }
             if (fitness > confidence) { stop = true; break; }
         }
-        if (batch_best >= 0) {  // keep the winning (R,t) of this batch before hyp is overwritten
-            TDV_HIP(ctx, hipMemcpy2DAsync(d_best12, 4, hyp + batch_best, (size_t)h_pad * 4, 4, 12, hipMemcpyDeviceToDevice, s));
+        if (batch_best >= 0) {  // keep the winning (R,t) of this batch (hyp[cur] is not overwritten before batch cur+2 is enqueued)
+            hipError_t e = hipMemcpy2DAsync(d_best12, 4, hyp[cur] + batch_best, (size_t)h_pad * 4, 4, 12, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) { status = set_err(ctx, e, "hipMemcpy2DAsync", __LINE__); break; }
         }
+        cur = nxt; it0 = it_next; cnt_cur = cnt_next;
     }
+    (void)hipStreamSynchronize(s);   // a speculative batch may still be in flight after an early exit
+    for (int q = 0; q < 2; ++q) (void)hipEventDestroy(ev[q]);
+    if (status != TDV_OK) return status;
     out->iterations_run = done_iters;
     if (best_iter >= 0) {
         k_ransac_rmse_partial<<<rblocks, 256, 0, s>>>(pq, ns, d_best12, tau, slabs);

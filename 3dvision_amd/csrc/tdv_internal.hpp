@@ -129,6 +129,17 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
 
 // host helpers
 void mt19937_lemire_triples(uint32_t seed, uint64_t n, int count, uint64_t* out);
+// the same index stream, drawn incrementally (one (i0, i1, i2) triple per call) so that it can be produced batch by
+// batch while the GPU scores the previous batch
+class TripleStream {
+public:
+    TripleStream(uint32_t seed, uint64_t n);
+    ~TripleStream();
+    void next(uint64_t* out3);
+private:
+    struct Impl; Impl* impl_; uint64_t n_;
+    TripleStream(const TripleStream&) = delete;
+};
 // largest float f with sqrtf(f) <= thr  (accept  <=>  d2 <= f  <=>  !(sqrtf(d2) > thr))
 float tau_le(float thr);
 // smallest float f with sqrtf(f) >= thr (inlier <=>  d2 < f   <=>  sqrtf(d2) < thr)
