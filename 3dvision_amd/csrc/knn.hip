@@ -118,6 +118,47 @@ __global__ void k_gather_sorted(const float* __restrict__ xyz, const uint4* __re
     } else { sx[i] = INFINITY; sy[i] = INFINITY; sz[i] = INFINITY; orig[i] = INT_MAX; }
 }
 
+// Bounding boxes of every 16-target chunk and of every super-chunk of 16 chunks (256 targets) of the sorted cloud.
+// box layout: 6 arrays [minx|miny|minz|maxx|maxy|maxz][count]
+__global__ void k_chunk_boxes(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                              int n_chunks, float* __restrict__ cb) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int t = 0; t < 16; ++t) {
+        float v[3] = {sx[c * 16 + t], sy[c * 16 + t], sz[c * 16 + t]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { cb[(size_t)a * n_chunks + c] = mn[a]; cb[(size_t)(3 + a) * n_chunks + c] = mx[a]; }
+}
+__global__ void k_super_boxes(const float* __restrict__ cb, int n_chunks, int n_super, float* __restrict__ sb) {
+    int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_super) return;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = u * 16; c < min(n_chunks, u * 16 + 16); ++c)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], cb[(size_t)a * n_chunks + c]); mx[a] = fmaxf(mx[a], cb[(size_t)(3 + a) * n_chunks + c]); }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { sb[(size_t)a * n_super + u] = mn[a]; sb[(size_t)(3 + a) * n_super + u] = mx[a]; }
+}
+
+// Lower bound on the reference's float d2 = dx*dx + (dy*dy + dz*dz) between ANY query inside [qmin,qmax] and ANY target
+// inside [bmin,bmax]: per-axis gaps by one float subtraction each, then the same expression tree.  Float subtraction,
+// multiplication and addition are monotone under round-to-nearest, so lb <= fl(d2) for every such pair — no margin
+// is needed, and "lb > bound" proves that nothing in the box can pass "d2 <= bound".
+__device__ __forceinline__ float box_lower_bound(const float* __restrict__ box, int count, int idx,
+                                                 const float (&qmin)[3], const float (&qmax)[3]) {
+    float g[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float bmin = box[(size_t)a * count + idx], bmax = box[(size_t)(3 + a) * count + idx];
+        g[a] = fmaxf(0.f, fmaxf(bmin - qmax[a], qmin[a] - bmax));
+    }
+    return g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);
+}
+
 // chunk visited at position v of the inside-out order centred at chunk cc (bijection onto [0, n_chunks))
 __device__ __forceinline__ int visit_chunk(int v, int cc, int n_chunks) {
     const int L = cc, R = n_chunks - 1 - cc;
@@ -176,7 +217,8 @@ __device__ __forceinline__ void reg_merge(float (&Ld)[K], int (&Li)[K], float (&
 template <int K>
 __global__ __launch_bounds__(KN_BLOCK, 4)   // 4 waves per SIMD: keeps the K = 30 instance within 128 VGPRs
 void k_topk_scan_reg(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                     const int* __restrict__ orig, int nq, int nq_pad, int n_chunks, int nsplit, int k, float bound0,
+                     const int* __restrict__ orig, int nq, int nq_pad, int n_chunks16, int n_super, int nsplit, int k, float bound0,
+                     const float* __restrict__ cbox, const float* __restrict__ sbox, int prune,
                      const int* __restrict__ qsel, int nsel,   // optional: the queries are sorted positions qsel[0..nsel)
                      float* __restrict__ out_d, int* __restrict__ out_i, int* __restrict__ out_cnt) {
     const int split = blockIdx.y;
@@ -186,7 +228,7 @@ void k_topk_scan_reg(const float* __restrict__ sx, const float* __restrict__ sy,
     const int qc = qsel ? qsel[qslot] : qslot;               // sorted position of this lane's query
     const float qx = sx[qc], qy = sy[qc], qz = sz[qc];
     const int mid = min(blockIdx.x * KN_BLOCK + KN_BLOCK / 2, nqq - 1);
-    const int cc = min((qsel ? qsel[mid] : mid) / KN_CH, n_chunks - 1);
+    const int cc = min((qsel ? qsel[mid] : mid) / 256, n_super - 1);   // the workgroup's own super-chunk
     float Ld[K]; int Li[K];
 #pragma unroll
     for (int e = 0; e < K; ++e) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
@@ -195,33 +237,54 @@ void k_topk_scan_reg(const float* __restrict__ sx, const float* __restrict__ sy,
     for (int s = 0; s < KN_PB; ++s) { pd[s] = INFINITY; pi[s] = INT_MAX; }
     int cnt = 0, pcnt = 0;
     float bound = bound0;
-    for (int v = split; v < n_chunks; v += nsplit) {
-        const int j = visit_chunk(v, cc, n_chunks) * KN_CH;
-        float d2[KN_CH];
+    // wave query box and the wave's largest bound (refreshed after every merge) for the exact box pruning
+    float qmin[3] = {qx, qy, qz}, qmax[3] = {qx, qy, qz};
 #pragma unroll
-        for (int t = 0; t < KN_CH; ++t) {
-            float dx = sx[j + t] - qx, dy = sy[j + t] - qy, dz = sz[j + t] - qz;   // (points[i] - query)
-            d2[t] = dx * dx + (dy * dy + dz * dz);
-        }
-        float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
-        if (!__any(m <= bound)) continue;
-        // slow path: make room ONCE per chunk (a single merge site keeps the 8 appends statically indexed)
-        int nacc = 0;
+    for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
-        if (__any(pcnt + nacc > KN_PB)) reg_merge<K>(Ld, Li, pd, pi, k, cnt, pcnt, bound0, bound);
+        for (int a = 0; a < 3; ++a) { qmin[a] = fminf(qmin[a], __shfl_xor(qmin[a], off, 64)); qmax[a] = fmaxf(qmax[a], __shfl_xor(qmax[a], off, 64)); }
+    float Bmax = bound0;
+    for (int vs = split; vs < n_super; vs += nsplit) {
+        const int u = visit_chunk(vs, cc, n_super);   // super-chunks (256 targets) inside-out from the workgroup's own
+        if (prune && !__any(box_lower_bound(sbox, n_super, u, qmin, qmax) <= Bmax)) continue;
+        const int c16_end = min(n_chunks16, u * 16 + 16);
+        for (int c16 = u * 16; c16 < c16_end; ++c16) {
+            if (prune && !__any(box_lower_bound(cbox, n_chunks16, c16, qmin, qmax) <= Bmax)) continue;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                const int j = c16 * 16 + h * KN_CH;
+                float d2[KN_CH];
 #pragma unroll
-        for (int t = 0; t < KN_CH; ++t) {
-            // padding targets (j + t >= nq, d2 = +inf) are never candidates; the bound only tightens, so what
-            // is refused now could never enter the list
-            const bool acc = (j + t < nq) && d2[t] <= bound;
-            if (__any(acc)) {
-                const int oi = orig[j + t];
+                for (int t = 0; t < KN_CH; ++t) {
+                    float dx = sx[j + t] - qx, dy = sy[j + t] - qy, dz = sz[j + t] - qz;   // (points[i] - query)
+                    d2[t] = dx * dx + (dy * dy + dz * dz);
+                }
+                float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
+                if (!__any(m <= bound)) continue;
+                // slow path: make room ONCE per chunk (a single merge site keeps the 8 appends statically indexed)
+                int nacc = 0;
 #pragma unroll
-                for (int s = KN_PB - 1; s >= 1; --s) { pd[s] = acc ? pd[s - 1] : pd[s]; pi[s] = acc ? pi[s - 1] : pi[s]; }
-                pd[0] = acc ? d2[t] : pd[0];
-                pi[0] = acc ? oi : pi[0];
-                pcnt += acc ? 1 : 0;
+                for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
+                if (__any(pcnt + nacc > KN_PB)) {
+                    reg_merge<K>(Ld, Li, pd, pi, k, cnt, pcnt, bound0, bound);
+                    Bmax = bound;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) Bmax = fmaxf(Bmax, __shfl_xor(Bmax, off, 64));
+                }
+#pragma unroll
+                for (int t = 0; t < KN_CH; ++t) {
+                    // padding targets (j + t >= nq, d2 = +inf) are never candidates; the bound only tightens, so what
+                    // is refused now could never enter the list
+                    const bool acc = (j + t < nq) && d2[t] <= bound;
+                    if (__any(acc)) {
+                        const int oi = orig[j + t];
+#pragma unroll
+                        for (int s = KN_PB - 1; s >= 1; --s) { pd[s] = acc ? pd[s - 1] : pd[s]; pi[s] = acc ? pi[s - 1] : pi[s]; }
+                        pd[0] = acc ? d2[t] : pd[0];
+                        pi[0] = acc ? oi : pi[0];
+                        pcnt += acc ? 1 : 0;
+                    }
+                }
             }
         }
     }
@@ -291,11 +354,12 @@ constexpr int CS_SPL = 2;
 constexpr int CS_CH = 16;
 __global__ __launch_bounds__(KN_BLOCK)
 void k_collect_scan(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                    const int* __restrict__ orig, int n, int n_chunks, int chunks_per_split,
+                    const int* __restrict__ orig, int n, int n_chunks, int n_super, int supers_per_split,
+                    const float* __restrict__ cbox, const float* __restrict__ sbox, int prune,
                     const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, int cap,
                     int* __restrict__ cnt, unsigned long long* __restrict__ cand) {
     const int split = blockIdx.y;
-    const int c0 = split * chunks_per_split, c1 = min(n_chunks, c0 + chunks_per_split);
+    const int u0 = split * supers_per_split, u1 = min(n_super, u0 + supers_per_split);
     float qx[CS_SPL], qy[CS_SPL], qz[CS_SPL], B[CS_SPL];
     int slot[CS_SPL];
 #pragma unroll
@@ -306,36 +370,51 @@ void k_collect_scan(const float* __restrict__ sx, const float* __restrict__ sy, 
         qx[s] = sx[sp]; qy[s] = sy[sp]; qz[s] = sz[sp];
         B[s] = slot[s] < nqq ? bound[sl] : -1.f;   // padding lanes never accept
     }
-    for (int c = c0; c < c1; ++c) {
-        const int j = c * CS_CH;
-        float tx[CS_CH], ty[CS_CH], tz[CS_CH];   // wave-uniform: three s_load_dwordx16
+    // the wave's query box and largest bound (padding lanes duplicate a live query, their bound is -1)
+    float qmin[3] = {fminf(qx[0], qx[1]), fminf(qy[0], qy[1]), fminf(qz[0], qz[1])};
+    float qmax[3] = {fmaxf(qx[0], qx[1]), fmaxf(qy[0], qy[1]), fmaxf(qz[0], qz[1])};
+    float Bmax = fmaxf(B[0], B[1]);
 #pragma unroll
-        for (int t = 0; t < CS_CH; ++t) { tx[t] = sx[j + t]; ty[t] = sy[j + t]; tz[t] = sz[j + t]; }
-        bool hit = false;
+    for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-        for (int s = 0; s < CS_SPL; ++s) {
-            float m = INFINITY;
+        for (int a = 0; a < 3; ++a) { qmin[a] = fminf(qmin[a], __shfl_xor(qmin[a], off, 64)); qmax[a] = fmaxf(qmax[a], __shfl_xor(qmax[a], off, 64)); }
+        Bmax = fmaxf(Bmax, __shfl_xor(Bmax, off, 64));
+    }
+    for (int u = u0; u < u1; ++u) {
+        if (prune && !__any(box_lower_bound(sbox, n_super, u, qmin, qmax) <= Bmax)) continue;   // 256 targets skipped
+        const int cend = min(n_chunks, u * 16 + 16);
+        for (int c = u * 16; c < cend; ++c) {
+            if (prune && !__any(box_lower_bound(cbox, n_chunks, c, qmin, qmax) <= Bmax)) continue;   // 16 targets skipped
+            const int j = c * CS_CH;
+            float tx[CS_CH], ty[CS_CH], tz[CS_CH];   // wave-uniform: three s_load_dwordx16
 #pragma unroll
-            for (int t = 0; t < CS_CH; ++t) {
-                float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];   // (points[i] - query)
-                float d2 = dx * dx + (dy * dy + dz * dz);
-                m = fminf(m, d2);
+            for (int t = 0; t < CS_CH; ++t) { tx[t] = sx[j + t]; ty[t] = sy[j + t]; tz[t] = sz[j + t]; }
+            bool hit = false;
+#pragma unroll
+            for (int s = 0; s < CS_SPL; ++s) {
+                float m = INFINITY;
+#pragma unroll
+                for (int t = 0; t < CS_CH; ++t) {
+                    float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];   // (points[i] - query)
+                    float d2 = dx * dx + (dy * dy + dz * dz);
+                    m = fminf(m, d2);
+                }
+                hit |= m <= B[s];
             }
-            hit |= m <= B[s];
-        }
-        if (!__any(hit)) continue;
+            if (!__any(hit)) continue;
 #pragma unroll
-        for (int s = 0; s < CS_SPL; ++s) {
+            for (int s = 0; s < CS_SPL; ++s) {
 #pragma unroll
-            for (int t = 0; t < CS_CH; ++t) {
-                float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];
-                float d2 = dx * dx + (dy * dy + dz * dz);
-                const bool acc = (j + t < n) && d2 <= B[s];
-                if (__any(acc)) {
-                    const int oi = orig[j + t];
-                    if (acc) {
-                        int at = atomicAdd(&cnt[slot[s]], 1);
-                        if (at < cap) cand[(size_t)slot[s] * cap + at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)oi;
+                for (int t = 0; t < CS_CH; ++t) {
+                    float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];
+                    float d2 = dx * dx + (dy * dy + dz * dz);
+                    const bool acc = (j + t < n) && d2 <= B[s];
+                    if (__any(acc)) {
+                        const int oi = orig[j + t];
+                        if (acc) {
+                            int at = atomicAdd(&cnt[slot[s]], 1);
+                            if (at < cap) cand[(size_t)slot[s] * cap + at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)oi;
+                        }
                     }
                 }
             }
@@ -436,7 +515,8 @@ __device__ __forceinline__ void glob_merge(float* __restrict__ ld, int* __restri
 
 __global__ __launch_bounds__(KN_BLOCK)
 void k_topk_scan_glob(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                      const int* __restrict__ orig, int nq, int nq_pad, int n_chunks, int nsplit, int k, float bound0,
+                      const int* __restrict__ orig, int nq, int nq_pad, int n_chunks16, int n_super, int nsplit, int k, float bound0,
+                      const float* __restrict__ cbox, const float* __restrict__ sbox, int prune,
                       float* __restrict__ out_d, int* __restrict__ out_i, int* __restrict__ out_cnt) {
     __shared__ float s_pd[KN_PB][KN_BLOCK];
     __shared__ int s_pi[KN_PB][KN_BLOCK];
@@ -445,7 +525,7 @@ void k_topk_scan_glob(const float* __restrict__ sx, const float* __restrict__ sy
     const int qi = blockIdx.x * KN_BLOCK + tid;
     const int qc = min(qi, nq - 1);
     const float qx = sx[qc], qy = sy[qc], qz = sz[qc];
-    const int cc = min((blockIdx.x * KN_BLOCK + KN_BLOCK / 2) / KN_CH, n_chunks - 1);
+    const int cc = min((blockIdx.x * KN_BLOCK + KN_BLOCK / 2) / 256, n_super - 1);
     float* ld = out_d + (size_t)split * k * nq_pad + qi;
     int* li = out_i + (size_t)split * k * nq_pad + qi;
     const size_t stride = (size_t)nq_pad;
@@ -453,23 +533,43 @@ void k_topk_scan_glob(const float* __restrict__ sx, const float* __restrict__ sy
     const int* pil = &s_pi[0][tid];
     int cnt_list = 0, pcnt = 0;
     float bound = bound0;
-    for (int v = split; v < n_chunks; v += nsplit) {
-        const int j = visit_chunk(v, cc, n_chunks) * KN_CH;
-        float d2[KN_CH];
+    float qmin[3] = {qx, qy, qz}, qmax[3] = {qx, qy, qz};
 #pragma unroll
-        for (int t = 0; t < KN_CH; ++t) {
-            float dx = sx[j + t] - qx, dy = sy[j + t] - qy, dz = sz[j + t] - qz;
-            d2[t] = dx * dx + (dy * dy + dz * dz);
-        }
-        float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
-        if (!__any(m <= bound)) continue;
-        int nacc = 0;
+    for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-        for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
-        if (__any(pcnt + nacc > KN_PB)) glob_merge(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
+        for (int a = 0; a < 3; ++a) { qmin[a] = fminf(qmin[a], __shfl_xor(qmin[a], off, 64)); qmax[a] = fmaxf(qmax[a], __shfl_xor(qmax[a], off, 64)); }
+    float Bmax = bound0;
+    for (int vs = split; vs < n_super; vs += nsplit) {
+        const int u = visit_chunk(vs, cc, n_super);
+        if (prune && !__any(box_lower_bound(sbox, n_super, u, qmin, qmax) <= Bmax)) continue;
+        const int c16_end = min(n_chunks16, u * 16 + 16);
+        for (int c16 = u * 16; c16 < c16_end; ++c16) {
+            if (prune && !__any(box_lower_bound(cbox, n_chunks16, c16, qmin, qmax) <= Bmax)) continue;
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                const int j = c16 * 16 + h * KN_CH;
+                float d2[KN_CH];
 #pragma unroll
-        for (int t = 0; t < KN_CH; ++t) {
-            if ((j + t < nq) && d2[t] <= bound) { s_pd[pcnt][tid] = d2[t]; s_pi[pcnt][tid] = orig[j + t]; pcnt++; }  // never a padding target
+                for (int t = 0; t < KN_CH; ++t) {
+                    float dx = sx[j + t] - qx, dy = sy[j + t] - qy, dz = sz[j + t] - qz;
+                    d2[t] = dx * dx + (dy * dy + dz * dz);
+                }
+                float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
+                if (!__any(m <= bound)) continue;
+                int nacc = 0;
+#pragma unroll
+                for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
+                if (__any(pcnt + nacc > KN_PB)) {
+                    glob_merge(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
+                    Bmax = bound;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) Bmax = fmaxf(Bmax, __shfl_xor(Bmax, off, 64));
+                }
+#pragma unroll
+                for (int t = 0; t < KN_CH; ++t) {
+                    if ((j + t < nq) && d2[t] <= bound) { s_pd[pcnt][tid] = d2[t]; s_pi[pcnt][tid] = orig[j + t]; pcnt++; }  // never a padding target
+                }
+            }
         }
     }
     if (__any(pcnt > 0)) glob_merge(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
@@ -657,10 +757,11 @@ namespace {
 
 struct ScanPlan { int n_pad, nt_pad, n_chunks, blocks_x, nsplit; };
 
-int pick_nsplit(int blocks_x, int n_chunks) {
-    // interleaved splits: enough workgroups for a short tail (>= ~6k), each split keeping >= 64 chunks
+int pick_nsplit(int blocks_x, int n_super) {
+    // interleaved splits over the 256-target super-chunks: enough workgroups for a short tail (>= ~6k),
+    // each split keeping >= 2 super-chunks
     int want = (6144 + blocks_x - 1) / blocks_x;
-    int max_split = std::max(1, n_chunks / 64);
+    int max_split = std::max(1, n_super / 2);
     int nsplit = std::max(1, std::min(std::min(want, max_split), KN_MAXSPLIT));
     if (const char* e = getenv("TDV_KNN_NSPLIT")) nsplit = std::max(1, std::min(std::min(atoi(e), max_split), KN_MAXSPLIT));  // tuning knob
     return nsplit;
@@ -669,14 +770,14 @@ int pick_nsplit(int blocks_x, int n_chunks) {
 ScanPlan make_scan_plan(int n) {
     ScanPlan p;
     p.n_pad = (int)align_up((size_t)n, KN_BLOCK);
-    p.nt_pad = (int)align_up((size_t)n, KN_CH);
-    p.n_chunks = p.nt_pad / KN_CH;
+    p.nt_pad = (int)align_up((size_t)n, 16);
+    p.n_chunks = p.nt_pad / 16;          // 16-target chunks
     p.blocks_x = p.n_pad / KN_BLOCK;
-    p.nsplit = pick_nsplit(p.blocks_x, p.n_chunks);
+    p.nsplit = pick_nsplit(p.blocks_x, (p.n_chunks + 15) / 16);
     return p;
 }
 
-struct Sorted { float *sx, *sy, *sz; int* orig; };
+struct Sorted { float *sx, *sy, *sz; int* orig; float *cbox, *sbox; int n_chunks16, n_super; };
 
 // Morton sort of the cloud: sorted SoA coordinates (padded with +inf) and the original index of each position
 int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sorted& so) {
@@ -696,6 +797,13 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     k_morton_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, bbox, rec);
     TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
     k_gather_sorted<<<(pad + 255) / 256, 256, 0, s>>>(d_xyz, rec, n, pad, so.sx, so.sy, so.sz, so.orig);
+    // bounding boxes of the 16-target chunks and 256-target super-chunks (exact pruning of the scans)
+    so.n_chunks16 = (int)(align_up((size_t)n, 16) / 16);
+    so.n_super = (so.n_chunks16 + 15) / 16;
+    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_chunks16, &so.cbox));
+    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_super, &so.sbox));
+    k_chunk_boxes<<<(so.n_chunks16 + 255) / 256, 256, 0, s>>>(so.sx, so.sy, so.sz, so.n_chunks16, so.cbox);
+    k_super_boxes<<<(so.n_super + 255) / 256, 256, 0, s>>>(so.cbox, so.n_chunks16, so.n_super, so.sbox);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
@@ -708,7 +816,8 @@ int scan_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int 
     if (nqq <= 0) return TDV_OK;
     const int nq_pad = (int)align_up((size_t)nqq, KN_BLOCK);
     const int blocks_x = nq_pad / KN_BLOCK;
-    const int nsplit = qsel ? pick_nsplit(blocks_x, p.n_chunks) : p.nsplit;
+    const int nsplit = qsel ? pick_nsplit(blocks_x, so.n_super) : p.nsplit;
+    static const int prune = getenv("TDV_NO_PRUNE") ? 0 : 1;   // A/B knob: 0 = evaluate every pair (pure brute force)
     float* pd; int *pi, *pc;
     TDV_TRY(ws_alloc(ctx, (size_t)nsplit * k * nq_pad, &pd));
     TDV_TRY(ws_alloc(ctx, (size_t)nsplit * k * nq_pad, &pi));
@@ -717,14 +826,16 @@ int scan_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int 
     {
         ScopedTimer tm(ctx, timer);
         dim3 grid(blocks_x, nsplit);
-#define TDV_REG_SCAN(KK) k_topk_scan_reg<KK><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, p.n_chunks, nsplit, k, bound0, qsel, nsel, pd, pi, pc)
+#define TDV_REG_SCAN(KK) k_topk_scan_reg<KK><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, so.n_chunks16, so.n_super, nsplit, k, bound0, \
+                                                                     so.cbox, so.sbox, prune, qsel, nsel, pd, pi, pc)
         if (k <= 8) TDV_REG_SCAN(8);
         else if (k <= 16) TDV_REG_SCAN(16);
         else if (k <= 30) TDV_REG_SCAN(30);
         else if (k <= 32) TDV_REG_SCAN(32);
         else {
             if (qsel) return TDV_ERR_INTERNAL;  // subset scans are only issued for k <= 32
-            k_topk_scan_glob<<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, p.n_chunks, nsplit, k, bound0, pd, pi, pc);
+            k_topk_scan_glob<<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, so.n_chunks16, so.n_super, nsplit, k, bound0,
+                                                       so.cbox, so.sbox, prune, pd, pi, pc);
         }
 #undef TDV_REG_SCAN
     }
@@ -760,7 +871,7 @@ int knn_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k
     TDV_TRY(ws_alloc(ctx, (size_t)nq_pad * CS_CAP, &cand));
     TDV_TRY(pin_reserve(ctx, 64));
     int* h_total = reinterpret_cast<int*>(ctx->pin);
-    const int n_chunks16 = (int)(align_up((size_t)n, CS_CH) / CS_CH);   // the sorted arrays are padded to >= this (spatial_sort)
+    static const int prune = getenv("TDV_NO_PRUNE") ? 0 : 1;   // A/B knob: 0 = evaluate every pair (pure brute force)
     const int* cur_q = qsel;
     float* cur_b = bound;
     int* next_q = qselA;
@@ -775,13 +886,14 @@ int knn_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k
         const int qblocks = (nqq + KN_BLOCK - 1) / KN_BLOCK;
         const int cblocks = (nqq + KN_BLOCK * CS_SPL - 1) / (KN_BLOCK * CS_SPL);
         int want = (8192 + cblocks - 1) / cblocks;
-        int csplit = std::max(1, std::min(want, std::max(1, n_chunks16 / 16)));
-        int cps = (n_chunks16 + csplit - 1) / csplit;
-        csplit = (n_chunks16 + cps - 1) / cps;
+        int csplit = std::max(1, std::min(want, so.n_super));
+        int ups = (so.n_super + csplit - 1) / csplit;      // super-chunks per split
+        csplit = (so.n_super + ups - 1) / ups;
         TDV_HIP(ctx, hipMemsetAsync(ccnt, 0, (size_t)nqq * 4, s));
         {
             ScopedTimer tm(ctx, TDV_TIMER_KNN);
-            k_collect_scan<<<dim3(cblocks, csplit), KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, n_chunks16, cps, cur_q, nqq, cur_b, CS_CAP, ccnt, cand);
+            k_collect_scan<<<dim3(cblocks, csplit), KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_chunks16, so.n_super, ups, so.cbox, so.sbox, prune,
+                                                                      cur_q, nqq, cur_b, CS_CAP, ccnt, cand);
 #define TDV_SEL(KK) k_select_topk<KK><<<qblocks, KN_BLOCK, 0, s>>>(so.orig, cur_q, nqq, k, CS_CAP, p.n_pad, ccnt, cand, lists, cnt, ovf, bnext)
             if (k <= 8) TDV_SEL(8); else if (k <= 16) TDV_SEL(16); else if (k <= 30) TDV_SEL(30); else TDV_SEL(32);
 #undef TDV_SEL
