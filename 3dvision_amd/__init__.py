@@ -41,7 +41,7 @@ TIMER_ICP_NN, TIMER_RANSAC_SCORE, TIMER_FEATURE_MATCH, TIMER_KNN, TIMER_RADIUS, 
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [
-    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
@@ -186,6 +186,12 @@ class Context:
         self.device = device
         if stream is not None:
             _check(self._h, lib().tdv_ctx_set_stream(self._h, C.c_void_p(stream)), "tdv_ctx_set_stream")
+
+    ICP_SEARCH = {"auto": 0, "brute": 1, "pruned": 2}
+
+    def set_icp_search(self, mode):
+        """'auto' (by size), 'brute' (the reference's scan) or 'pruned' (exact box-pruned walk); same results."""
+        _check(self._h, lib().tdv_ctx_set_icp_search(self._h, self.ICP_SEARCH[mode]), "tdv_ctx_set_icp_search")
 
     def close(self):
         if self._h:

@@ -185,7 +185,17 @@ int tdv_ctx_create(int device, tdv_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TDV_ERR_NO_DEVICE; }
     c->own_stream = true;
+    if (const char* e = getenv("TDV_ICP_SEARCH")) {
+        if (!strcmp(e, "brute")) c->icp_search = TDV_ICP_SEARCH_BRUTE;
+        else if (!strcmp(e, "pruned")) c->icp_search = TDV_ICP_SEARCH_PRUNED;
+    }
     *out = c;
+    return TDV_OK;
+}
+
+int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode) {
+    if (!ctx || mode < TDV_ICP_SEARCH_AUTO || mode > TDV_ICP_SEARCH_PRUNED) return TDV_ERR_BAD_ARG;
+    ctx->icp_search = mode;
     return TDV_OK;
 }
 

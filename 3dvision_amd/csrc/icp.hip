@@ -22,10 +22,17 @@
 //    in a FIXED order (wave64 shuffles -> LDS -> one slab per block); f64 accumulators.
 //  * icp_solve: one block folds the slabs in fixed order, one lane solves the 6x6 system
 //    (pivoted LDL^T) or the 3x3 Kabsch SVD, updates T on the device and evaluates convergence.
+//  * icp_nn_pruned (large clouds, same correspondences bit for bit): both clouds are Morton-sorted once per call;
+//    a wave of 64 neighbouring source points walks the target's 4096/256/16-point bounding boxes and skips every
+//    box whose exact lower bound exceeds all its lanes' current bounds (bound = the inclusive acceptance threshold,
+//    then the best distance found).  Float subtraction, multiplication and addition are monotone under
+//    round-to-nearest, so the bound needs no margin; ties keep the lowest original target index as the scan does.
+//    Results are written at the original source index, so accumulate/solve run unchanged.
 // No float atomics anywhere: two runs give identical bits.
 #include "tdv_internal.hpp"
 #include "device_linalg.hpp"
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <algorithm>
 
@@ -36,6 +43,7 @@ constexpr int NN_CH = 16;      // targets per chunk (one s_load_dwordx16 per coo
 constexpr int NN_BLOCK = 128;    // two waves per workgroup (no LDS, no barrier): many workgroups with few target splits,
                                  // so the per-split partials (8 B per source per split) stay small
 constexpr int NN_SRC_PER_BLOCK = NN_SPL * NN_BLOCK;
+constexpr double PRUNED_MIN_PAIRS = 2e9;   // auto mode: pruned search from this many source x target pairs
 constexpr int ACC_NV = 32;     // reduction slots per block (29 used p2plane, 17 p2point)
 
 struct IcpState {
@@ -111,6 +119,106 @@ void k_icp_nn_scan(const float* __restrict__ src, int ns, int ns_pad,
     }
 }
 
+// ---- exact pruned search --------------------------------------------------------------------------------------
+constexpr int PN_BLOCK = 64;   // one wave per workgroup
+
+// lower bound of fl(d2) between point p and any point inside box idx (see knn.hip: box_lower_bound)
+__device__ __forceinline__ float point_box_lb(const float* __restrict__ box, int count, int idx, float px, float py, float pz) {
+    const float gx = fmaxf(0.f, fmaxf(box[idx] - px, px - box[(size_t)3 * count + idx]));
+    const float gy = fmaxf(0.f, fmaxf(box[(size_t)count + idx] - py, py - box[(size_t)4 * count + idx]));
+    const float gz = fmaxf(0.f, fmaxf(box[(size_t)2 * count + idx] - pz, pz - box[(size_t)5 * count + idx]));
+    return gx * gx + (gy * gy + gz * gz);
+}
+
+// the 16 targets of chunk c against the lane's point: bound/bidx keep the smallest d2 (<= the initial bound),
+// lowest original index on ties
+__device__ __forceinline__ void pruned_eval_chunk(const float* __restrict__ tx, const float* __restrict__ ty,
+                                                  const float* __restrict__ tz, const int* __restrict__ torig, int nt,
+                                                  int c, float px, float py, float pz, float& bound, int& bidx) {
+    const int j = c * NN_CH;
+    float d2[NN_CH];
+    float m = FLT_MAX;
+#pragma unroll
+    for (int t = 0; t < NN_CH; ++t) {
+        float dx = px - tx[j + t], dy = py - ty[j + t], dz = pz - tz[j + t];
+        d2[t] = dx * dx + (dy * dy + dz * dz);
+        m = fminf(m, d2[t]);
+    }
+    if (!__any(m <= bound)) return;
+#pragma unroll
+    for (int t = 0; t < NN_CH; ++t) {
+        const int o = torig[j + t];
+        const bool take = (j + t < nt) && (d2[t] < bound || (d2[t] == bound && o < bidx));
+        bound = take ? d2[t] : bound;
+        bidx = take ? o : bidx;
+    }
+}
+
+__device__ __forceinline__ void pruned_eval_super(const float* __restrict__ tx, const float* __restrict__ ty,
+                                                  const float* __restrict__ tz, const int* __restrict__ torig, int nt,
+                                                  const float* __restrict__ cbox, int n_c16, int u,
+                                                  float px, float py, float pz, float& bound, int& bidx) {
+    const int cend = min(n_c16, u * 16 + 16);
+    for (int c = u * 16; c < cend; ++c) {
+        if (!__any(point_box_lb(cbox, n_c16, c, px, py, pz) <= bound)) continue;
+        pruned_eval_chunk(tx, ty, tz, torig, nt, c, px, py, pz, bound, bidx);
+    }
+}
+
+__global__ __launch_bounds__(PN_BLOCK)
+void k_icp_nn_pruned(const float* __restrict__ ssx, const float* __restrict__ ssy, const float* __restrict__ ssz,
+                     const int* __restrict__ sorig, int ns,
+                     const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                     const int* __restrict__ torig, int nt,
+                     const float* __restrict__ cbox, int n_c16, const float* __restrict__ sbox, int n_super,
+                     const float* __restrict__ tbox, int n_top,
+                     const IcpState* __restrict__ st, float tau,
+                     float* __restrict__ out_d2, int* __restrict__ out_idx) {
+    if (st->done) return;
+    const int i = blockIdx.x * PN_BLOCK + threadIdx.x;
+    const int ii = min(i, ns - 1);
+    float px, py, pz;
+    transform_point(st->T, ssx[ii], ssy[ii], ssz[ii], px, py, pz);
+    float bound = tau;       // inclusive: a target passes iff d2 <= bound
+    int bidx = INT_MAX;      // none yet
+    // seed: the closest 256-target box of each lane (by lower bound) is evaluated first, so that the bound is
+    // near the true NN distance before the walk even when the acceptance threshold is loose
+    {
+        int bt = 0; float bl = INFINITY;
+        for (int t = 0; t < n_top; ++t) {
+            const float l = point_box_lb(tbox, n_top, t, px, py, pz);
+            if (l < bl) { bl = l; bt = t; }
+        }
+        int bs = bt * 16; bl = INFINITY;
+        const int uend = min(n_super, bt * 16 + 16);
+        for (int u = bt * 16; u < uend; ++u) {   // lane-divergent boxes: vector loads
+            const float l = point_box_lb(sbox, n_super, u, px, py, pz);
+            if (l < bl) { bl = l; bs = u; }
+        }
+        bool seeded = false;
+        while (true) {
+            const unsigned long long todo = __ballot(!seeded);
+            if (!todo) break;
+            const int u = __builtin_amdgcn_readfirstlane(__shfl(bs, __ffsll((long long)todo) - 1, 64));
+            pruned_eval_super(tx, ty, tz, torig, nt, cbox, n_c16, u, px, py, pz, bound, bidx);
+            seeded = seeded || (bs == u);
+        }
+    }
+    for (int t = 0; t < n_top; ++t) {
+        if (!__any(point_box_lb(tbox, n_top, t, px, py, pz) <= bound)) continue;
+        const int uend = min(n_super, t * 16 + 16);
+        for (int u = t * 16; u < uend; ++u) {
+            if (!__any(point_box_lb(sbox, n_super, u, px, py, pz) <= bound)) continue;
+            pruned_eval_super(tx, ty, tz, torig, nt, cbox, n_c16, u, px, py, pz, bound, bidx);
+        }
+    }
+    if (i < ns) {
+        const int o = sorig[i];
+        out_d2[o] = bidx == INT_MAX ? FLT_MAX : bound;
+        out_idx[o] = bidx == INT_MAX ? 0 : bidx;
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -124,7 +232,7 @@ __global__ __launch_bounds__(256)
 void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
                       const float* __restrict__ tgt, const float* __restrict__ tgt_normals,
                       const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
-                      int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk,
+                      int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk, int direct,
                       const IcpState* __restrict__ st, float tau_accept,
                       double* __restrict__ slabs,
                       int* __restrict__ out_corr, float* __restrict__ out_d2, uint8_t* __restrict__ out_acc) {
@@ -143,7 +251,9 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
             if (d < best) { best = d; bc = c; }
         }
         int idx = 0;
-        if (best < FLT_MAX) {
+        if (direct) {   // pruned search: pd2/pchunk already hold the final (d2, target index)
+            idx = bc;
+        } else if (best < FLT_MAX) {
             idx = bc;
 #pragma unroll
             for (int t = NN_CH - 1; t >= 0; --t) {
@@ -326,7 +436,14 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     out->fitness = 0.f; out->rmse = 0.f; out->iterations = 0; out->n_corr = 0;
     if (max_iterations == 0) return TDV_OK;
     if (ns == 0 || nt == 0) return TDV_OK;  // n_corr == 0 < 3 -> break at the first iteration
-    const NnPlan p = make_plan(ns, nt);
+    const float tau = tau_le(thr);
+    // search: brute force for small problems (the two Morton sorts cost more than they save), exact pruned walk
+    // for large ones; both give the same correspondences bit for bit
+    bool pruned = ctx->icp_search == TDV_ICP_SEARCH_PRUNED ||
+                  (ctx->icp_search == TDV_ICP_SEARCH_AUTO && (double)ns * (double)nt >= PRUNED_MIN_PAIRS);
+    if (!(tau < FLT_MAX)) pruned = false;   // unbounded threshold: keep the scan's handling of overflowing distances
+    NnPlan p = make_plan(ns, nt);
+    if (pruned) p.nsplit = 1;
     IcpBuffers b;
     TDV_TRY(alloc_buffers(ctx, p, b));
     TDV_TRY(pin_reserve(ctx, sizeof(IcpState)));
@@ -335,10 +452,16 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     std::memcpy(h->T, T0, 64); std::memcpy(h->res_T, T0, 64);
     hipStream_t s = ctx->stream;
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
-    k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
+    SortedCloud ss{}, st{};
+    if (pruned) {
+        TDV_TRY(spatial_sort_cloud(ctx, d_src, ns, ss));   // rigid motion keeps neighbours together: sorted once
+        TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
+    } else {
+        k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
+    }
     TDV_CHECK_LAUNCH(ctx);
     const bool p2pl = point_to_plane && d_tgt_normals;
-    const float tau = tau_le(thr);
+    const int direct = pruned ? 1 : 0;
     const dim3 grid(p.blocks_x, p.nsplit);
     const int poll = 8;
     int it = 0;
@@ -347,16 +470,21 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
         for (int k = 0; k < burst; ++k) {
             {
                 ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
-                k_icp_nn_scan<<<grid, NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
-                                                        p.chunks_per_split, b.st, b.pd2, b.pchunk);
+                if (pruned)
+                    k_icp_nn_pruned<<<(ns + PN_BLOCK - 1) / PN_BLOCK, PN_BLOCK, 0, s>>>(
+                        ss.sx, ss.sy, ss.sz, ss.orig, ns, st.sx, st.sy, st.sz, st.orig, nt, st.cbox, st.n_chunks16,
+                        st.sbox, st.n_super, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
+                else
+                    k_icp_nn_scan<<<grid, NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
+                                                            p.chunks_per_split, b.st, b.pd2, b.pchunk);
             }
             if (p2pl) {
                 k_icp_accumulate<0><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, d_tgt_normals, b.tx, b.ty, b.tz,
-                                                                 p.nsplit, b.pd2, b.pchunk, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
+                                                                 p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
                 k_icp_solve<0><<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, ns, b.st, fixed_iterations);
             } else {
                 k_icp_accumulate<1><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz,
-                                                                 p.nsplit, b.pd2, b.pchunk, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
+                                                                 p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
                 k_icp_solve<1><<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, ns, b.st, fixed_iterations);
             }
         }
@@ -375,7 +503,9 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
                             const float* T, float thr, IcpOutputs outs, int* n_corr) {
     if (!ctx || !d_src || !d_tgt || !T || ns <= 0 || nt <= 0) return TDV_ERR_BAD_ARG;
     TDV_HIP(ctx, hipSetDevice(ctx->device));
-    const NnPlan p = make_plan(ns, nt);
+    NnPlan p = make_plan(ns, nt);
+    const bool pruned = ctx->icp_search == TDV_ICP_SEARCH_PRUNED && tau_le(thr) < FLT_MAX;
+    if (pruned) p.nsplit = 1;
     IcpBuffers b;
     TDV_TRY(alloc_buffers(ctx, p, b));
     TDV_TRY(pin_reserve(ctx, sizeof(IcpState)));
@@ -384,11 +514,21 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
     std::memcpy(h->T, T, 64);
     hipStream_t s = ctx->stream;
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
-    k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
-    k_icp_nn_scan<<<dim3(p.blocks_x, p.nsplit), NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
-                                                                  p.chunks_per_split, b.st, b.pd2, b.pchunk);
+    const float tau = tau_le(thr);
+    if (pruned) {   // explicit request only: entries beyond the threshold come back as corr 0 / d2 FLT_MAX
+        SortedCloud ss{}, st{};
+        TDV_TRY(spatial_sort_cloud(ctx, d_src, ns, ss));
+        TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
+        k_icp_nn_pruned<<<(ns + PN_BLOCK - 1) / PN_BLOCK, PN_BLOCK, 0, s>>>(
+            ss.sx, ss.sy, ss.sz, ss.orig, ns, st.sx, st.sy, st.sz, st.orig, nt, st.cbox, st.n_chunks16,
+            st.sbox, st.n_super, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
+    } else {
+        k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
+        k_icp_nn_scan<<<dim3(p.blocks_x, p.nsplit), NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
+                                                                      p.chunks_per_split, b.st, b.pd2, b.pchunk);
+    }
     k_icp_accumulate<2><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz, p.nsplit,
-                                                     b.pd2, b.pchunk, b.st, tau_le(thr), b.slabs, outs.corr, outs.d2, outs.accepted);
+                                                     b.pd2, b.pchunk, pruned ? 1 : 0, b.st, tau, b.slabs, outs.corr, outs.d2, outs.accepted);
     k_icp_count_only<<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, b.st);
     TDV_CHECK_LAUNCH(ctx);
     TDV_HIP(ctx, hipMemcpyAsync(h, b.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));

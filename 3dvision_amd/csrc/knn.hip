@@ -808,6 +808,23 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     return TDV_OK;
 }
 
+}  // namespace
+
+int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out) {
+    const ScanPlan p = make_scan_plan(n);
+    Sorted so;
+    TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
+    out.sx = so.sx; out.sy = so.sy; out.sz = so.sz; out.orig = so.orig; out.cbox = so.cbox; out.sbox = so.sbox;
+    out.n = n; out.pad = std::max(p.n_pad, (int)align_up((size_t)p.nt_pad, 16));
+    out.n_chunks16 = so.n_chunks16; out.n_super = so.n_super; out.n_top = (so.n_super + 15) / 16;
+    TDV_TRY(ws_alloc(ctx, (size_t)6 * out.n_top, &out.tbox));
+    k_super_boxes<<<(out.n_top + 255) / 256, 256, 0, ctx->stream>>>(so.sbox, so.n_super, out.n_top, out.tbox);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+namespace {
+
 // Scan + per-split lists + merge into lists[r * p.n_pad + original index] / cnt[original index].
 // qsel == nullptr: all n queries; else the nsel sorted positions in qsel (device).
 int scan_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, float bound0, int timer,

@@ -53,6 +53,13 @@ int tdv_ctx_set_stream(tdv_ctx* ctx, void* hip_stream);
 void* tdv_ctx_get_stream(tdv_ctx* ctx);
 int tdv_ctx_synchronize(tdv_ctx* ctx);
 void tdv_ctx_destroy(tdv_ctx* ctx);
+/* ICP correspondence search.  The reference's kernel is a brute-force scan (cuda/icp.cu:14-55); the pruned search
+ * returns the SAME correspondences bit for bit (exact bounding-box lower bounds, lowest index on ties) and only
+ * differs in time.  AUTO (default; env TDV_ICP_SEARCH=brute|pruned overrides at ctx creation) picks by size. */
+#define TDV_ICP_SEARCH_AUTO 0
+#define TDV_ICP_SEARCH_BRUTE 1
+#define TDV_ICP_SEARCH_PRUNED 2
+int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode);
 const char* tdv_status_string(int status);
 /* Text of the last HIP error seen by this ctx ("" if none). */
 const char* tdv_last_error(tdv_ctx* ctx);

@@ -64,6 +64,29 @@ def test_icp_200k_reproducible_and_converges(ctx, synth, clouds):
     assert np.abs(T_gt[:3, 3] - a.transformation[:3, 3]).max() < 5e-4
 
 
+def test_icp_pruned_search_200k_identical_to_scan(ctx, synth, clouds):
+    """Headline size: the pruned walk and the brute-force scan give the same accepted correspondences (all 200k rows)
+    and the same ICP result bit for bit."""
+    src, tgt, nrm, T_gt = clouds
+    T0 = synth.perturb(T_gt)
+    try:
+        ctx.set_icp_search("brute")
+        cb = ctx.icp_correspondences(src, tgt, T0, 0.003)
+        a = ctx.icp(src, tgt, nrm, T0, 0.003, 12, True)
+        ctx.set_icp_search("pruned")
+        cp = ctx.icp_correspondences(src, tgt, T0, 0.003)
+        b = ctx.icp(src, tgt, nrm, T0, 0.003, 12, True)
+    finally:
+        ctx.set_icp_search("auto")
+    acc = cb["accepted"].astype(bool)
+    assert acc.sum() > N // 4
+    assert np.array_equal(cp["accepted"], cb["accepted"]) and cp["n_corr"] == cb["n_corr"]
+    assert np.array_equal(cp["corr"][acc], cb["corr"][acc])
+    assert cp["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
+    assert a.transformation.tobytes() == b.transformation.tobytes()
+    assert (a.iterations, a.n_corr, a.rmse, a.fitness) == (b.iterations, b.n_corr, b.rmse, b.fitness)
+
+
 def test_feature_match_100k_sampled(ctx, orc, synth):
     """Config C3 (100k x 100k descriptors): 300 sampled source rows against the oracle."""
     n = 100000

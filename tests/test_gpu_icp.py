@@ -124,3 +124,70 @@ def test_gpu_registration_operator_api(tdv, orc, synth):
     ref = orc.icp(src, tgt, nrm, synth.perturb(T_gt), 0.004, 40, True)
     assert synth.rotation_angle(ref["T"][:3, :3], res.transformation[:3, :3]) <= ROT_TOL
     assert np.abs(ref["T"][:3, 3] - res.transformation[:3, 3]).max() <= TRANS_TOL
+
+
+# ---- exact pruned correspondence search (same results as the scan, bit for bit) -------------------------------
+
+@pytest.fixture
+def pruned(ctx):
+    ctx.set_icp_search("pruned")
+    yield ctx
+    ctx.set_icp_search("auto")
+
+
+@pytest.mark.parametrize("ns,nt,thr", [(3000, 2000, 0.004), (1, 1, 0.5), (5, 3, 0.5), (1025, 9, 0.01), (4097, 1031, 0.004),
+                                       (6000, 5000, 10.0), (6000, 5000, 1e-4), (300, 70000, 0.02)])
+def test_pruned_search_matches_oracle(pruned, orc, synth, ns, nt, thr):
+    """Accepted correspondences (index, d2) identical to the oracle's full scan; the rest are rejected in both."""
+    src, tgt, nrm, T_gt = _pair(synth, ns, nt)
+    T = synth.perturb(T_gt)
+    ref = orc.icp_correspondences(src, tgt, nrm, T, thr)
+    got = pruned.icp_correspondences(src, tgt, T, thr)
+    acc = ref["accepted"].astype(bool)
+    assert np.array_equal(got["accepted"], ref["accepted"])
+    assert np.array_equal(got["corr"][acc], ref["corr"][acc])
+    assert got["d2"][acc].tobytes() == ref["d2"][acc].tobytes()
+    assert got["n_corr"] == ref["n_corr"]
+    if thr >= 10.0:
+        assert acc.all()   # loose threshold: the seeded walk still returns the true nearest neighbour of every point
+
+
+def test_pruned_search_ties_lowest_index(pruned, orc, synth):
+    src, tgt, nrm, T_gt = _pair(synth, 2000, 700)
+    tgt = np.concatenate([tgt, tgt[::-1], tgt[:300]], 0)
+    ref = orc.icp_correspondences(src, tgt, None, T_gt, 0.01, point_to_plane=False)
+    got = pruned.icp_correspondences(src, tgt, T_gt, 0.01)
+    acc = ref["accepted"].astype(bool)
+    assert acc.sum() > 1000
+    assert np.array_equal(got["accepted"], ref["accepted"])
+    assert np.array_equal(got["corr"][acc], ref["corr"][acc])
+    assert got["corr"][acc].max() < 700
+
+
+def test_pruned_threshold_inclusive(pruned, orc):
+    tgt = np.zeros((4, 3), np.float32)
+    tgt[1:] = 100.0
+    thr = np.float32(0.003)
+    d = np.array([0.003, np.nextafter(np.float32(0.003), np.float32(1)), np.nextafter(np.float32(0.003), np.float32(0)), 0.0029999], np.float32)
+    src = np.zeros((len(d), 3), np.float32)
+    src[:, 0] = d
+    ref = orc.icp_correspondences(src, tgt, None, np.eye(4, dtype=np.float32), thr, point_to_plane=False)
+    got = pruned.icp_correspondences(src, tgt, np.eye(4, dtype=np.float32), thr)
+    assert np.array_equal(got["accepted"], ref["accepted"])
+
+
+@pytest.mark.parametrize("p2plane", [True, False])
+@pytest.mark.parametrize("thr", [0.004, 0.05])
+def test_icp_pruned_and_brute_identical_bits(ctx, synth, p2plane, thr):
+    src, tgt, nrm, T_gt = _pair(synth, 9000, 7000)
+    T0 = synth.perturb(T_gt)
+    try:
+        ctx.set_icp_search("brute")
+        a = ctx.icp(src, tgt, nrm, T0, thr, 30, p2plane)
+        ctx.set_icp_search("pruned")
+        b = ctx.icp(src, tgt, nrm, T0, thr, 30, p2plane)
+    finally:
+        ctx.set_icp_search("auto")
+    assert a.transformation.tobytes() == b.transformation.tobytes()
+    assert (a.iterations, a.n_corr) == (b.iterations, b.n_corr)
+    assert a.rmse == b.rmse and a.fitness == b.fitness

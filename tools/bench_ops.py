@@ -160,16 +160,19 @@ def main():
             d_s = torch.from_numpy(src).to(dev); d_t = torch.from_numpy(tgt).to(dev); d_n = torch.from_numpy(nrm).to(dev)
             thr = float(synth.mean_spacing(nt)) * 4
             iters = 50
-            for mode in (True, False):
+            for search in ("brute", "pruned"):
+              ctx.set_icp_search(search)
+              for mode in (True, False):
                 def f():
                     return ctx.icp_dev(d_s.data_ptr(), ns, d_t.data_ptr(), d_n.data_ptr(), nt, T0, thr, iters, mode, fixed_iterations=True)
                 ctx.timing_read(tdv.TIMER_ICP_NN)
                 t = timed(f, reps=2)
                 ms, l = ctx.timing_read(tdv.TIMER_ICP_NN)
                 r = f()
-                emit(op="icp_fixed50", ns=ns, nt=nt, point_to_plane=mode, wall_ms=t * 1e3, iters_per_s=iters / t, nn_kernel_ms=ms / max(l, 1),
+                emit(op="icp_fixed50", search=search, ns=ns, nt=nt, point_to_plane=mode, wall_ms=t * 1e3, iters_per_s=iters / t, nn_kernel_ms=ms / max(l, 1),
                      nn_Tops=8.0 * ns * nt / (ms / max(l, 1) * 1e-3) / 1e12, fitness=float(r.fitness),
                      ang_to_gt=synth.rotation_angle(T_gt[:3, :3], r.transformation[:3, :3]))
+            ctx.set_icp_search("auto")
     # ---------------- C3: RANSAC 100k, 50k hypotheses
     if want("ransac"):
         for n, hyps in [(100000, 50000)] + ([] if args.quick else [(200000, 100000)]):
