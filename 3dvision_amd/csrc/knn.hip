@@ -423,43 +423,64 @@ void k_collect_scan(const float* __restrict__ sx, const float* __restrict__ sy, 
 }
 
 // Phase C: exact top-k of a query's candidates in (d2, idx) order; the final list goes to lists[r*n_pad + i], cnt_out[i]
-// (by original index).  overflow[slot] = 1 when the row was too small (the caller re-runs those queries by streaming).
-template <int K>
+// (by original index).  overflow[slot] = 1 when the row was too small (the caller re-runs those queries with
+// bound_next, the k-th smallest of the cap candidates it did keep: a valid, tighter bound).
+// One WAVE per query: the row (<= 128 keys, 64-bit = d2 bits : original index, so unsigned order is (d2, idx) order)
+// is sorted by a bitonic network across the lanes, two keys per lane.
+__device__ __forceinline__ void cmpx_keys(unsigned& hi, unsigned& lo, unsigned phi, unsigned plo, bool keep_min) {
+    const bool p_less = (phi < hi) || (phi == hi && plo < lo);
+    const bool take = keep_min ? p_less : !p_less;   // keys are distinct (distinct indices) except the ~0 padding
+    hi = take ? phi : hi; lo = take ? plo : lo;
+}
+constexpr int SEL_WAVES = KN_BLOCK / 64;
 __global__ __launch_bounds__(KN_BLOCK)
 void k_select_topk(const int* __restrict__ orig, const int* __restrict__ qsel, int nqq, int k, int cap, int n_pad,
                    const int* __restrict__ cnt, const unsigned long long* __restrict__ cand,
                    int* __restrict__ lists, int* __restrict__ cnt_out, int* __restrict__ overflow, float* __restrict__ bound_next) {
-    const int slot = blockIdx.x * KN_BLOCK + threadIdx.x;
-    const bool live = slot < nqq;
-    const int sl = min(slot, nqq - 1);
-    const int m_all = live ? cnt[sl] : 0;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * SEL_WAVES + (threadIdx.x >> 6);
+    if (slot >= nqq) return;   // wave-uniform
+    const int m_all = cnt[slot];
     const int m = min(m_all, cap);
-    float Ld[K]; int Li[K];
+    unsigned hi[2], lo[2];
 #pragma unroll
-    for (int e = 0; e < K; ++e) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
-    int maxm = m;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxm = max(maxm, __shfl_xor(maxm, off, 64));
-    for (int e = 0; e < maxm; ++e) {
-        unsigned long long key = e < m ? cand[(size_t)sl * cap + e] : ~0ull;
-        float d = e < m ? __uint_as_float((unsigned)(key >> 32)) : INFINITY;
-        int i = e < m ? (int)(unsigned)key : INT_MAX;
-        reg_insert<K>(Ld, Li, d, i);
+    for (int r = 0; r < 2; ++r) {
+        const int e = r * 64 + lane;
+        const unsigned long long key = e < m ? cand[(size_t)slot * cap + e] : ~0ull;
+        hi[r] = (unsigned)(key >> 32); lo[r] = (unsigned)key;
     }
-    if (!live) return;
-    const int i0 = orig[qsel ? qsel[sl] : sl];
+    // element index i = r*64 + lane; ascending bitonic sort of 128 (or of the first 64 when the row is short)
+    const int nsort = m > 64 ? 128 : 64;   // wave-uniform
+    for (int kk = 2; kk <= nsort; kk <<= 1) {
+        for (int j = kk >> 1; j >= 1; j >>= 1) {
+            if (j == 64) {   // partner is the lane's other key (only in the 128 sort, kk == 128: ascending everywhere)
+                const bool swap = (hi[1] < hi[0]) || (hi[1] == hi[0] && lo[1] < lo[0]);
+                const unsigned th = hi[0], tl = lo[0];
+                hi[0] = swap ? hi[1] : hi[0]; lo[0] = swap ? lo[1] : lo[0];
+                hi[1] = swap ? th : hi[1]; lo[1] = swap ? tl : lo[1];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (r == 1 && nsort == 64) continue;
+                    const int i = r * 64 + lane;
+                    const unsigned phi = __shfl_xor(hi[r], j, 64), plo = __shfl_xor(lo[r], j, 64);
+                    const bool asc = (i & kk) == 0;
+                    const bool lower = (i & j) == 0;
+                    cmpx_keys(hi[r], lo[r], phi, plo, asc == lower);
+                }
+            }
+        }
+    }
+    const int i0 = orig[qsel ? qsel[slot] : slot];
     const int c = min(k, m);
-#pragma unroll
-    for (int e = 0; e < K; ++e) if (e < c) lists[(size_t)e * n_pad + i0] = Li[e];
-    cnt_out[i0] = c;
-    overflow[slot] = m_all > cap ? 1 : 0;
-    // an overflowed row still holds cap >= k real candidates: their k-th smallest distance is a valid, tighter bound
-    float kth = Ld[K - 1];
-    if (k < K) {
-#pragma unroll
-        for (int e = 0; e < K; ++e) if (e == k - 1) kth = Ld[e];
+    if (lane < c) lists[(size_t)lane * n_pad + i0] = (int)lo[0];   // k <= 32: the output ranks sit in the first key of lanes 0..k-1
+    const unsigned kbits = __shfl(hi[0], k - 1, 64);
+    const float kth = kbits == 0xffffffffu ? INFINITY : __uint_as_float(kbits);   // padding: fewer than k candidates
+    if (lane == 0) {
+        cnt_out[i0] = c;
+        overflow[slot] = m_all > cap ? 1 : 0;
+        bound_next[slot] = kth;
     }
-    bound_next[slot] = kth;
 }
 __global__ void k_compact_overflow(const int* __restrict__ flag, const int* __restrict__ pos, const int* __restrict__ qsel, int nqq,
                                    const float* __restrict__ bound_next, int* __restrict__ qsel2, float* __restrict__ bound2) {
@@ -911,9 +932,8 @@ int knn_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k
             ScopedTimer tm(ctx, TDV_TIMER_KNN);
             k_collect_scan<<<dim3(cblocks, csplit), KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_chunks16, so.n_super, ups, so.cbox, so.sbox, prune,
                                                                       cur_q, nqq, cur_b, CS_CAP, ccnt, cand);
-#define TDV_SEL(KK) k_select_topk<KK><<<qblocks, KN_BLOCK, 0, s>>>(so.orig, cur_q, nqq, k, CS_CAP, p.n_pad, ccnt, cand, lists, cnt, ovf, bnext)
-            if (k <= 8) TDV_SEL(8); else if (k <= 16) TDV_SEL(16); else if (k <= 30) TDV_SEL(30); else TDV_SEL(32);
-#undef TDV_SEL
+            static_assert(CS_CAP == 128, "k_select_topk sorts rows of at most 128 keys");
+            k_select_topk<<<(nqq + SEL_WAVES - 1) / SEL_WAVES, KN_BLOCK, 0, s>>>(so.orig, cur_q, nqq, k, CS_CAP, p.n_pad, ccnt, cand, lists, cnt, ovf, bnext);
         }
         TDV_CHECK_LAUNCH(ctx);
         // queries whose candidate row overflowed go another round with the tightened bound

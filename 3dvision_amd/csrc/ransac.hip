@@ -34,52 +34,81 @@ constexpr int FM_SPL = 2;
 constexpr int FM_BLOCK = 256;
 constexpr int FM_SRC_PER_BLOCK = FM_SPL * FM_BLOCK;
 constexpr int FD = 33;
+constexpr int FM_SEED = 256;   // targets of the seeding launch
 
+// EARLY: partial-distance early exit.  dist accumulates non-negative terms in d order, and fl(a + b) >= a for b >= 0,
+// so once the partial sum is >= the lane's best the final distance cannot pass the strict "<": a target is dropped
+// as soon as that holds for every lane of the wave (checked after 11 and 22 of the 33 dimensions).  `seed` (the exact
+// best over the first targets, computed by a first launch) lets every split start with a tight bound.
+template <bool EARLY>
 __global__ __launch_bounds__(FM_BLOCK)
 void k_feature_match_scan(const float* __restrict__ fs, int ns, int ns_pad,
-                          const float* __restrict__ ft, int nt, int per_split,
+                          const float* __restrict__ ft, int j_begin, int j_end, int per_split,
+                          const float* __restrict__ seed, const uint4* __restrict__ order,
                           float* __restrict__ pd, int* __restrict__ pj) {
     const int split = blockIdx.y;
-    const int j0 = split * per_split;
-    const int j1 = min(nt, j0 + per_split);
+    const int j0 = j_begin + split * per_split;
+    const int j1 = min(j_end, j0 + per_split);
     const int base = blockIdx.x * FM_SRC_PER_BLOCK + threadIdx.x;
     float f[FM_SPL][FD];
-    float best[FM_SPL]; int bj[FM_SPL];
+    float best[FM_SPL]; int bj[FM_SPL]; int src[FM_SPL];
 #pragma unroll
     for (int s = 0; s < FM_SPL; ++s) {
-        int i = min(base + s * FM_BLOCK, ns - 1);
+        // with `order` (records sorted by seed distance, .w = source index) a wave holds sources whose bounds are
+        // alike, so it leaves a target as early as its typical lane does; results go back to the source's own row
+        const int t = base + s * FM_BLOCK;
+        src[s] = order ? (int)order[min(t, ns - 1)].w : t;
+        const int i = min(src[s], ns - 1);
 #pragma unroll
         for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
-        best[s] = FLT_MAX; bj[s] = 0;
+        best[s] = seed ? seed[i] : FLT_MAX;   // a seed comes from lower target indices: strict < keeps the tie rule
+        bj[s] = seed ? -1 : 0;
+        if (order && t >= ns) src[s] = -1;    // padding lane: duplicate work, no output
     }
     for (int j = j0; j < j1; ++j) {
         const float* __restrict__ g = ft + (size_t)j * FD;  // wave-uniform -> scalar loads
         float q[FD];
 #pragma unroll
         for (int d = 0; d < FD; ++d) q[d] = g[d];
+        float dist[FM_SPL];
+#pragma unroll
+        for (int s = 0; s < FM_SPL; ++s) dist[s] = 0.f;
+#pragma unroll
+        for (int seg = 0; seg < 3; ++seg) {
+#pragma unroll
+            for (int s = 0; s < FM_SPL; ++s)
+#pragma unroll
+                for (int d = seg * 11; d < seg * 11 + 11; ++d) { float diff = f[s][d] - q[d]; dist[s] += diff * diff; }
+            if (EARLY && seg < 2) {
+                bool alive = false;
+#pragma unroll
+                for (int s = 0; s < FM_SPL; ++s) alive = alive || (dist[s] < best[s]);
+                if (!__any(alive)) goto next_target;
+            }
+        }
 #pragma unroll
         for (int s = 0; s < FM_SPL; ++s) {
-            float dist = 0.f;
-#pragma unroll
-            for (int d = 0; d < FD; ++d) { float diff = f[s][d] - q[d]; dist += diff * diff; }
-            bool lt = dist < best[s];
-            best[s] = lt ? dist : best[s];
+            bool lt = dist[s] < best[s];
+            best[s] = lt ? dist[s] : best[s];
             bj[s] = lt ? j : bj[s];
         }
+    next_target:;
     }
 #pragma unroll
     for (int s = 0; s < FM_SPL; ++s) {
-        size_t o = (size_t)split * ns_pad + base + s * FM_BLOCK;
+        if (src[s] < 0) continue;
+        size_t o = (size_t)split * ns_pad + src[s];
         pd[o] = best[s]; pj[o] = bj[s];
     }
 }
 
-__global__ void k_feature_match_combine(int ns, int ns_pad, int nsplit, const float* __restrict__ pd,
+// partial results are combined in launch/split order with strict <: the lowest target index wins ties
+__global__ void k_feature_match_combine(int ns, int ns_pad, int nparts, const float* __restrict__ pd,
                                         const int* __restrict__ pj, int* __restrict__ corr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns) return;
     float best = FLT_MAX; int bj = 0;
-    for (int s = 0; s < nsplit; ++s) {
+    for (int s = 0; s < nparts; ++s) {
         float d = pd[(size_t)s * ns_pad + i];
         if (d < best) { best = d; bj = pj[(size_t)s * ns_pad + i]; }
     }
@@ -91,20 +120,32 @@ int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft
     if (ns == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
     if (nt == 0) { TDV_HIP(ctx, hipMemsetAsync(d_corr, 0, (size_t)ns * 4, s)); return TDV_OK; }
+    static const bool early = getenv("TDV_FM_NO_EARLY_EXIT") == nullptr;   // A/B knob: same results either way
     const int ns_pad = (int)align_up((size_t)ns, FM_SRC_PER_BLOCK);
     const int blocks_x = ns_pad / FM_SRC_PER_BLOCK;
+    // part 0: the first n_seed targets in one split (its exact best seeds the bound of every later split)
+    const int n_seed = early ? std::min(nt, FM_SEED) : 0;
+    const int rest = nt - n_seed;
     int want = (4096 + blocks_x - 1) / blocks_x;
-    int nsplit = std::max(1, std::min(std::min(want, std::max(1, nt / 64)), 64));
-    int per_split = (nt + nsplit - 1) / nsplit;
-    nsplit = (nt + per_split - 1) / per_split;
+    int nsplit = rest > 0 ? std::max(1, std::min(std::min(want, std::max(1, rest / 64)), 64)) : 0;
+    int per_split = nsplit ? (rest + nsplit - 1) / nsplit : 0;
+    nsplit = nsplit ? (rest + per_split - 1) / per_split : 0;
+    const int nparts = nsplit + (n_seed ? 1 : 0);
     float* pd; int* pj;
-    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pd));
-    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pj));
+    TDV_TRY(ws_alloc(ctx, (size_t)nparts * ns_pad, &pd));
+    TDV_TRY(ws_alloc(ctx, (size_t)nparts * ns_pad, &pj));
     {
         ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
-        k_feature_match_scan<<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, nt, per_split, pd, pj);
+        if (early) {
+            k_feature_match_scan<true><<<dim3(blocks_x, 1), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, n_seed, n_seed, nullptr, nullptr, pd, pj);
+            if (nsplit)   // (ordering the sources by seed distance was measured: no gain on FPFH descriptors, so rows stay in place)
+                k_feature_match_scan<true><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, n_seed, nt, per_split, pd, nullptr,
+                                                                                      pd + ns_pad, pj + ns_pad);
+        } else {
+            k_feature_match_scan<false><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, nt, per_split, nullptr, nullptr, pd, pj);
+        }
     }
-    k_feature_match_combine<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nsplit, pd, pj, d_corr);
+    k_feature_match_combine<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nparts, pd, pj, d_corr);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }

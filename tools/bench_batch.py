@@ -35,7 +35,12 @@ def main():
     ap.add_argument("--hyps", type=int, default=10000)
     ap.add_argument("--icp-iters", type=int, default=50)
     ap.add_argument("--voxel", type=float, default=0.0005)
+    ap.add_argument("--matched", action="store_true",
+                    help="scene and model voxelised at the same 1 mm (as pipeline.cpp does with one voxel_size): smaller clouds, "
+                         "but the registration is well-posed, so angle_to_gt is meaningful")
     args = ap.parse_args()
+    if args.matched:
+        args.voxel = 0.001
     import torch
     tdv = importlib.import_module("3dvision_amd")
     synth = importlib.import_module("3dvision_amd.synth")
@@ -52,10 +57,10 @@ def main():
     mask = np.where(hit, 255, 0).astype(np.uint8)
     B = args.instances
     masks = np.repeat(mask[None], B, 0)
-    model_raw, _ = synth.sample_object(args.model_points * 3, 7)
+    model_raw, _ = synth.sample_object(600000 if args.matched else args.model_points * 3, 7)
     d_raw = torch.from_numpy(model_raw).to(dev)
     d_mx = torch.empty_like(d_raw); d_mn = torch.empty_like(d_raw); d_mf = torch.empty((len(model_raw), 33), dtype=torch.float32, device=dev)
-    mvox = float(synth.mean_spacing(args.model_points))
+    mvox = args.voxel if args.matched else float(synth.mean_spacing(args.model_points))
     nm = ctx.prepare_model_dev(d_raw.data_ptr(), len(model_raw), mvox, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr())
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev)
     prm = tdv.batch_params(width=w, height=h, fx=f, fy=f, cx=cx, cy=cy, zmax=1.5, voxel_size=args.voxel,
@@ -73,7 +78,7 @@ def main():
     stage = {n: ctx.timing_read(i)[0] / B for i, n in enumerate(names)}
     Tinv = np.linalg.inv(T.astype(np.float64))
     ang = [synth.rotation_angle(Tinv[:3, :3], r["T"][:3, :3]) for r in res]
-    print(json.dumps(dict(config="C4-style batch: %d instances x %d-px mask of one 1280x720 frame vs %d-pt model" % (B, int(hit.sum()), nm),
+    print(json.dumps(dict(config=("matched-resolution batch (1 mm): " if args.matched else "C4-style batch: ") + "%d instances x %d-px mask of one 1280x720 frame vs %d-pt model" % (B, int(hit.sum()), nm),
                           instances=B, pixels_per_instance=int(hit.sum()), voxels_per_instance=res[0]["n_voxels"], model_points=nm,
                           wall_s=dt, instances_per_s=B / dt, ms_per_instance=dt / B * 1e3,
                           ransac_hyps_per_s=B * args.hyps / dt, icp_iters_per_s=sum(r["icp_iterations"] for r in res) / dt,
