@@ -1,34 +1,29 @@
-// Exact brute-force neighbour searches on gfx950 and the per-point estimators built on them.
+// Exact neighbour searches on gfx950 and the per-point estimators built on them.
 //
 // Replaces (no GPU entry point exists in the reference; src/pipeline.cpp:93-95 calls the CPU statics):
 //   findKNN + Registration::estimateNormals   /root/reference/src/registration.cpp:63-81, :105-130
 //   findRadiusNN + Registration::computeFPFH  /root/reference/src/registration.cpp:83-102, :133-201
 //
-// Every query still evaluates its distance to EVERY point (the reference's O(N^2) scan, 8 VALU ops per pair,
-// no FMA: d2 = dx*dx + (dy*dy + dz*dz)); what is engineered is what surrounds the scan, so that selection work
-// nearly vanishes and the scan itself has the shape of the ICP nearest-neighbour kernel:
-//   0. the cloud is sorted along a 30-bit Morton curve (bitonic sort shared with voxel.hip): the 64 queries of
-//      a wave are spatial neighbours, and so are the targets of a chunk;
-//   kNN (normals, k <= 32) — two phases, no selection state inside the scan:
-//   A. k_window_bound : an upper bound on each query's k-th neighbour distance from a 768-point window around
-//                       its own curve position (a subset of the cloud, so the bound can only be too large);
-//   B. k_collect_scan : the full scan with that FIXED bound — two queries per lane in VGPRs, 16 targets per
-//                       wave-uniform s_load step, min3 tree + one compare per chunk; the rare hits are appended
-//                       to the query's candidate row (integer atomic slot counter; row order is irrelevant);
-//   C. k_select_topk  : exact top-k of the row in the reference's (d2, index) order.  A row that overflowed still
-//                       holds >= k real candidates, whose k-th distance is a tighter valid bound: those few
-//                       queries repeat B/C as a subset until none overflows; exact ties beyond the row size end
-//                       in the streaming kernel below.
-//   radius search (FPFH, cap 100) and the kNN fallback — streaming selection: chunks are visited INSIDE-OUT from
-//   the workgroup's own curve position (splits take interleaved positions), so the per-lane bound is tight almost
-//   immediately and >99 % of chunks take the 70-instruction fast path; candidates queue per lane (8 entries) and
-//   are merged into a sorted per-lane list — in VGPRs with static indexing (k <= 32) or in global memory by a
-//   rank-merge (larger k).
-// Results are independent of the scan order and of the atomic arrival order; lists, normals and descriptors are
-// bit-identical to the CPU code's (tests/test_gpu_features.py, incl. massive exact ties).
-// In the batched chain normals_fpfh_dev shares ONE radius scan between normals and FPFH: a radius list is sorted by
-// (d2, idx), so its first k entries are the k nearest neighbours wherever it holds >= k; only the deficient points
-// go through A-C as a subset.
+// The reference scans all N points per query.  Here every (query, target) distance that is evaluated uses the
+// reference's expression, d2 = dx*dx + (dy*dy + dz*dz) with no FMA, and every target that is NOT evaluated is
+// excluded by an exact bounding-box lower bound (float subtraction, multiplication and addition are monotone under
+// round-to-nearest, so lb <= fl(d2) for every point inside the box: no margin), so the neighbour lists are the
+// reference's lists bit for bit, ties included:
+//   0. the cloud is sorted along a 30-bit Morton curve (bitonic sort shared with voxel.hip) and the bounding boxes
+//      of its 16- and 256-point runs are built once per cloud;
+//   1. k_window_bound (kNN, k <= 32): an upper bound on each query's k-th neighbour distance from a 768-point window
+//      around its own curve position (a subset of the cloud, so the bound can only be too large);
+//   2. k_query_wave: ONE WAVE PER QUERY.  The 256-point boxes are tested 64 per step (one per lane) against the
+//      query point and its bound; the targets of the boxes that pass are evaluated one per lane with coalesced
+//      loads; every target with d2 <= bound is appended to the query's row in LDS (ballot prefix: no atomics,
+//      deterministic order).  When the row fills, it is sorted in-wave (bitonic network on 64-bit keys
+//      d2 bits : original index, whose unsigned order is the reference's (d2, index) order), cut to the best k, and
+//      the bound drops to the k-th: exact for any number of ties.  At the end the row is sorted and its first k
+//      entries are the list.  kNN with k > 32 starts unbounded from the query's own 256-point run instead of step 1;
+//      the radius search (FPFH, cap 100) starts from r^2 and needs no step 1.
+// In the batched chain normals_fpfh_dev shares ONE radius search between normals and FPFH: a radius list is sorted
+// by (d2, idx), so its first k entries are the k nearest neighbours wherever it holds >= k; only the deficient
+// points go through steps 1-2 as a subset.
 // Per-point estimators run one lane per point with sequential sums in neighbour order, i.e. the same f32
 // expression trees as the CPU loops; atan2 is evaluated in f64 and rounded once.
 #include "tdv_internal.hpp"
@@ -42,11 +37,6 @@
 namespace tdv {
 
 constexpr int KN_BLOCK = 256;
-constexpr int KN_CH = 8;
-constexpr int KN_PB = 8;
-constexpr int KN_MAXSPLIT = 8;
-
-__device__ __forceinline__ bool lex_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
 // ------------------------------------------------------------------ spatial sort
 __global__ __launch_bounds__(256)
@@ -159,148 +149,6 @@ __device__ __forceinline__ float box_lower_bound(const float* __restrict__ box, 
     return g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);
 }
 
-// chunk visited at position v of the inside-out order centred at chunk cc (bijection onto [0, n_chunks))
-__device__ __forceinline__ int visit_chunk(int v, int cc, int n_chunks) {
-    const int L = cc, R = n_chunks - 1 - cc;
-    const int m = min(L, R);
-    if (v <= 2 * m) { int k = (v + 1) >> 1; return (v & 1) ? cc + k : cc - k; }
-    return R > L ? cc + (v - m) : cc - (v - m);
-}
-
-// ------------------------------------------------------------------ register-resident top-k (k <= 32)
-template <int K>
-__device__ __forceinline__ void reg_insert(float (&Ld)[K], int (&Li)[K], float nd, int ni) {
-    bool lt_cur = lex_less(nd, ni, Ld[K - 1], Li[K - 1]);
-#pragma unroll
-    for (int e = K - 1; e >= 1; --e) {
-        bool lt_prev = lex_less(nd, ni, Ld[e - 1], Li[e - 1]);
-        float d_keep = lt_cur ? nd : Ld[e];
-        int i_keep = lt_cur ? ni : Li[e];
-        Ld[e] = lt_prev ? Ld[e - 1] : d_keep;
-        Li[e] = lt_prev ? Li[e - 1] : i_keep;
-        lt_cur = lt_prev;
-    }
-    Ld[0] = lt_cur ? nd : Ld[0];
-    Li[0] = lt_cur ? ni : Li[0];
-}
-
-template <int K>
-__device__ __forceinline__ void reg_merge(float (&Ld)[K], int (&Li)[K], float (&pd)[KN_PB], int (&pi)[KN_PB],
-                                          int k, int& cnt, int& pcnt, float bound0, float& bound) {
-    int maxp = pcnt;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxp = max(maxp, __shfl_xor(maxp, off, 64));
-#pragma unroll
-    for (int s = 0; s < KN_PB; ++s) {
-        if (s < maxp) {  // wave-uniform
-            float nd = s < pcnt ? pd[s] : INFINITY;
-            int ni = s < pcnt ? pi[s] : INT_MAX;
-            reg_insert<K>(Ld, Li, nd, ni);
-        }
-    }
-    cnt = min(k, cnt + pcnt);
-    pcnt = 0;
-    if (k < K) {
-#pragma unroll
-        for (int e = 0; e < K; ++e) if (e >= k) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
-    }
-    float kth = Ld[K - 1];
-    if (k < K) {
-#pragma unroll
-        for (int e = 0; e < K; ++e) if (e == k - 1) kth = Ld[e];
-    }
-    // inclusive bound: an equal-d2 candidate with a smaller original index must still get in
-    bound = (cnt == k) ? fminf(bound0, kth) : bound0;
-}
-
-// out lists: element e of sorted query position i in split s at [(s*k + e) * nq_pad + i]; counts at [s*nq_pad + i]
-template <int K>
-__global__ __launch_bounds__(KN_BLOCK, 4)   // 4 waves per SIMD: keeps the K = 30 instance within 128 VGPRs
-void k_topk_scan_reg(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                     const int* __restrict__ orig, int nq, int nq_pad, int n_chunks16, int n_super, int nsplit, int k, float bound0,
-                     const float* __restrict__ cbox, const float* __restrict__ sbox, int prune,
-                     const int* __restrict__ qsel, int nsel,   // optional: the queries are sorted positions qsel[0..nsel)
-                     float* __restrict__ out_d, int* __restrict__ out_i, int* __restrict__ out_cnt) {
-    const int split = blockIdx.y;
-    const int qi = blockIdx.x * KN_BLOCK + threadIdx.x;
-    const int nqq = qsel ? nsel : nq;                       // number of queries of this launch
-    const int qslot = min(qi, nqq - 1);
-    const int qc = qsel ? qsel[qslot] : qslot;               // sorted position of this lane's query
-    const float qx = sx[qc], qy = sy[qc], qz = sz[qc];
-    const int mid = min(blockIdx.x * KN_BLOCK + KN_BLOCK / 2, nqq - 1);
-    const int cc = min((qsel ? qsel[mid] : mid) / 256, n_super - 1);   // the workgroup's own super-chunk
-    float Ld[K]; int Li[K];
-#pragma unroll
-    for (int e = 0; e < K; ++e) { Ld[e] = INFINITY; Li[e] = INT_MAX; }
-    float pd[KN_PB]; int pi[KN_PB];
-#pragma unroll
-    for (int s = 0; s < KN_PB; ++s) { pd[s] = INFINITY; pi[s] = INT_MAX; }
-    int cnt = 0, pcnt = 0;
-    float bound = bound0;
-    // wave query box and the wave's largest bound (refreshed after every merge) for the exact box pruning
-    float qmin[3] = {qx, qy, qz}, qmax[3] = {qx, qy, qz};
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { qmin[a] = fminf(qmin[a], __shfl_xor(qmin[a], off, 64)); qmax[a] = fmaxf(qmax[a], __shfl_xor(qmax[a], off, 64)); }
-    float Bmax = bound0;
-    for (int vs = split; vs < n_super; vs += nsplit) {
-        const int u = visit_chunk(vs, cc, n_super);   // super-chunks (256 targets) inside-out from the workgroup's own
-        if (prune && !__any(box_lower_bound(sbox, n_super, u, qmin, qmax) <= Bmax)) continue;
-        const int c16_end = min(n_chunks16, u * 16 + 16);
-        for (int c16 = u * 16; c16 < c16_end; ++c16) {
-            if (prune && !__any(box_lower_bound(cbox, n_chunks16, c16, qmin, qmax) <= Bmax)) continue;
-#pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                const int j = c16 * 16 + h * KN_CH;
-                float d2[KN_CH];
-#pragma unroll
-                for (int t = 0; t < KN_CH; ++t) {
-                    float dx = sx[j + t] - qx, dy = sy[j + t] - qy, dz = sz[j + t] - qz;   // (points[i] - query)
-                    d2[t] = dx * dx + (dy * dy + dz * dz);
-                }
-                float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
-                if (!__any(m <= bound)) continue;
-                // slow path: make room ONCE per chunk (a single merge site keeps the 8 appends statically indexed)
-                int nacc = 0;
-#pragma unroll
-                for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
-                if (__any(pcnt + nacc > KN_PB)) {
-                    reg_merge<K>(Ld, Li, pd, pi, k, cnt, pcnt, bound0, bound);
-                    Bmax = bound;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) Bmax = fmaxf(Bmax, __shfl_xor(Bmax, off, 64));
-                }
-#pragma unroll
-                for (int t = 0; t < KN_CH; ++t) {
-                    // padding targets (j + t >= nq, d2 = +inf) are never candidates; the bound only tightens, so what
-                    // is refused now could never enter the list
-                    const bool acc = (j + t < nq) && d2[t] <= bound;
-                    if (__any(acc)) {
-                        const int oi = orig[j + t];
-#pragma unroll
-                        for (int s = KN_PB - 1; s >= 1; --s) { pd[s] = acc ? pd[s - 1] : pd[s]; pi[s] = acc ? pi[s - 1] : pi[s]; }
-                        pd[0] = acc ? d2[t] : pd[0];
-                        pi[0] = acc ? oi : pi[0];
-                        pcnt += acc ? 1 : 0;
-                    }
-                }
-            }
-        }
-    }
-    if (__any(pcnt > 0)) reg_merge<K>(Ld, Li, pd, pi, k, cnt, pcnt, bound0, bound);
-    if (qi < nq_pad) {
-        out_cnt[(size_t)split * nq_pad + qi] = cnt;
-#pragma unroll
-        for (int e = 0; e < K; ++e) {
-            if (e < k) {
-                out_d[((size_t)split * k + e) * nq_pad + qi] = Ld[e];
-                out_i[((size_t)split * k + e) * nq_pad + qi] = Li[e];
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ two-phase kNN: window bound -> collect scan -> select
 // Phase A: an upper bound on each query's k-th neighbour distance from a small window around its own position
 // on the Morton curve (a subset of the cloud, so its k-th smallest distance can only be >= the true one).
@@ -347,303 +195,143 @@ void k_window_bound(const float* __restrict__ sx, const float* __restrict__ sy, 
     if (slot < nqq) bound[slot] = kth;   // +inf when the window holds fewer than k points
 }
 
-// Phase B: the full brute-force scan with a FIXED per-query bound and no selection state in the loop:
-// two queries per lane, 16 targets per scalar-load step (the ICP scan's shape).  Every target with d2 <= bound is
-// appended to the query's candidate row (64-bit key = d2 bits : original index; order in the row is irrelevant).
-constexpr int CS_SPL = 2;
-constexpr int CS_CH = 16;
-__global__ __launch_bounds__(KN_BLOCK)
-void k_collect_scan(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                    const int* __restrict__ orig, int n, int n_chunks, int n_super, int supers_per_split,
-                    const float* __restrict__ cbox, const float* __restrict__ sbox, int prune,
-                    const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, int cap,
-                    int* __restrict__ cnt, unsigned long long* __restrict__ cand) {
-    const int split = blockIdx.y;
-    const int u0 = split * supers_per_split, u1 = min(n_super, u0 + supers_per_split);
-    float qx[CS_SPL], qy[CS_SPL], qz[CS_SPL], B[CS_SPL];
-    int slot[CS_SPL];
-#pragma unroll
-    for (int s = 0; s < CS_SPL; ++s) {
-        slot[s] = blockIdx.x * (KN_BLOCK * CS_SPL) + s * KN_BLOCK + threadIdx.x;
-        const int sl = min(slot[s], nqq - 1);
-        const int sp = qsel ? qsel[sl] : sl;
-        qx[s] = sx[sp]; qy[s] = sy[sp]; qz[s] = sz[sp];
-        B[s] = slot[s] < nqq ? bound[sl] : -1.f;   // padding lanes never accept
-    }
-    // the wave's query box and largest bound (padding lanes duplicate a live query, their bound is -1)
-    float qmin[3] = {fminf(qx[0], qx[1]), fminf(qy[0], qy[1]), fminf(qz[0], qz[1])};
-    float qmax[3] = {fmaxf(qx[0], qx[1]), fmaxf(qy[0], qy[1]), fmaxf(qz[0], qz[1])};
-    float Bmax = fmaxf(B[0], B[1]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { qmin[a] = fminf(qmin[a], __shfl_xor(qmin[a], off, 64)); qmax[a] = fmaxf(qmax[a], __shfl_xor(qmax[a], off, 64)); }
-        Bmax = fmaxf(Bmax, __shfl_xor(Bmax, off, 64));
-    }
-    for (int u = u0; u < u1; ++u) {
-        if (prune && !__any(box_lower_bound(sbox, n_super, u, qmin, qmax) <= Bmax)) continue;   // 256 targets skipped
-        const int cend = min(n_chunks, u * 16 + 16);
-        for (int c = u * 16; c < cend; ++c) {
-            if (prune && !__any(box_lower_bound(cbox, n_chunks, c, qmin, qmax) <= Bmax)) continue;   // 16 targets skipped
-            const int j = c * CS_CH;
-            float tx[CS_CH], ty[CS_CH], tz[CS_CH];   // wave-uniform: three s_load_dwordx16
-#pragma unroll
-            for (int t = 0; t < CS_CH; ++t) { tx[t] = sx[j + t]; ty[t] = sy[j + t]; tz[t] = sz[j + t]; }
-            bool hit = false;
-#pragma unroll
-            for (int s = 0; s < CS_SPL; ++s) {
-                float m = INFINITY;
-#pragma unroll
-                for (int t = 0; t < CS_CH; ++t) {
-                    float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];   // (points[i] - query)
-                    float d2 = dx * dx + (dy * dy + dz * dz);
-                    m = fminf(m, d2);
-                }
-                hit |= m <= B[s];
-            }
-            if (!__any(hit)) continue;
-#pragma unroll
-            for (int s = 0; s < CS_SPL; ++s) {
-#pragma unroll
-                for (int t = 0; t < CS_CH; ++t) {
-                    float dx = tx[t] - qx[s], dy = ty[t] - qy[s], dz = tz[t] - qz[s];
-                    float d2 = dx * dx + (dy * dy + dz * dz);
-                    const bool acc = (j + t < n) && d2 <= B[s];
-                    if (__any(acc)) {
-                        const int oi = orig[j + t];
-                        if (acc) {
-                            int at = atomicAdd(&cnt[slot[s]], 1);
-                            if (at < cap) cand[(size_t)slot[s] * cap + at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)oi;
-                        }
-                    }
-                }
-            }
-        }
-    }
+// ------------------------------------------------------------------ one wave per query: walk, collect, select
+constexpr int QW_WAVES = KN_BLOCK / 64;
+
+__device__ __forceinline__ bool key_less(unsigned ahi, unsigned alo, unsigned bhi, unsigned blo) {
+    return ahi < bhi || (ahi == bhi && alo < blo);
 }
 
-// Phase C: exact top-k of a query's candidates in (d2, idx) order; the final list goes to lists[r*n_pad + i], cnt_out[i]
-// (by original index).  overflow[slot] = 1 when the row was too small (the caller re-runs those queries with
-// bound_next, the k-th smallest of the cap candidates it did keep: a valid, tighter bound).
-// One WAVE per query: the row (<= 128 keys, 64-bit = d2 bits : original index, so unsigned order is (d2, idx) order)
-// is sorted by a bitonic network across the lanes, two keys per lane.
-__device__ __forceinline__ void cmpx_keys(unsigned& hi, unsigned& lo, unsigned phi, unsigned plo, bool keep_min) {
-    const bool p_less = (phi < hi) || (phi == hi && plo < lo);
-    const bool take = keep_min ? p_less : !p_less;   // keys are distinct (distinct indices) except the ~0 padding
-    hi = take ? phi : hi; lo = take ? plo : lo;
-}
-constexpr int SEL_WAVES = KN_BLOCK / 64;
-__global__ __launch_bounds__(KN_BLOCK)
-void k_select_topk(const int* __restrict__ orig, const int* __restrict__ qsel, int nqq, int k, int cap, int n_pad,
-                   const int* __restrict__ cnt, const unsigned long long* __restrict__ cand,
-                   int* __restrict__ lists, int* __restrict__ cnt_out, int* __restrict__ overflow, float* __restrict__ bound_next) {
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * SEL_WAVES + (threadIdx.x >> 6);
-    if (slot >= nqq) return;   // wave-uniform
-    const int m_all = cnt[slot];
-    const int m = min(m_all, cap);
-    unsigned hi[2], lo[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int e = r * 64 + lane;
-        const unsigned long long key = e < m ? cand[(size_t)slot * cap + e] : ~0ull;
-        hi[r] = (unsigned)(key >> 32); lo[r] = (unsigned)key;
-    }
-    // element index i = r*64 + lane; ascending bitonic sort of 128 (or of the first 64 when the row is short)
-    const int nsort = m > 64 ? 128 : 64;   // wave-uniform
+// ascending bitonic sort of the first nsort (64, 128, ... 64*R; wave-uniform) keys of a wave; element i = r*64 + lane.
+// Keys are distinct (distinct indices) except the ~0 padding, which sorts last.
+template <int R>
+__device__ __forceinline__ void wave_sort_keys(unsigned (&hi)[R], unsigned (&lo)[R], int nsort, int lane) {
     for (int kk = 2; kk <= nsort; kk <<= 1) {
         for (int j = kk >> 1; j >= 1; j >>= 1) {
-            if (j == 64) {   // partner is the lane's other key (only in the 128 sort, kk == 128: ascending everywhere)
-                const bool swap = (hi[1] < hi[0]) || (hi[1] == hi[0] && lo[1] < lo[0]);
-                const unsigned th = hi[0], tl = lo[0];
-                hi[0] = swap ? hi[1] : hi[0]; lo[0] = swap ? lo[1] : lo[0];
-                hi[1] = swap ? th : hi[1]; lo[1] = swap ? tl : lo[1];
+            if (j >= 64) {   // partner is another key of the same lane
+#pragma unroll
+                for (int dr = R / 2; dr >= 1; dr >>= 1) {
+                    if (j != dr * 64) continue;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        if ((r & dr) != 0 || (r + dr) * 64 >= nsort) continue;
+                        const bool asc = ((r * 64 + lane) & kk) == 0;
+                        const bool hi_less = key_less(hi[r + dr], lo[r + dr], hi[r], lo[r]);
+                        const bool swap = asc ? hi_less : !hi_less;
+                        const unsigned th = hi[r], tl = lo[r];
+                        hi[r] = swap ? hi[r + dr] : hi[r]; lo[r] = swap ? lo[r + dr] : lo[r];
+                        hi[r + dr] = swap ? th : hi[r + dr]; lo[r + dr] = swap ? tl : lo[r + dr];
+                    }
+                }
             } else {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if (r == 1 && nsort == 64) continue;
+                for (int r = 0; r < R; ++r) {
+                    if (r * 64 >= nsort) continue;
                     const int i = r * 64 + lane;
                     const unsigned phi = __shfl_xor(hi[r], j, 64), plo = __shfl_xor(lo[r], j, 64);
-                    const bool asc = (i & kk) == 0;
-                    const bool lower = (i & j) == 0;
-                    cmpx_keys(hi[r], lo[r], phi, plo, asc == lower);
+                    const bool keep_min = ((i & kk) == 0) == ((i & j) == 0);
+                    const bool p_less = key_less(phi, plo, hi[r], lo[r]);
+                    const bool take = keep_min ? p_less : !p_less;
+                    hi[r] = take ? phi : hi[r]; lo[r] = take ? plo : lo[r];
                 }
             }
         }
     }
-    const int i0 = orig[qsel ? qsel[slot] : slot];
-    const int c = min(k, m);
-    if (lane < c) lists[(size_t)lane * n_pad + i0] = (int)lo[0];   // k <= 32: the output ranks sit in the first key of lanes 0..k-1
-    const unsigned kbits = __shfl(hi[0], k - 1, 64);
-    const float kth = kbits == 0xffffffffu ? INFINITY : __uint_as_float(kbits);   // padding: fewer than k candidates
-    if (lane == 0) {
-        cnt_out[i0] = c;
-        overflow[slot] = m_all > cap ? 1 : 0;
-        bound_next[slot] = kth;
-    }
-}
-__global__ void k_compact_overflow(const int* __restrict__ flag, const int* __restrict__ pos, const int* __restrict__ qsel, int nqq,
-                                   const float* __restrict__ bound_next, int* __restrict__ qsel2, float* __restrict__ bound2) {
-    int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot < nqq && flag[slot]) { qsel2[pos[slot]] = qsel ? qsel[slot] : slot; bound2[pos[slot]] = bound_next[slot]; }  // ascending sorted positions
 }
 
-// ------------------------------------------------------------------ global-list top-k (any k; FPFH radius search)
-// Sorted per-lane list with elements at base[e * stride] in global memory; pending queue in LDS.
-__device__ __forceinline__ void glob_merge(float* __restrict__ ld, int* __restrict__ li, size_t stride,
-                                           const float* __restrict__ pd_lds, const int* __restrict__ pi_lds,
-                                           int k, int& cnt_list, int& pcnt, float bound0, float& bound) {
-    float pd[KN_PB]; int pi[KN_PB]; int prank[KN_PB];
+__device__ __forceinline__ int sort_span(int m) { int s = 64; while (s < m) s <<= 1; return s; }
+
+// row[0..m) -> registers, sorted ascending
+template <int R>
+__device__ __forceinline__ void load_sort_row(const unsigned long long* row, int m, int lane, unsigned (&hi)[R], unsigned (&lo)[R]) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row was written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int p = 0; p < KN_PB; ++p) {
-        bool v = p < pcnt;
-        pd[p] = v ? pd_lds[p * KN_BLOCK] : INFINITY;
-        pi[p] = v ? pi_lds[p * KN_BLOCK] : INT_MAX;
+    for (int r = 0; r < R; ++r) {
+        const int e = r * 64 + lane;
+        const unsigned long long key = e < m ? row[e] : ~0ull;
+        hi[r] = (unsigned)(key >> 32); lo[r] = (unsigned)key;
     }
-#pragma unroll
-    for (int a = 0; a < KN_PB; ++a) {
-        int r = 0;
-#pragma unroll
-        for (int b = 0; b < KN_PB; ++b) r += (b != a && lex_less(pd[b], pi[b], pd[a], pi[a])) ? 1 : 0;
-        prank[a] = r;
-    }
-    int maxc = cnt_list;  // wave-uniform trip count: the longest list in the wave
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxc = max(maxc, __shfl_xor(maxc, off, 64));
-    // descending e: an entry only moves right (new position >= e), onto slots already vacated
-    for (int e = maxc - 1; e >= 0; --e) {
-        bool valid = e < cnt_list;
-        float d = valid ? ld[e * stride] : INFINITY;
-        int i = valid ? li[e * stride] : INT_MAX;
-        int shift = 0;
-#pragma unroll
-        for (int p = 0; p < KN_PB; ++p) {
-            bool lt = lex_less(pd[p], pi[p], d, i);
-            shift += lt ? 1 : 0;
-            prank[p] += (valid && !lt) ? 1 : 0;
-        }
-        int np = e + shift;
-        if (valid && shift > 0 && np < k) { ld[np * stride] = d; li[np * stride] = i; }
-    }
-#pragma unroll
-    for (int p = 0; p < KN_PB; ++p) {
-        if (p < pcnt && prank[p] < k) { ld[prank[p] * stride] = pd[p]; li[prank[p] * stride] = pi[p]; }
-    }
-    cnt_list = min(k, cnt_list + pcnt);
-    pcnt = 0;
-    if (cnt_list == k) bound = fminf(bound0, ld[(k - 1) * stride]);
+    wave_sort_keys<R>(hi, lo, sort_span(m), lane);
 }
 
+// lists[r * n_pad + original index] = the first min(k, found) targets in (d2, idx) order with d2 <= bound
+// (bound = bound[slot] if given, else bound0), cnt_out[original index] = their number.  Requires k <= 64*R - 64.
+template <int R>
 __global__ __launch_bounds__(KN_BLOCK)
-void k_topk_scan_glob(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                      const int* __restrict__ orig, int nq, int nq_pad, int n_chunks16, int n_super, int nsplit, int k, float bound0,
-                      const float* __restrict__ cbox, const float* __restrict__ sbox, int prune,
-                      float* __restrict__ out_d, int* __restrict__ out_i, int* __restrict__ out_cnt) {
-    __shared__ float s_pd[KN_PB][KN_BLOCK];
-    __shared__ int s_pi[KN_PB][KN_BLOCK];
-    const int tid = threadIdx.x;
-    const int split = blockIdx.y;
-    const int qi = blockIdx.x * KN_BLOCK + tid;
-    const int qc = min(qi, nq - 1);
-    const float qx = sx[qc], qy = sy[qc], qz = sz[qc];
-    const int cc = min((blockIdx.x * KN_BLOCK + KN_BLOCK / 2) / 256, n_super - 1);
-    float* ld = out_d + (size_t)split * k * nq_pad + qi;
-    int* li = out_i + (size_t)split * k * nq_pad + qi;
-    const size_t stride = (size_t)nq_pad;
-    const float* pdl = &s_pd[0][tid];
-    const int* pil = &s_pi[0][tid];
-    int cnt_list = 0, pcnt = 0;
-    float bound = bound0;
-    float qmin[3] = {qx, qy, qz}, qmax[3] = {qx, qy, qz};
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { qmin[a] = fminf(qmin[a], __shfl_xor(qmin[a], off, 64)); qmax[a] = fmaxf(qmax[a], __shfl_xor(qmax[a], off, 64)); }
-    float Bmax = bound0;
-    for (int vs = split; vs < n_super; vs += nsplit) {
-        const int u = visit_chunk(vs, cc, n_super);
-        if (prune && !__any(box_lower_bound(sbox, n_super, u, qmin, qmax) <= Bmax)) continue;
-        const int c16_end = min(n_chunks16, u * 16 + 16);
-        for (int c16 = u * 16; c16 < c16_end; ++c16) {
-            if (prune && !__any(box_lower_bound(cbox, n_chunks16, c16, qmin, qmax) <= Bmax)) continue;
+void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                  const int* __restrict__ orig, int n, int n_super, const float* __restrict__ sbox,
+                  const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, float bound0, int seed_own,
+                  int k, int n_pad, int* __restrict__ lists, int* __restrict__ cnt_out) {
+    constexpr int ROW = 64 * R;
+    __shared__ unsigned long long rows[QW_WAVES][ROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = blockIdx.x * QW_WAVES + wave;
+    if (slot >= nqq) return;   // wave-uniform; no block-level barrier below
+    unsigned long long* row = rows[wave];
+    const int sp = qsel ? qsel[slot] : slot;
+    const float qx = sx[sp], qy = sy[sp], qz = sz[sp];
+    const float qp[3] = {qx, qy, qz};
+    float B = bound ? bound[slot] : bound0;   // wave-uniform; only ever decreases
+    int wcnt = 0;                             // wave-uniform fill of the row
+
+    auto eval_super = [&](int su) {
 #pragma unroll 1
-            for (int h = 0; h < 2; ++h) {
-                const int j = c16 * 16 + h * KN_CH;
-                float d2[KN_CH];
+        for (int step = 0; step < 4; ++step) {
+            const int pidx = su * 256 + step * 64 + lane;   // arrays are padded with +inf to a multiple of 256
+            float dx = sx[pidx] - qx, dy = sy[pidx] - qy, dz = sz[pidx] - qz;   // (points[i] - query)
+            float d2 = dx * dx + (dy * dy + dz * dz);
+            bool acc = pidx < n && d2 <= B;
+            unsigned long long am = __ballot(acc);
+            if (!am) continue;
+            if (wcnt + __popcll(am) > ROW) {
+                // the row cannot take them all: keep the best k seen so far (wcnt > ROW - 64 >= k), tighten the bound
+                unsigned hi[R], lo[R];
+                load_sort_row<R>(row, wcnt, lane, hi, lo);
+                unsigned kb = 0;
 #pragma unroll
-                for (int t = 0; t < KN_CH; ++t) {
-                    float dx = sx[j + t] - qx, dy = sy[j + t] - qy, dz = sz[j + t] - qz;
-                    d2[t] = dx * dx + (dy * dy + dz * dz);
+                for (int r = 0; r < R; ++r) {
+                    const int e = r * 64 + lane;
+                    if (e < k) row[e] = ((unsigned long long)hi[r] << 32) | lo[r];
+                    if (r == ((k - 1) >> 6)) kb = __shfl(hi[r], (k - 1) & 63, 64);
                 }
-                float m = fminf(fminf(fminf(d2[0], d2[1]), fminf(d2[2], d2[3])), fminf(fminf(d2[4], d2[5]), fminf(d2[6], d2[7])));
-                if (!__any(m <= bound)) continue;
-                int nacc = 0;
-#pragma unroll
-                for (int t = 0; t < KN_CH; ++t) nacc += (d2[t] <= bound) ? 1 : 0;
-                if (__any(pcnt + nacc > KN_PB)) {
-                    glob_merge(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
-                    Bmax = bound;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) Bmax = fmaxf(Bmax, __shfl_xor(Bmax, off, 64));
-                }
-#pragma unroll
-                for (int t = 0; t < KN_CH; ++t) {
-                    if ((j + t < nq) && d2[t] <= bound) { s_pd[pcnt][tid] = d2[t]; s_pi[pcnt][tid] = orig[j + t]; pcnt++; }  // never a padding target
-                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                wcnt = k;
+                B = __uint_as_float(kb);
+                acc = acc && d2 <= B;
+                am = __ballot(acc);
+                if (!am) continue;
             }
+            const int at = wcnt + __popcll(am & ((1ull << lane) - 1ull));
+            if (acc) row[at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig[pidx];
+            wcnt += __popcll(am);
         }
-    }
-    if (__any(pcnt > 0)) glob_merge(ld, li, stride, pdl, pil, k, cnt_list, pcnt, bound0, bound);
-    if (qi < nq_pad) out_cnt[(size_t)split * nq_pad + qi] = cnt_list;
-}
+    };
 
-// k-way merge of the per-split sorted lists of one query; calls emit(rank, d2, idx) in order.
-template <class F>
-__device__ __forceinline__ int merge_splits(const float* __restrict__ pd, const int* __restrict__ pi,
-                                            const int* __restrict__ pc, int nsplit, int k, int nq_pad, int qi, F emit) {
-    float hd[KN_MAXSPLIT]; int hi[KN_MAXSPLIT]; int pos[KN_MAXSPLIT]; int cn[KN_MAXSPLIT];
-#pragma unroll
-    for (int s = 0; s < KN_MAXSPLIT; ++s) {
-        pos[s] = 0; cn[s] = s < nsplit ? pc[(size_t)s * nq_pad + qi] : 0;
-        bool v = cn[s] > 0;
-        hd[s] = v ? pd[((size_t)s * k) * nq_pad + qi] : INFINITY;
-        hi[s] = v ? pi[((size_t)s * k) * nq_pad + qi] : INT_MAX;
-    }
-    int out = 0;
-    for (; out < k; ++out) {
-        int bs = -1; float bd = INFINITY; int bi = INT_MAX;
-#pragma unroll
-        for (int s = 0; s < KN_MAXSPLIT; ++s) {
-            bool v = pos[s] < cn[s];
-            if (v && (bs < 0 || lex_less(hd[s], hi[s], bd, bi))) { bd = hd[s]; bi = hi[s]; bs = s; }
-        }
-        if (bs < 0) break;
-        emit(out, bd, bi);
-#pragma unroll
-        for (int s = 0; s < KN_MAXSPLIT; ++s) {
-            if (s == bs) {
-                pos[s]++;
-                bool v = pos[s] < cn[s];
-                hd[s] = v ? pd[((size_t)s * k + pos[s]) * nq_pad + qi] : INFINITY;
-                hi[s] = v ? pi[((size_t)s * k + pos[s]) * nq_pad + qi] : INT_MAX;
-            }
+    const int own = sp >> 8;
+    if (seed_own) eval_super(own);   // unbounded start: the query's own run brings the bound down first
+    for (int base = 0; base < n_super; base += 64) {
+        const int u = base + lane;
+        const float lb = u < n_super ? box_lower_bound(sbox, n_super, u, qp, qp) : INFINITY;
+        unsigned long long smask = __ballot(u < n_super && lb <= B && !(seed_own && u == own));
+        while (smask) {
+            const int b = __ffsll((long long)smask) - 1;
+            smask &= smask - 1;
+            if (__shfl(lb, b, 64) > B) continue;   // the bound may have dropped since the test
+            eval_super(base + b);
         }
     }
-    return out;
-}
-
-// ------------------------------------------------------------------ list finishing (shared by kNN and radius)
-// k-way merge of the per-split lists of each query of the launch (all sorted positions, or the subset qsel);
-// the final list is stored BY ORIGINAL POINT INDEX: lists[r * n_pad + i], cnt[i].
-__global__ __launch_bounds__(KN_BLOCK)
-void k_lists_finish(const int* __restrict__ orig, const int* __restrict__ qsel, int nqq, int nq_pad, int n_pad, int k, int nsplit,
-                    const float* __restrict__ pd, const int* __restrict__ pi, const int* __restrict__ pc,
-                    int* __restrict__ lists, int* __restrict__ cnt) {
-    const int slot = blockIdx.x * KN_BLOCK + threadIdx.x;
-    if (slot >= nqq) return;
-    const int i = orig[qsel ? qsel[slot] : slot];
-    int c = merge_splits(pd, pi, pc, nsplit, k, nq_pad, slot, [&](int r, float, int idx) { lists[(size_t)r * n_pad + i] = idx; });
-    cnt[i] = c;
+    unsigned hi[R], lo[R];
+    load_sort_row<R>(row, wcnt, lane, hi, lo);
+    const int i0 = orig[sp];
+    const int c = min(k, wcnt);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int e = r * 64 + lane;
+        if (e < c) lists[(size_t)e * n_pad + i0] = (int)lo[r];
+    }
+    if (lane == 0) cnt_out[i0] = c;
 }
 
 // ------------------------------------------------------------------ normals (registration.cpp:105-130)
@@ -776,17 +464,7 @@ void k_fpfh(const float* __restrict__ xyz, int n, int n_pad, const int* __restri
 
 namespace {
 
-struct ScanPlan { int n_pad, nt_pad, n_chunks, blocks_x, nsplit; };
-
-int pick_nsplit(int blocks_x, int n_super) {
-    // interleaved splits over the 256-target super-chunks: enough workgroups for a short tail (>= ~6k),
-    // each split keeping >= 2 super-chunks
-    int want = (6144 + blocks_x - 1) / blocks_x;
-    int max_split = std::max(1, n_super / 2);
-    int nsplit = std::max(1, std::min(std::min(want, max_split), KN_MAXSPLIT));
-    if (const char* e = getenv("TDV_KNN_NSPLIT")) nsplit = std::max(1, std::min(std::min(atoi(e), max_split), KN_MAXSPLIT));  // tuning knob
-    return nsplit;
-}
+struct ScanPlan { int n_pad, nt_pad, n_chunks, blocks_x; };
 
 ScanPlan make_scan_plan(int n) {
     ScanPlan p;
@@ -794,7 +472,6 @@ ScanPlan make_scan_plan(int n) {
     p.nt_pad = (int)align_up((size_t)n, 16);
     p.n_chunks = p.nt_pad / 16;          // 16-target chunks
     p.blocks_x = p.n_pad / KN_BLOCK;
-    p.nsplit = pick_nsplit(p.blocks_x, (p.n_chunks + 15) / 16);
     return p;
 }
 
@@ -846,111 +523,49 @@ int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out
 
 namespace {
 
-// Scan + per-split lists + merge into lists[r * p.n_pad + original index] / cnt[original index].
-// qsel == nullptr: all n queries; else the nsel sorted positions in qsel (device).
-int scan_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, float bound0, int timer,
-                  const int* qsel, int nsel, int* lists, int* cnt) {
+constexpr int CS_HALF_WINDOW = 384;
+
+// One k_query_wave launch: lists[r * p.n_pad + original index] / cnt[original index] for all n queries
+// (qsel == nullptr) or for the nsel sorted positions in qsel (device).
+int query_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, const float* bound, float bound0, int seed_own,
+                   int timer, const int* qsel, int nsel, int* lists, int* cnt) {
     const int nqq = qsel ? nsel : n;
     if (nqq <= 0) return TDV_OK;
-    const int nq_pad = (int)align_up((size_t)nqq, KN_BLOCK);
-    const int blocks_x = nq_pad / KN_BLOCK;
-    const int nsplit = qsel ? pick_nsplit(blocks_x, so.n_super) : p.nsplit;
-    static const int prune = getenv("TDV_NO_PRUNE") ? 0 : 1;   // A/B knob: 0 = evaluate every pair (pure brute force)
-    float* pd; int *pi, *pc;
-    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * k * nq_pad, &pd));
-    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * k * nq_pad, &pi));
-    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * nq_pad, &pc));
     hipStream_t s = ctx->stream;
-    {
-        ScopedTimer tm(ctx, timer);
-        dim3 grid(blocks_x, nsplit);
-#define TDV_REG_SCAN(KK) k_topk_scan_reg<KK><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, so.n_chunks16, so.n_super, nsplit, k, bound0, \
-                                                                     so.cbox, so.sbox, prune, qsel, nsel, pd, pi, pc)
-        if (k <= 8) TDV_REG_SCAN(8);
-        else if (k <= 16) TDV_REG_SCAN(16);
-        else if (k <= 30) TDV_REG_SCAN(30);
-        else if (k <= 32) TDV_REG_SCAN(32);
-        else {
-            if (qsel) return TDV_ERR_INTERNAL;  // subset scans are only issued for k <= 32
-            k_topk_scan_glob<<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, nq_pad, so.n_chunks16, so.n_super, nsplit, k, bound0,
-                                                       so.cbox, so.sbox, prune, pd, pi, pc);
-        }
-#undef TDV_REG_SCAN
-    }
-    k_lists_finish<<<blocks_x, KN_BLOCK, 0, s>>>(so.orig, qsel, nqq, nq_pad, p.n_pad, k, nsplit, pd, pi, pc, lists, cnt);
+    const unsigned grid = (unsigned)((nqq + QW_WAVES - 1) / QW_WAVES);
+    ScopedTimer tm(ctx, timer);
+#define TDV_QW(RR) k_query_wave<RR><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_super, so.sbox, qsel, nqq, bound, bound0, \
+                                                            seed_own, k, p.n_pad, lists, cnt)
+    if (k <= 64) TDV_QW(2);
+    else if (k <= 192) TDV_QW(4);
+    else if (k <= 448) TDV_QW(8);
+    else return TDV_ERR_BAD_ARG;
+#undef TDV_QW
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
 
-}  // namespace
+// radius search: every target with d2 <= r2, the first k in (d2, idx) order
+int radius_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, float r2, int* lists, int* cnt) {
+    return query_to_lists(ctx, so, n, p, k, nullptr, r2, 0, TDV_TIMER_RADIUS, nullptr, 0, lists, cnt);
+}
 
-namespace {
-
-constexpr int CS_CAP = 128;       // candidate row per query (k <= 32): typical fill 30-70
-constexpr int CS_HALF_WINDOW = 384;
-
-// exact kNN lists (k <= 32) of all queries (qsel == nullptr) or of the subset qsel, by the two-phase scheme;
-// queries whose candidate row overflows (or whose window gave no finite bound) are redone by the streaming scan.
+// exact kNN lists of all queries (qsel == nullptr) or of the subset qsel
 int knn_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, const int* qsel, int nsel, int* lists, int* cnt) {
-    int nqq = qsel ? nsel : n;
+    const int nqq = qsel ? nsel : n;
     if (nqq <= 0) return TDV_OK;
+    if (k > 32) return query_to_lists(ctx, so, n, p, k, nullptr, INFINITY, 1, TDV_TIMER_KNN, qsel, nsel, lists, cnt);
     hipStream_t s = ctx->stream;
-    const int nq_pad = (int)align_up((size_t)nqq, KN_BLOCK * CS_SPL);
-    float *bound, *bnext, *bound2; int *ccnt, *ovf, *pos, *qselA, *qselB, *d_total; unsigned long long* cand;
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &bound));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &bnext));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &bound2));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &ccnt));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &ovf));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &pos));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &qselA));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad, &qselB));
-    TDV_TRY(ws_alloc(ctx, 1, &d_total));
-    TDV_TRY(ws_alloc(ctx, (size_t)nq_pad * CS_CAP, &cand));
-    TDV_TRY(pin_reserve(ctx, 64));
-    int* h_total = reinterpret_cast<int*>(ctx->pin);
-    static const int prune = getenv("TDV_NO_PRUNE") ? 0 : 1;   // A/B knob: 0 = evaluate every pair (pure brute force)
-    const int* cur_q = qsel;
-    float* cur_b = bound;
-    int* next_q = qselA;
-    {   // phase A: bounds from the local window
+    float* bound;
+    TDV_TRY(ws_alloc(ctx, align_up((size_t)nqq, KN_BLOCK), &bound));
+    {
         ScopedTimer tm(ctx, TDV_TIMER_KNN);
         const int qblocks = (nqq + KN_BLOCK - 1) / KN_BLOCK;
-#define TDV_WB(KK) k_window_bound<KK><<<qblocks, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, n, cur_q, nqq, k, CS_HALF_WINDOW, cur_b)
+#define TDV_WB(KK) k_window_bound<KK><<<qblocks, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, n, qsel, nqq, k, CS_HALF_WINDOW, bound)
         if (k <= 8) TDV_WB(8); else if (k <= 16) TDV_WB(16); else if (k <= 30) TDV_WB(30); else TDV_WB(32);
 #undef TDV_WB
     }
-    for (int round = 0; round < 8 && nqq > 0; ++round) {
-        const int qblocks = (nqq + KN_BLOCK - 1) / KN_BLOCK;
-        const int cblocks = (nqq + KN_BLOCK * CS_SPL - 1) / (KN_BLOCK * CS_SPL);
-        int want = (8192 + cblocks - 1) / cblocks;
-        int csplit = std::max(1, std::min(want, so.n_super));
-        int ups = (so.n_super + csplit - 1) / csplit;      // super-chunks per split
-        csplit = (so.n_super + ups - 1) / ups;
-        TDV_HIP(ctx, hipMemsetAsync(ccnt, 0, (size_t)nqq * 4, s));
-        {
-            ScopedTimer tm(ctx, TDV_TIMER_KNN);
-            k_collect_scan<<<dim3(cblocks, csplit), KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_chunks16, so.n_super, ups, so.cbox, so.sbox, prune,
-                                                                      cur_q, nqq, cur_b, CS_CAP, ccnt, cand);
-            static_assert(CS_CAP == 128, "k_select_topk sorts rows of at most 128 keys");
-            k_select_topk<<<(nqq + SEL_WAVES - 1) / SEL_WAVES, KN_BLOCK, 0, s>>>(so.orig, cur_q, nqq, k, CS_CAP, p.n_pad, ccnt, cand, lists, cnt, ovf, bnext);
-        }
-        TDV_CHECK_LAUNCH(ctx);
-        // queries whose candidate row overflowed go another round with the tightened bound
-        TDV_TRY(exclusive_scan_dev(ctx, ovf, nqq, pos, d_total));
-        float* nb = (cur_b == bound2) ? bound : bound2;
-        k_compact_overflow<<<qblocks, KN_BLOCK, 0, s>>>(ovf, pos, cur_q, nqq, bnext, next_q, nb);
-        TDV_CHECK_LAUNCH(ctx);
-        TDV_HIP(ctx, hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, s));
-        TDV_HIP(ctx, hipStreamSynchronize(s));
-        if (getenv("TDV_DEBUG")) fprintf(stderr, "[tdv] knn_to_lists: round %d queries=%d overflow=%d (k=%d)\n", round, nqq, *h_total, k);
-        nqq = *h_total;
-        cur_q = next_q; next_q = (next_q == qselA) ? qselB : qselA;
-        cur_b = nb;
-    }
-    // pathological leftovers (e.g. more than CS_CAP points at exactly the k-th distance): streaming scan
-    if (nqq > 0) TDV_TRY(scan_to_lists(ctx, so, n, p, k, INFINITY, TDV_TIMER_KNN, cur_q, nqq, lists, cnt));
-    return TDV_OK;
+    return query_to_lists(ctx, so, n, p, k, bound, 0.f, 0, TDV_TIMER_KNN, qsel, nsel, lists, cnt);
 }
 
 }  // namespace
@@ -964,9 +579,7 @@ int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* 
     TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
     TDV_TRY(ws_alloc(ctx, (size_t)kk * p.n_pad, &lists));
     TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
-    static const bool streaming_only = getenv("TDV_KNN_STREAMING") != nullptr;  // tuning / A-B knob
-    if (kk <= 32 && !streaming_only) TDV_TRY(knn_to_lists(ctx, so, n, p, kk, nullptr, 0, lists, cnt));
-    else TDV_TRY(scan_to_lists(ctx, so, n, p, kk, INFINITY, TDV_TIMER_KNN, nullptr, 0, lists, cnt));
+    TDV_TRY(knn_to_lists(ctx, so, n, p, kk, nullptr, 0, lists, cnt));
     k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, ctx->stream>>>(d_xyz, n, p.n_pad, kk, nullptr, nullptr, lists, cnt, d_normals, d_knn, k);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
@@ -996,7 +609,7 @@ int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, i
     TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
     TDV_TRY(ws_alloc(ctx, (size_t)FP_MAXNN * p.n_pad, &nbr));
     TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
-    TDV_TRY(scan_to_lists(ctx, so, n, p, FP_MAXNN, r2, TDV_TIMER_RADIUS, nullptr, 0, nbr, cnt));
+    TDV_TRY(radius_to_lists(ctx, so, n, p, FP_MAXNN, r2, nbr, cnt));
     return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, nbr, cnt, d_desc, d_nbr, d_nbr_cnt);
 }
 
@@ -1008,7 +621,7 @@ int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radiu
     if (!ctx || n < 0 || k <= 0 || k > 255 || (n > 0 && (!d_xyz || !d_normals || !d_desc))) return TDV_ERR_BAD_ARG;
     if (n == 0) return TDV_OK;
     const int kk = std::min(k, n);
-    if (kk > 32 || kk > FP_MAXNN) {  // subset scans use the register kernel (k <= 32): otherwise the two plain calls
+    if (kk > FP_MAXNN) {  // a radius list (cap 100) cannot serve as the kNN list: the two plain calls
         TDV_TRY(estimate_normals_dev(ctx, d_xyz, n, k, d_normals, nullptr));
         return compute_fpfh_dev(ctx, d_xyz, d_normals, n, radius, d_desc, nullptr, nullptr);
     }
@@ -1019,7 +632,7 @@ int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radiu
     TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
     TDV_TRY(ws_alloc(ctx, (size_t)FP_MAXNN * p.n_pad, &nbr));
     TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
-    TDV_TRY(scan_to_lists(ctx, so, n, p, FP_MAXNN, r2, TDV_TIMER_RADIUS, nullptr, 0, nbr, cnt));
+    TDV_TRY(radius_to_lists(ctx, so, n, p, FP_MAXNN, r2, nbr, cnt));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &flag));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &pos));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &qsel));
