@@ -11,19 +11,17 @@
 // reference's lists bit for bit, ties included:
 //   0. the cloud is sorted along a 30-bit Morton curve (bitonic sort shared with voxel.hip) and the bounding boxes
 //      of its 16- and 256-point runs are built once per cloud;
-//   1. k_window_bound (kNN, k <= 32): an upper bound on each query's k-th neighbour distance from a 768-point window
-//      around its own curve position (a subset of the cloud, so the bound can only be too large);
-//   2. k_query_wave: ONE WAVE PER QUERY.  The 256-point boxes are tested 64 per step (one per lane) against the
+//   1. k_query_wave: ONE WAVE PER QUERY.  The 256-point boxes are tested 64 per step (one per lane) against the
 //      query point and its bound; the targets of the boxes that pass are evaluated one per lane with coalesced
 //      loads; every target with d2 <= bound is appended to the query's row in LDS (ballot prefix: no atomics,
 //      deterministic order).  When the row fills, it is sorted in-wave (bitonic network on 64-bit keys
 //      d2 bits : original index, whose unsigned order is the reference's (d2, index) order), cut to the best k, and
 //      the bound drops to the k-th: exact for any number of ties.  At the end the row is sorted and its first k
-//      entries are the list.  kNN with k > 32 starts unbounded from the query's own 256-point run instead of step 1;
-//      the radius search (FPFH, cap 100) starts from r^2 and needs no step 1.
+//      entries are the list.  kNN starts unbounded: the query's 64 curve neighbours give the first bound, the rest of
+//      its own 256-point run follows, then the walk; the radius search (FPFH, cap 100) starts from r^2.
 // In the batched chain normals_fpfh_dev shares ONE radius search between normals and FPFH: a radius list is sorted
 // by (d2, idx), so its first k entries are the k nearest neighbours wherever it holds >= k; only the deficient
-// points go through steps 1-2 as a subset.
+// points go through the kNN search as a subset.
 // Per-point estimators run one lane per point with sequential sums in neighbour order, i.e. the same f32
 // expression trees as the CPU loops; atan2 is evaluated in f64 and rounded once.
 #include "tdv_internal.hpp"
@@ -149,52 +147,6 @@ __device__ __forceinline__ float box_lower_bound(const float* __restrict__ box, 
     return g[0] * g[0] + (g[1] * g[1] + g[2] * g[2]);
 }
 
-// ------------------------------------------------------------------ two-phase kNN: window bound -> collect scan -> select
-// Phase A: an upper bound on each query's k-th neighbour distance from a small window around its own position
-// on the Morton curve (a subset of the cloud, so its k-th smallest distance can only be >= the true one).
-// One lane per query, per-lane (vector) loads, a register-resident sorted list of distances only.
-template <int K>
-__global__ __launch_bounds__(KN_BLOCK)
-void k_window_bound(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                    int n, const int* __restrict__ qsel, int nqq, int k, int half_window, float* __restrict__ bound) {
-    const int slot = blockIdx.x * KN_BLOCK + threadIdx.x;
-    const int sl = min(slot, nqq - 1);
-    const int sp = qsel ? qsel[sl] : sl;
-    const float qx = sx[sp], qy = sy[sp], qz = sz[sp];
-    int lo = max(0, sp - half_window), hi = min(n, sp + half_window);
-    if (hi - lo < 2 * half_window) { if (lo == 0) hi = min(n, 2 * half_window); else lo = max(0, n - 2 * half_window); }
-    float Ld[K];
-#pragma unroll
-    for (int e = 0; e < K; ++e) Ld[e] = INFINITY;
-    const int len = hi - lo;
-    int maxlen = len;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
-    for (int it = 0; it < maxlen; ++it) {
-        const bool in = it < len;
-        const int p = in ? lo + it : sp;
-        float dx = sx[p] - qx, dy = sy[p] - qy, dz = sz[p] - qz;
-        float d2 = dx * dx + (dy * dy + dz * dz);
-        if (!in) d2 = INFINITY;
-        if (__any(d2 < Ld[K - 1])) {   // compare-and-shift insertion of a distance (indices are irrelevant for a bound)
-            bool lt_cur = d2 < Ld[K - 1];
-#pragma unroll
-            for (int e = K - 1; e >= 1; --e) {
-                bool lt_prev = d2 < Ld[e - 1];
-                Ld[e] = lt_prev ? Ld[e - 1] : (lt_cur ? d2 : Ld[e]);
-                lt_cur = lt_prev;
-            }
-            Ld[0] = lt_cur ? d2 : Ld[0];
-        }
-    }
-    float kth = Ld[K - 1];
-    if (k < K) {
-#pragma unroll
-        for (int e = 0; e < K; ++e) if (e == k - 1) kth = Ld[e];
-    }
-    if (slot < nqq) bound[slot] = kth;   // +inf when the window holds fewer than k points
-}
-
 // ------------------------------------------------------------------ one wave per query: walk, collect, select
 constexpr int QW_WAVES = KN_BLOCK / 64;
 
@@ -275,42 +227,50 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
     float B = bound ? bound[slot] : bound0;   // wave-uniform; only ever decreases
     int wcnt = 0;                             // wave-uniform fill of the row
 
-    auto eval_super = [&](int su) {
-#pragma unroll 1
-        for (int step = 0; step < 4; ++step) {
-            const int pidx = su * 256 + step * 64 + lane;   // arrays are padded with +inf to a multiple of 256
-            float dx = sx[pidx] - qx, dy = sy[pidx] - qy, dz = sz[pidx] - qz;   // (points[i] - query)
-            float d2 = dx * dx + (dy * dy + dz * dz);
-            bool acc = pidx < n && d2 <= B;
-            unsigned long long am = __ballot(acc);
-            if (!am) continue;
-            if (wcnt + __popcll(am) > ROW) {
-                // the row cannot take them all: keep the best k seen so far (wcnt > ROW - 64 >= k), tighten the bound
-                unsigned hi[R], lo[R];
-                load_sort_row<R>(row, wcnt, lane, hi, lo);
-                unsigned kb = 0;
+    // keep the best k of the row (needs wcnt >= k) and drop the bound to the k-th
+    auto compact = [&]() {
+        unsigned hi[R], lo[R];
+        load_sort_row<R>(row, wcnt, lane, hi, lo);
+        unsigned kb = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = r * 64 + lane;
-                    if (e < k) row[e] = ((unsigned long long)hi[r] << 32) | lo[r];
-                    if (r == ((k - 1) >> 6)) kb = __shfl(hi[r], (k - 1) & 63, 64);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                wcnt = k;
-                B = __uint_as_float(kb);
-                acc = acc && d2 <= B;
-                am = __ballot(acc);
-                if (!am) continue;
-            }
-            const int at = wcnt + __popcll(am & ((1ull << lane) - 1ull));
-            if (acc) row[at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig[pidx];
-            wcnt += __popcll(am);
+        for (int r = 0; r < R; ++r) {
+            const int e = r * 64 + lane;
+            if (e < k) row[e] = ((unsigned long long)hi[r] << 32) | lo[r];
+            if (r == ((k - 1) >> 6)) kb = __shfl(hi[r], (k - 1) & 63, 64);
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        wcnt = k;
+        B = __uint_as_float(kb);
+    };
+    // 64 targets, one per lane
+    auto eval_step = [&](int su, int step) {
+        const int pidx = su * 256 + step * 64 + lane;   // arrays are padded with +inf to a multiple of 256
+        float dx = sx[pidx] - qx, dy = sy[pidx] - qy, dz = sz[pidx] - qz;   // (points[i] - query)
+        float d2 = dx * dx + (dy * dy + dz * dz);
+        bool acc = pidx < n && d2 <= B;
+        unsigned long long am = __ballot(acc);
+        if (!am) return;
+        if (wcnt + __popcll(am) > ROW) {   // the row cannot take them all (wcnt > ROW - 64 >= k)
+            compact();
+            acc = acc && d2 <= B;
+            am = __ballot(acc);
+            if (!am) return;
+        }
+        const int at = wcnt + __popcll(am & ((1ull << lane) - 1ull));
+        if (acc) row[at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig[pidx];
+        wcnt += __popcll(am);
     };
 
     const int own = sp >> 8;
-    if (seed_own) eval_super(own);   // unbounded start: the query's own run brings the bound down first
+    if (seed_own) {
+        // unbounded start: the 64 curve neighbours of the query give the first bound, the rest of its 256-point run follows
+        const int s0 = (sp >> 6) & 3;
+        eval_step(own, s0);
+        if (wcnt >= k) compact();
+#pragma unroll 1
+        for (int step = 0; step < 4; ++step) if (step != s0) eval_step(own, step);
+    }
     for (int base = 0; base < n_super; base += 64) {
         const int u = base + lane;
         const float lb = u < n_super ? box_lower_bound(sbox, n_super, u, qp, qp) : INFINITY;
@@ -319,7 +279,8 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
             const int b = __ffsll((long long)smask) - 1;
             smask &= smask - 1;
             if (__shfl(lb, b, 64) > B) continue;   // the bound may have dropped since the test
-            eval_super(base + b);
+#pragma unroll 1
+            for (int step = 0; step < 4; ++step) eval_step(base + b, step);
         }
     }
     unsigned hi[R], lo[R];
@@ -523,8 +484,6 @@ int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out
 
 namespace {
 
-constexpr int CS_HALF_WINDOW = 384;
-
 // One k_query_wave launch: lists[r * p.n_pad + original index] / cnt[original index] for all n queries
 // (qsel == nullptr) or for the nsel sorted positions in qsel (device).
 int query_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, const float* bound, float bound0, int seed_own,
@@ -550,22 +509,10 @@ int radius_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, in
     return query_to_lists(ctx, so, n, p, k, nullptr, r2, 0, TDV_TIMER_RADIUS, nullptr, 0, lists, cnt);
 }
 
-// exact kNN lists of all queries (qsel == nullptr) or of the subset qsel
+// exact kNN lists of all queries (qsel == nullptr) or of the subset qsel: unbounded start from the query's own run
+// (an initial bound from a 768-point window in a separate kernel was measured slower at every size)
 int knn_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, const int* qsel, int nsel, int* lists, int* cnt) {
-    const int nqq = qsel ? nsel : n;
-    if (nqq <= 0) return TDV_OK;
-    if (k > 32) return query_to_lists(ctx, so, n, p, k, nullptr, INFINITY, 1, TDV_TIMER_KNN, qsel, nsel, lists, cnt);
-    hipStream_t s = ctx->stream;
-    float* bound;
-    TDV_TRY(ws_alloc(ctx, align_up((size_t)nqq, KN_BLOCK), &bound));
-    {
-        ScopedTimer tm(ctx, TDV_TIMER_KNN);
-        const int qblocks = (nqq + KN_BLOCK - 1) / KN_BLOCK;
-#define TDV_WB(KK) k_window_bound<KK><<<qblocks, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, n, qsel, nqq, k, CS_HALF_WINDOW, bound)
-        if (k <= 8) TDV_WB(8); else if (k <= 16) TDV_WB(16); else if (k <= 30) TDV_WB(30); else TDV_WB(32);
-#undef TDV_WB
-    }
-    return query_to_lists(ctx, so, n, p, k, bound, 0.f, 0, TDV_TIMER_KNN, qsel, nsel, lists, cnt);
+    return query_to_lists(ctx, so, n, p, k, nullptr, INFINITY, 1, TDV_TIMER_KNN, qsel, nsel, lists, cnt);
 }
 
 }  // namespace
