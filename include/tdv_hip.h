@@ -197,7 +197,8 @@ int tdv_icp(tdv_ctx* ctx, const float* src, int ns, const float* tgt, const floa
 
 /* One correspondence pass for a given T (registration.cpp:325-359): nearest target index per
  * source (always written), its squared distance, and the accepted flag; n_corr = accepted count.
- * Exposed for parity tests. */
+ * Exposed for parity tests.  Full scan by default; with TDV_ICP_SEARCH_PRUNED set on the ctx the pruned
+ * search is used and rows beyond the threshold report corr 0 / d2 FLT_MAX (accepted rows are identical). */
 int tdv_icp_correspondences(tdv_ctx* ctx, const float* src, int ns, const float* tgt, int nt,
                             const float* T, float distance_threshold,
                             int* out_corr, float* out_d2, uint8_t* out_accepted, int* out_n_corr);
