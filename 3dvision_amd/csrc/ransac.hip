@@ -23,6 +23,7 @@
 #include "tdv_internal.hpp"
 #include "device_linalg.hpp"
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <algorithm>
 #include <vector>
@@ -115,11 +116,197 @@ __global__ void k_feature_match_combine(int ns, int ns_pad, int nparts, const fl
     corr[i] = bj;
 }
 
+// ---- exact pruned descriptor match (large problems) -------------------------------------------------------------
+// FPFH descriptors of a real part are strongly clustered (most of their variance lies along one direction), so both
+// sides are ordered by a cheap scalar key (the three centre bins) with a counting sort, 33-D bounding boxes are built
+// over runs of 64 ordered targets, and a wave of neighbouring sources skips every box whose lower bound exceeds all
+// its lanes' current best.  The bound is the distance expression itself applied to the per-dimension gaps, summed in
+// the same order: every term is <= the corresponding term of any target inside the box and float addition /
+// multiplication are monotone, so lb <= fl(dist) holds exactly and no margin is needed.  Targets are visited
+// inside-out from the wave's own key position; ties keep the lowest ORIGINAL target index, as the CPU scan does.
+// The order only affects speed: any key (and the arbitrary order inside a bucket) gives the same correspondences.
+constexpr int FMP_BUCKETS = 4096;
+constexpr int FMP_BOX = 64;
+
+__device__ __forceinline__ int fm_bucket(const float* __restrict__ f) {
+    float k = (f[5] + (f[16] + f[27])) * (float)FMP_BUCKETS;   // descriptors sum to 1: the key lies in [0, 1]
+    int b = (k == k) ? (int)fminf(fmaxf(k, 0.f), (float)(FMP_BUCKETS - 1)) : 0;
+    return b;
+}
+__global__ void k_fm_hist(const float* __restrict__ f, int n, int* __restrict__ hist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&hist[fm_bucket(f + (size_t)i * FD)], 1);
+}
+__global__ void k_fm_scatter(const float* __restrict__ f, int n, const int* __restrict__ start, int* __restrict__ cursor,
+                             int* __restrict__ perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = fm_bucket(f + (size_t)i * FD);
+    perm[start[b] + atomicAdd(&cursor[b], 1)] = i;   // order inside a bucket is irrelevant to the result
+}
+__global__ void k_fm_gather_targets(const float* __restrict__ ft, const int* __restrict__ perm, int nt, int nt_pad,
+                                    float* __restrict__ T, int* __restrict__ torig) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)nt_pad * FD) return;
+    const int row = (int)(e / FD), d = (int)(e % FD);
+    T[e] = row < nt ? ft[(size_t)perm[row] * FD + d] : INFINITY;   // padding rows: distance +inf, never chosen
+    if (d == 0) torig[row] = row < nt ? perm[row] : INT_MAX;
+}
+__global__ void k_fm_boxes(const float* __restrict__ T, int nt, int nbox, float* __restrict__ bmin, float* __restrict__ bmax) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nbox * FD) return;
+    const int b = e / FD, d = e % FD;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int r = b * FMP_BOX; r < min(nt, (b + 1) * FMP_BOX); ++r) { float v = T[(size_t)r * FD + d]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    bmin[e] = mn; bmax[e] = mx;
+}
+
+// box visited at position v of the inside-out order centred at box c (bijection onto [0, nbox))
+__device__ __forceinline__ int visit_inside_out(int v, int c, int nbox) {
+    const int L = c, R = nbox - 1 - c;
+    const int m = min(L, R);
+    if (v <= 2 * m) { int k = (v + 1) >> 1; return (v & 1) ? c + k : c - k; }
+    return R > L ? c + (v - m) : c - (v - m);
+}
+
+template <int SPL>
+__global__ __launch_bounds__(FM_BLOCK)
+void k_feature_match_pruned(const float* __restrict__ fs, const int* __restrict__ sperm, int ns, int ns_pad,
+                            const float* __restrict__ T, const int* __restrict__ torig, int nbox,
+                            const float* __restrict__ bmin, const float* __restrict__ bmax, const int* __restrict__ tstart,
+                            int nsplit, float* __restrict__ pd, int* __restrict__ pj) {
+    const int split = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wbase = (blockIdx.x * (FM_BLOCK / 64) + wave) * (64 * SPL);   // the wave's 64*SPL consecutive ordered sources
+    float f[SPL][FD];
+    float best[SPL]; int bj[SPL]; int src[SPL];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        const int t = wbase + s * 64 + lane;
+        const int i = sperm[min(t, ns - 1)];
+        src[s] = t < ns ? i : -1;   // padding lanes duplicate the last source and write nothing
+#pragma unroll
+        for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
+        best[s] = INFINITY; bj[s] = INT_MAX;
+    }
+    // start where the targets with the wave's own key begin
+    const int c = min(nbox - 1, tstart[__builtin_amdgcn_readfirstlane(fm_bucket(f[0]))] / FMP_BOX);
+    for (int v = split; v < nbox; v += nsplit) {
+        const int b = visit_inside_out(v, c, nbox);
+        const float* __restrict__ lo = bmin + (size_t)b * FD;   // wave-uniform -> scalar loads
+        const float* __restrict__ hi = bmax + (size_t)b * FD;
+        float lb[SPL];
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) lb[s] = 0.f;
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {
+            const float l = lo[d], h = hi[d];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) { float g = fmaxf(fmaxf(l - f[s][d], f[s][d] - h), 0.f); lb[s] += g * g; }
+        }
+        bool alive = false;
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) alive = alive || (lb[s] <= best[s]);   // <=: an equal distance with a lower index still wins
+        if (!__any(alive)) continue;
+#pragma unroll 1
+        for (int t = 0; t < FMP_BOX; ++t) {
+            const int j = b * FMP_BOX + t;
+            const float* __restrict__ g = T + (size_t)j * FD;
+            const int o = torig[j];
+            float q[FD];
+#pragma unroll
+            for (int d = 0; d < FD; ++d) q[d] = g[d];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                float dist = 0.f;
+#pragma unroll
+                for (int d = 0; d < FD; ++d) { float diff = f[s][d] - q[d]; dist += diff * diff; }
+                const bool take = dist < best[s] || (dist == best[s] && o < bj[s]);
+                best[s] = take ? dist : best[s];
+                bj[s] = take ? o : bj[s];
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        if (src[s] < 0) continue;
+        const size_t o = (size_t)split * ns_pad + src[s];
+        pd[o] = best[s]; pj[o] = bj[s];
+    }
+}
+
+// partials of the pruned match: lexicographic (distance, original index) minimum, order-independent
+__global__ void k_feature_match_combine_lex(int ns, int ns_pad, int nparts, const float* __restrict__ pd,
+                                            const int* __restrict__ pj, int* __restrict__ corr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    float best = INFINITY; int bj = INT_MAX;
+    for (int s = 0; s < nparts; ++s) {
+        const float d = pd[(size_t)s * ns_pad + i]; const int j = pj[(size_t)s * ns_pad + i];
+        if (d < best || (d == best && j < bj)) { best = d; bj = j; }
+    }
+    corr[i] = bj == INT_MAX ? 0 : bj;   // nothing finite: the CPU loop keeps its initial index 0
+}
+
+namespace {
+// counting sort of n descriptors by key bucket: perm (ordered position -> row) and, optionally, the bucket starts
+int fm_order(tdv_ctx* ctx, const float* d_f, int n, int* perm, int* start /* FMP_BUCKETS + 1 */) {
+    hipStream_t s = ctx->stream;
+    int *hist, *cursor, *d_total;
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &hist));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &cursor));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
+    k_fm_hist<<<(n + 255) / 256, 256, 0, s>>>(d_f, n, hist);
+    TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
+    k_fm_scatter<<<(n + 255) / 256, 256, 0, s>>>(d_f, n, start, cursor, perm);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+constexpr int FMP_SPL = 1;   // 1 measured better than 2 (C4: 0.84 vs 0.93 ms)
+
+int feature_match_pruned_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
+    hipStream_t s = ctx->stream;
+    const int nt_pad = (int)align_up((size_t)nt, FMP_BOX);
+    const int nbox = nt_pad / FMP_BOX;
+    constexpr int SRC_PER_BLOCK = FM_BLOCK * FMP_SPL;
+    const int ns_pad = (int)align_up((size_t)ns, SRC_PER_BLOCK);
+    const int blocks_x = ns_pad / SRC_PER_BLOCK;
+    int want = (4096 + blocks_x - 1) / blocks_x;
+    const int nsplit = std::max(1, std::min(std::min(want, std::max(1, nbox / 8)), 32));
+    int *sperm, *tperm, *tstart, *sstart, *torig; float *T, *bmin, *bmax, *pd; int* pj;
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &sperm));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &tperm));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &tstart));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &sstart));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt_pad, &torig));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt_pad * FD, &T));
+    TDV_TRY(ws_alloc(ctx, (size_t)nbox * FD, &bmin));
+    TDV_TRY(ws_alloc(ctx, (size_t)nbox * FD, &bmax));
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pd));
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pj));
+    ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
+    TDV_TRY(fm_order(ctx, d_ft, nt, tperm, tstart));
+    TDV_TRY(fm_order(ctx, d_fs, ns, sperm, sstart));
+    k_fm_gather_targets<<<(unsigned)(((size_t)nt_pad * FD + 255) / 256), 256, 0, s>>>(d_ft, tperm, nt, nt_pad, T, torig);
+    k_fm_boxes<<<(nbox * FD + 255) / 256, 256, 0, s>>>(T, nt, nbox, bmin, bmax);
+    k_feature_match_pruned<FMP_SPL><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, sperm, ns, ns_pad, T, torig, nbox, bmin, bmax, tstart,
+                                                                               nsplit, pd, pj);
+    k_feature_match_combine_lex<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nsplit, pd, pj, d_corr);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+}  // namespace
+
 int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
     if (!ctx || !d_fs || !d_ft || !d_corr || ns < 0 || nt < 0) return TDV_ERR_BAD_ARG;
     if (ns == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
     if (nt == 0) { TDV_HIP(ctx, hipMemsetAsync(d_corr, 0, (size_t)ns * 4, s)); return TDV_OK; }
+    static const bool pruned_ok = getenv("TDV_FM_BRUTE") == nullptr;         // A/B knob: same results either way
+    if (pruned_ok && ns >= 4096 && nt >= 2048) return feature_match_pruned_dev(ctx, d_fs, ns, d_ft, nt, d_corr);
     static const bool early = getenv("TDV_FM_NO_EARLY_EXIT") == nullptr;   // A/B knob: same results either way
     const int ns_pad = (int)align_up((size_t)ns, FM_SRC_PER_BLOCK);
     const int blocks_x = ns_pad / FM_SRC_PER_BLOCK;

@@ -34,6 +34,51 @@ def test_feature_match_exact(ctx, orc, synth, ns, nt):
     assert np.array_equal(ctx.feature_match(fs, ft), orc.feature_match(fs, ft))
 
 
+def _real_fpfh(orc, synth, n, seed, scene=False):
+    if scene:
+        x, _ = synth.make_scene(n, seed)
+    else:
+        x, _ = synth.sample_object(n, seed)
+    nrm = orc.estimate_normals(x, 30)
+    return orc.compute_fpfh(x, nrm, 5.0 * float(synth.mean_spacing(n)))
+
+
+def test_feature_match_pruned_path_random(ctx, orc, synth):
+    """Sizes that take the box-pruned match (ns >= 4096, nt >= 2048): unstructured descriptors, duplicates, ties."""
+    ns, nt = 6000, 3000
+    fs = synth.random_features(ns, 1)
+    ft = synth.random_features(nt, 2)
+    ft[2000:2100] = ft[100:200]          # duplicated target rows: the lower index must win
+    fs[:100] = ft[2000:2100]             # exact hits (distance 0) on duplicated rows
+    fs[100:200] = ft[100:200][::-1]
+    got = ctx.feature_match(fs, ft)
+    ref = orc.feature_match(fs, ft)
+    assert np.array_equal(got, ref)
+    assert (got[:200] < 2000).all()
+
+
+def test_feature_match_pruned_path_real_fpfh(ctx, orc, synth):
+    """Real (strongly clustered, many near-ties) FPFH descriptors of the synthetic part: scene vs model."""
+    fs = _real_fpfh(orc, synth, 7000, 42, scene=True)
+    ft = _real_fpfh(orc, synth, 4000, 7)
+    ft[3000:3050] = ft[:50]              # exact duplicates among clustered rows
+    got = ctx.feature_match(fs, ft)
+    ref = orc.feature_match(fs, ft)
+    assert np.array_equal(got, ref)
+    # and the brute-force kernel on the same data (below the size gate) agrees on a slice
+    assert np.array_equal(ctx.feature_match(fs[:3000], ft[:2000]), orc.feature_match(fs[:3000], ft[:2000]))
+
+
+def test_feature_match_pruned_degenerate_keys(ctx, orc, synth):
+    """All descriptors in one key bucket (constant centre bins) and all-zero rows: ordering degenerates, result must not."""
+    ns, nt = 5000, 2500
+    fs = synth.random_features(ns, 3); ft = synth.random_features(nt, 4)
+    for f in (fs, ft):
+        f[:, 5] = 0.01; f[:, 16] = 0.02; f[:, 27] = 0.03
+    ft[10] = 0.0; fs[20] = 0.0
+    assert np.array_equal(ctx.feature_match(fs, ft), orc.feature_match(fs, ft))
+
+
 def test_ransac_inlier_counts_bit_exact(ctx, orc, synth):
     ns, nt = 3000, 2000
     src, tgt, corr, T_gt = _case(synth, ns, nt)
