@@ -9,8 +9,8 @@
 // excluded by an exact bounding-box lower bound (float subtraction, multiplication and addition are monotone under
 // round-to-nearest, so lb <= fl(d2) for every point inside the box: no margin), so the neighbour lists are the
 // reference's lists bit for bit, ties included:
-//   0. the cloud is sorted along a 30-bit Morton curve (bitonic sort shared with voxel.hip) and the bounding boxes
-//      of its 16- and 256-point runs are built once per cloud;
+//   0. the cloud is ordered along a Morton curve (counting sort on the top 21 bits of the 30-bit code) and the
+//      bounding boxes of its 16- and 256-point runs are built once per cloud;
 //   1. k_query_wave: ONE WAVE PER QUERY.  The 256-point boxes are tested 64 per step (one per lane) against the
 //      query point and its bound; the targets of the boxes that pass are evaluated one per lane with coalesced
 //      loads; every target with d2 <= bound is appended to the query's row in LDS (ballot prefix: no atomics,
@@ -80,10 +80,12 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every 
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-__global__ void k_morton_records(const float* __restrict__ xyz, int n, int n_pow2, const float* __restrict__ bbox, uint4* __restrict__ rec) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pow2) return;
-    if (i >= n) { rec[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu); return; }
+// Curve order by counting sort: bucket = the top MORTON_BUCKET_BITS of the 30-bit Morton code (a 128^3 grid over the
+// cloud's bounding box).  Only locality matters for the searches (their results do not depend on the order, nor on
+// the arbitrary order of the few points that share a bucket), so 5 small launches replace a ~60-launch full sort.
+constexpr int MORTON_BUCKET_BITS = 21;
+constexpr int MORTON_BUCKETS = 1 << MORTON_BUCKET_BITS;
+__device__ __forceinline__ int morton_bucket(const float* __restrict__ xyz, int i, const float* __restrict__ bbox) {
     unsigned q[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -94,16 +96,26 @@ __global__ void k_morton_records(const float* __restrict__ xyz, int n, int n_pow
         q[c] = (unsigned)(t * 1023.f);
     }
     unsigned code = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-    rec[i] = make_uint4(code, 0u, 0u, (unsigned)i);
+    return (int)(code >> (30 - MORTON_BUCKET_BITS));
 }
-__global__ void k_gather_sorted(const float* __restrict__ xyz, const uint4* __restrict__ rec, int n, int n_pad,
-                                float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz, int* __restrict__ orig) {
+__global__ void k_morton_hist(const float* __restrict__ xyz, int n, const float* __restrict__ bbox, int* __restrict__ bucket_of,
+                              int* __restrict__ hist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = morton_bucket(xyz, i, bbox);
+    bucket_of[i] = b;
+    atomicAdd(&hist[b], 1);
+}
+__global__ void k_morton_scatter(const float* __restrict__ xyz, int n, int n_pad, const int* __restrict__ bucket_of,
+                                 const int* __restrict__ start, int* __restrict__ cursor,
+                                 float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz, int* __restrict__ orig) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pad) return;
     if (i < n) {
-        unsigned o = rec[i].w;
-        sx[i] = xyz[3 * (size_t)o]; sy[i] = xyz[3 * (size_t)o + 1]; sz[i] = xyz[3 * (size_t)o + 2]; orig[i] = (int)o;
-    } else { sx[i] = INFINITY; sy[i] = INFINITY; sz[i] = INFINITY; orig[i] = INT_MAX; }
+        const int b = bucket_of[i];
+        const int pos = start[b] + atomicAdd(&cursor[b], 1);
+        sx[pos] = xyz[3 * (size_t)i]; sy[pos] = xyz[3 * (size_t)i + 1]; sz[pos] = xyz[3 * (size_t)i + 2]; orig[pos] = i;
+    } else { sx[i] = INFINITY; sy[i] = INFINITY; sz[i] = INFINITY; orig[i] = INT_MAX; }   // padding positions n..n_pad
 }
 
 // Bounding boxes of every 16-target chunk and of every super-chunk of 16 chunks (256 targets) of the sorted cloud.
@@ -441,21 +453,26 @@ struct Sorted { float *sx, *sy, *sz; int* orig; float *cbox, *sbox; int n_chunks
 // Morton sort of the cloud: sorted SoA coordinates (padded with +inf) and the original index of each position
 int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sorted& so) {
     hipStream_t s = ctx->stream;
-    const size_t n_pow2 = sort_pow2((size_t)n);
     const int pad = std::max(p.n_pad, (int)align_up((size_t)p.nt_pad, 16));   // multiple of 256 >= n: covers 8- and 16-target chunks
-    float* soa; uint4* rec; float *part, *bbox;
+    float* soa; float *part, *bbox; int *bucket_of, *hist, *cursor, *start, *d_total;
     TDV_TRY(ws_alloc(ctx, (size_t)3 * pad, &soa));
     TDV_TRY(ws_alloc(ctx, (size_t)pad, &so.orig));
-    TDV_TRY(ws_alloc(ctx, n_pow2, &rec));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &bucket_of));
+    TDV_TRY(ws_alloc(ctx, (size_t)MORTON_BUCKETS, &hist));
+    TDV_TRY(ws_alloc(ctx, (size_t)MORTON_BUCKETS, &cursor));
+    TDV_TRY(ws_alloc(ctx, (size_t)MORTON_BUCKETS, &start));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
     const int bblocks = std::min(1024, (n + 255) / 256);
     TDV_TRY(ws_alloc(ctx, (size_t)bblocks * 6, &part));
     TDV_TRY(ws_alloc(ctx, 6, &bbox));
     so.sx = soa; so.sy = soa + pad; so.sz = soa + 2 * (size_t)pad;
+    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)MORTON_BUCKETS * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)MORTON_BUCKETS * 4, s));
     k_bbox_partial<<<bblocks, 256, 0, s>>>(d_xyz, n, part);
     k_bbox_final<<<1, 64, 0, s>>>(part, bblocks, bbox);
-    k_morton_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, bbox, rec);
-    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
-    k_gather_sorted<<<(pad + 255) / 256, 256, 0, s>>>(d_xyz, rec, n, pad, so.sx, so.sy, so.sz, so.orig);
+    k_morton_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, bbox, bucket_of, hist);
+    TDV_TRY(exclusive_scan_dev(ctx, hist, MORTON_BUCKETS, start, d_total));
+    k_morton_scatter<<<(pad + 255) / 256, 256, 0, s>>>(d_xyz, n, pad, bucket_of, start, cursor, so.sx, so.sy, so.sz, so.orig);
     // bounding boxes of the 16-target chunks and 256-target super-chunks (exact pruning of the scans)
     so.n_chunks16 = (int)(align_up((size_t)n, 16) / 16);
     so.n_super = (so.n_chunks16 + 15) / 16;
