@@ -22,12 +22,12 @@
 //    in a FIXED order (wave64 shuffles -> LDS -> one slab per block); f64 accumulators.
 //  * icp_solve: one block folds the slabs in fixed order, one lane solves the 6x6 system
 //    (pivoted LDL^T) or the 3x3 Kabsch SVD, updates T on the device and evaluates convergence.
-//  * icp_nn_pruned (large clouds, same correspondences bit for bit): both clouds are Morton-sorted once per call;
-//    a wave of 64 neighbouring source points walks the target's 4096/256/16-point bounding boxes and skips every
-//    box whose exact lower bound exceeds all its lanes' current bounds (bound = the inclusive acceptance threshold,
-//    then the best distance found).  Float subtraction, multiplication and addition are monotone under
-//    round-to-nearest, so the bound needs no margin; ties keep the lowest original target index as the scan does.
-//    Results are written at the original source index, so accumulate/solve run unchanged.
+//  * icp_nn_pruned (large clouds, same correspondences bit for bit): the target is put in Morton order once per
+//    call; ONE WAVE PER SOURCE POINT tests the target's 4096- and 64-point bounding boxes one per lane, visits them
+//    best-first, and evaluates the points of the boxes that can hold a neighbour within the bound one per lane
+//    (bound = the inclusive acceptance threshold, then the best distance found).  Float subtraction, multiplication
+//    and addition are monotone under round-to-nearest, so the box bound needs no margin; ties keep the lowest
+//    original target index as the scan does.  accumulate/solve run unchanged.
 // No float atomics anywhere: two runs give identical bits.
 #include "tdv_internal.hpp"
 #include "device_linalg.hpp"
@@ -120,7 +120,7 @@ void k_icp_nn_scan(const float* __restrict__ src, int ns, int ns_pad,
 }
 
 // ---- exact pruned search --------------------------------------------------------------------------------------
-constexpr int PN_BLOCK = 64;   // one wave per workgroup
+constexpr int PN_WAVES = 4;   // one wave per source point, four per workgroup
 
 // lower bound of fl(d2) between point p and any point inside box idx (see knn.hip: box_lower_bound)
 __device__ __forceinline__ float point_box_lb(const float* __restrict__ box, int count, int idx, float px, float py, float pz) {
@@ -130,92 +130,72 @@ __device__ __forceinline__ float point_box_lb(const float* __restrict__ box, int
     return gx * gx + (gy * gy + gz * gz);
 }
 
-// the 16 targets of chunk c against the lane's point: bound/bidx keep the smallest d2 (<= the initial bound),
-// lowest original index on ties
-__device__ __forceinline__ void pruned_eval_chunk(const float* __restrict__ tx, const float* __restrict__ ty,
-                                                  const float* __restrict__ tz, const int* __restrict__ torig, int nt,
-                                                  int c, float px, float py, float pz, float& bound, int& bidx) {
-    const int j = c * NN_CH;
-    float d2[NN_CH];
-    float m = FLT_MAX;
-#pragma unroll
-    for (int t = 0; t < NN_CH; ++t) {
-        float dx = px - tx[j + t], dy = py - ty[j + t], dz = pz - tz[j + t];
-        d2[t] = dx * dx + (dy * dy + dz * dz);
-        m = fminf(m, d2[t]);
-    }
-    if (!__any(m <= bound)) return;
-#pragma unroll
-    for (int t = 0; t < NN_CH; ++t) {
-        const int o = torig[j + t];
-        const bool take = (j + t < nt) && (d2[t] < bound || (d2[t] == bound && o < bidx));
-        bound = take ? d2[t] : bound;
-        bidx = take ? o : bidx;
-    }
-}
-
-__device__ __forceinline__ void pruned_eval_super(const float* __restrict__ tx, const float* __restrict__ ty,
-                                                  const float* __restrict__ tz, const int* __restrict__ torig, int nt,
-                                                  const float* __restrict__ cbox, int n_c16, int u,
-                                                  float px, float py, float pz, float& bound, int& bidx) {
-    const int cend = min(n_c16, u * 16 + 16);
-    for (int c = u * 16; c < cend; ++c) {
-        if (!__any(point_box_lb(cbox, n_c16, c, px, py, pz) <= bound)) continue;
-        pruned_eval_chunk(tx, ty, tz, torig, nt, c, px, py, pz, bound, bidx);
-    }
-}
-
-__global__ __launch_bounds__(PN_BLOCK)
-void k_icp_nn_pruned(const float* __restrict__ ssx, const float* __restrict__ ssy, const float* __restrict__ ssz,
-                     const int* __restrict__ sorig, int ns,
+// One wave per source point.  The 4096-point boxes are tested one per lane and visited best-first (smallest lower
+// bound first, until it exceeds the bound); inside one, its 64 leaves (64 points each) are tested one per lane, and
+// the points of a leaf that passes are evaluated one per lane (coalesced).  bound = the inclusive acceptance
+// threshold, then the best distance found so far.  Each lane keeps its own (d2, original index) minimum; the wave
+// minimum in that lexicographic order is the brute-force scan's answer (lowest index on ties).
+__global__ __launch_bounds__(64 * PN_WAVES)
+void k_icp_nn_pruned(const float* __restrict__ src, int ns,
                      const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
                      const int* __restrict__ torig, int nt,
-                     const float* __restrict__ cbox, int n_c16, const float* __restrict__ sbox, int n_super,
-                     const float* __restrict__ tbox, int n_top,
+                     const float* __restrict__ lbox, int n_leaf, const float* __restrict__ tbox, int n_top,
                      const IcpState* __restrict__ st, float tau,
                      float* __restrict__ out_d2, int* __restrict__ out_idx) {
     if (st->done) return;
-    const int i = blockIdx.x * PN_BLOCK + threadIdx.x;
-    const int ii = min(i, ns - 1);
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * PN_WAVES + (threadIdx.x >> 6);
+    if (i >= ns) return;   // wave-uniform
     float px, py, pz;
-    transform_point(st->T, ssx[ii], ssy[ii], ssz[ii], px, py, pz);
-    float bound = tau;       // inclusive: a target passes iff d2 <= bound
-    int bidx = INT_MAX;      // none yet
-    // seed: the closest 256-target box of each lane (by lower bound) is evaluated first, so that the bound is
-    // near the true NN distance before the walk even when the acceptance threshold is loose
-    {
-        int bt = 0; float bl = INFINITY;
-        for (int t = 0; t < n_top; ++t) {
-            const float l = point_box_lb(tbox, n_top, t, px, py, pz);
-            if (l < bl) { bl = l; bt = t; }
-        }
-        int bs = bt * 16; bl = INFINITY;
-        const int uend = min(n_super, bt * 16 + 16);
-        for (int u = bt * 16; u < uend; ++u) {   // lane-divergent boxes: vector loads
-            const float l = point_box_lb(sbox, n_super, u, px, py, pz);
-            if (l < bl) { bl = l; bs = u; }
-        }
-        bool seeded = false;
+    transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+    float B = tau;           // wave-uniform; a target passes iff d2 <= B
+    float bd = INFINITY;     // this lane's best
+    int bo = INT_MAX;
+    for (int tb = 0; tb < n_top; tb += 64) {
+        const int t = tb + lane;
+        float lbt = t < n_top ? point_box_lb(tbox, n_top, t, px, py, pz) : INFINITY;
         while (true) {
-            const unsigned long long todo = __ballot(!seeded);
-            if (!todo) break;
-            const int u = __builtin_amdgcn_readfirstlane(__shfl(bs, __ffsll((long long)todo) - 1, 64));
-            pruned_eval_super(tx, ty, tz, torig, nt, cbox, n_c16, u, px, py, pz, bound, bidx);
-            seeded = seeded || (bs == u);
+            // best-first over the remaining 4096-point boxes of this group
+            float m = lbt;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+            if (!(m <= B)) break;
+            const int tl = __ffsll((long long)__ballot(lbt == m)) - 1;   // wave-uniform lane of that box
+            if (lane == tl) lbt = INFINITY;                               // visited
+            const int u = (tb + tl) * 64 + lane;
+            const float lbl = u < n_leaf ? point_box_lb(lbox, n_leaf, u, px, py, pz) : INFINITY;
+            unsigned long long lmask = __ballot(lbl <= B);
+            while (lmask) {
+                const int bl = __ffsll((long long)lmask) - 1;
+                lmask &= lmask - 1;
+                if (__shfl(lbl, bl, 64) > B) continue;   // the bound may have dropped since the test
+                const int j = ((tb + tl) * 64 + bl) * 64 + lane;   // arrays are padded with +inf to a multiple of 256
+                float dx = px - tx[j], dy = py - ty[j], dz = pz - tz[j];
+                float d2 = dx * dx + (dy * dy + dz * dz);
+                const bool cand = j < nt && d2 <= B && d2 <= bd;
+                if (__any(cand)) {
+                    const int o = torig[j];
+                    const bool take = cand && (d2 < bd || o < bo);
+                    bd = take ? d2 : bd;
+                    bo = take ? o : bo;
+                    float nb = bd;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) nb = fminf(nb, __shfl_xor(nb, off, 64));
+                    B = fminf(B, nb);
+                }
+            }
         }
     }
-    for (int t = 0; t < n_top; ++t) {
-        if (!__any(point_box_lb(tbox, n_top, t, px, py, pz) <= bound)) continue;
-        const int uend = min(n_super, t * 16 + 16);
-        for (int u = t * 16; u < uend; ++u) {
-            if (!__any(point_box_lb(sbox, n_super, u, px, py, pz) <= bound)) continue;
-            pruned_eval_super(tx, ty, tz, torig, nt, cbox, n_c16, u, px, py, pz, bound, bidx);
-        }
+    // lexicographic (d2, index) minimum over the lanes
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off, 64); const int oo = __shfl_xor(bo, off, 64);
+        const bool take = od < bd || (od == bd && oo < bo);
+        bd = take ? od : bd; bo = take ? oo : bo;
     }
-    if (i < ns) {
-        const int o = sorig[i];
-        out_d2[o] = bidx == INT_MAX ? FLT_MAX : bound;
-        out_idx[o] = bidx == INT_MAX ? 0 : bidx;
+    if (lane == 0) {
+        out_d2[i] = bo == INT_MAX ? FLT_MAX : bd;
+        out_idx[i] = bo == INT_MAX ? 0 : bo;
     }
 }
 
@@ -452,9 +432,8 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     std::memcpy(h->T, T0, 64); std::memcpy(h->res_T, T0, 64);
     hipStream_t s = ctx->stream;
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
-    SortedCloud ss{}, st{};
+    SortedCloud st{};
     if (pruned) {
-        TDV_TRY(spatial_sort_cloud(ctx, d_src, ns, ss));   // rigid motion keeps neighbours together: sorted once
         TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
     } else {
         k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
@@ -471,9 +450,8 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
             {
                 ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
                 if (pruned)
-                    k_icp_nn_pruned<<<(ns + PN_BLOCK - 1) / PN_BLOCK, PN_BLOCK, 0, s>>>(
-                        ss.sx, ss.sy, ss.sz, ss.orig, ns, st.sx, st.sy, st.sz, st.orig, nt, st.cbox, st.n_chunks16,
-                        st.sbox, st.n_super, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
+                    k_icp_nn_pruned<<<(ns + PN_WAVES - 1) / PN_WAVES, 64 * PN_WAVES, 0, s>>>(
+                        d_src, ns, st.sx, st.sy, st.sz, st.orig, nt, st.lbox, st.n_leaf, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
                 else
                     k_icp_nn_scan<<<grid, NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
                                                             p.chunks_per_split, b.st, b.pd2, b.pchunk);
@@ -516,12 +494,10 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
     const float tau = tau_le(thr);
     if (pruned) {   // explicit request only: entries beyond the threshold come back as corr 0 / d2 FLT_MAX
-        SortedCloud ss{}, st{};
-        TDV_TRY(spatial_sort_cloud(ctx, d_src, ns, ss));
+        SortedCloud st{};
         TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
-        k_icp_nn_pruned<<<(ns + PN_BLOCK - 1) / PN_BLOCK, PN_BLOCK, 0, s>>>(
-            ss.sx, ss.sy, ss.sz, ss.orig, ns, st.sx, st.sy, st.sz, st.orig, nt, st.cbox, st.n_chunks16,
-            st.sbox, st.n_super, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
+        k_icp_nn_pruned<<<(ns + PN_WAVES - 1) / PN_WAVES, 64 * PN_WAVES, 0, s>>>(
+            d_src, ns, st.sx, st.sy, st.sz, st.orig, nt, st.lbox, st.n_leaf, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
     } else {
         k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
         k_icp_nn_scan<<<dim3(p.blocks_x, p.nsplit), NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,

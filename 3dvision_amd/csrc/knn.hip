@@ -10,15 +10,15 @@
 // round-to-nearest, so lb <= fl(d2) for every point inside the box: no margin), so the neighbour lists are the
 // reference's lists bit for bit, ties included:
 //   0. the cloud is ordered along a Morton curve (counting sort on the top 21 bits of the 30-bit code) and the
-//      bounding boxes of its 16- and 256-point runs are built once per cloud;
-//   1. k_query_wave: ONE WAVE PER QUERY.  The 256-point boxes are tested 64 per step (one per lane) against the
-//      query point and its bound; the targets of the boxes that pass are evaluated one per lane with coalesced
-//      loads; every target with d2 <= bound is appended to the query's row in LDS (ballot prefix: no atomics,
+//      bounding boxes of its 64-point leaves and 4096-point groups of leaves are built once per cloud;
+//   1. k_query_wave: ONE WAVE PER QUERY.  Boxes are tested 64 per step (one per lane) against the query point and
+//      its bound — first the 4096-point groups, then the 64 leaves of each group that passes; the 64 targets of a
+//      leaf that passes are evaluated one per lane with coalesced loads; every target with d2 <= bound is appended to the query's row in LDS (ballot prefix: no atomics,
 //      deterministic order).  When the row fills, it is sorted in-wave (bitonic network on 64-bit keys
 //      d2 bits : original index, whose unsigned order is the reference's (d2, index) order), cut to the best k, and
 //      the bound drops to the k-th: exact for any number of ties.  At the end the row is sorted and its first k
-//      entries are the list.  kNN starts unbounded: the query's 64 curve neighbours give the first bound, the rest of
-//      its own 256-point run follows, then the walk; the radius search (FPFH, cap 100) starts from r^2.
+//      entries are the list.  kNN starts unbounded: the query's own leaf (its 64 curve neighbours) gives the first
+//      bound, then the walk; the radius search (FPFH, cap 100) starts from r^2.
 // In the batched chain normals_fpfh_dev shares ONE radius search between normals and FPFH: a radius list is sorted
 // by (d2, idx), so its first k entries are the k nearest neighbours wherever it holds >= k; only the deficient
 // points go through the kNN search as a subset.
@@ -118,30 +118,33 @@ __global__ void k_morton_scatter(const float* __restrict__ xyz, int n, int n_pad
     } else { sx[i] = INFINITY; sy[i] = INFINITY; sz[i] = INFINITY; orig[i] = INT_MAX; }   // padding positions n..n_pad
 }
 
-// Bounding boxes of every 16-target chunk and of every super-chunk of 16 chunks (256 targets) of the sorted cloud.
+// Bounding boxes of every 64-point run ("leaf") of the ordered cloud and of every group of 64 leaves ("top",
+// 4096 points): a wave tests 64 boxes per step, one per lane, and evaluates a leaf's 64 points in one step.
 // box layout: 6 arrays [minx|miny|minz|maxx|maxy|maxz][count]
-__global__ void k_chunk_boxes(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                              int n_chunks, float* __restrict__ cb) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_chunks) return;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int t = 0; t < 16; ++t) {
-        float v[3] = {sx[c * 16 + t], sy[c * 16 + t], sz[c * 16 + t]};
+__global__ void k_leaf_boxes(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
+                             int n_leaf, float* __restrict__ lb) {
+    // one wave per leaf
+    const int leaf = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (leaf >= n_leaf) return;
+    const int lane = threadIdx.x & 63;
+    const float v[3] = {sx[leaf * 64 + lane], sy[leaf * 64 + lane], sz[leaf * 64 + lane]};   // +inf padding widens the last box: still valid
+    float mn[3] = {v[0], v[1], v[2]}, mx[3] = {v[0], v[1], v[2]};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], v[a]); mx[a] = fmaxf(mx[a], v[a]); }
-    }
+    for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { cb[(size_t)a * n_chunks + c] = mn[a]; cb[(size_t)(3 + a) * n_chunks + c] = mx[a]; }
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64)); }
+    if (lane < 3) lb[(size_t)lane * n_leaf + leaf] = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
+    else if (lane < 6) lb[(size_t)lane * n_leaf + leaf] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
 }
-__global__ void k_super_boxes(const float* __restrict__ cb, int n_chunks, int n_super, float* __restrict__ sb) {
+__global__ void k_top_boxes(const float* __restrict__ lb, int n_leaf, int n_top, float* __restrict__ tb) {
     int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n_super) return;
+    if (u >= n_top) return;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int c = u * 16; c < min(n_chunks, u * 16 + 16); ++c)
+    for (int c = u * 64; c < min(n_leaf, u * 64 + 64); ++c)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], cb[(size_t)a * n_chunks + c]); mx[a] = fmaxf(mx[a], cb[(size_t)(3 + a) * n_chunks + c]); }
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], lb[(size_t)a * n_leaf + c]); mx[a] = fmaxf(mx[a], lb[(size_t)(3 + a) * n_leaf + c]); }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { sb[(size_t)a * n_super + u] = mn[a]; sb[(size_t)(3 + a) * n_super + u] = mx[a]; }
+    for (int a = 0; a < 3; ++a) { tb[(size_t)a * n_top + u] = mn[a]; tb[(size_t)(3 + a) * n_top + u] = mx[a]; }
 }
 
 // Lower bound on the reference's float d2 = dx*dx + (dy*dy + dz*dz) between ANY query inside [qmin,qmax] and ANY target
@@ -161,6 +164,10 @@ __device__ __forceinline__ float box_lower_bound(const float* __restrict__ box, 
 
 // ------------------------------------------------------------------ one wave per query: walk, collect, select
 constexpr int QW_WAVES = KN_BLOCK / 64;
+// kNN start, measured at 50k/100k/200k (k = 30): own leaf only 0.55/0.55/1.00 ms; own leaf +-1 0.23/0.41/0.61; with nearest-leaf-first
+// inside a group 0.19/0.37/0.67 (kept: it also protects clouds of uneven density); +-2 leaves no better
+constexpr int QW_SEED_SPAN = 1;
+constexpr bool QW_BEST_FIRST = true;
 
 __device__ __forceinline__ bool key_less(unsigned ahi, unsigned alo, unsigned bhi, unsigned blo) {
     return ahi < bhi || (ahi == bhi && alo < blo);
@@ -221,10 +228,10 @@ __device__ __forceinline__ void load_sort_row(const unsigned long long* row, int
 
 // lists[r * n_pad + original index] = the first min(k, found) targets in (d2, idx) order with d2 <= bound
 // (bound = bound[slot] if given, else bound0), cnt_out[original index] = their number.  Requires k <= 64*R - 64.
-template <int R>
+template <int R, int SEED_SPAN, bool BEST_FIRST>
 __global__ __launch_bounds__(KN_BLOCK)
 void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
-                  const int* __restrict__ orig, int n, int n_super, const float* __restrict__ sbox,
+                  const int* __restrict__ orig, int n, int n_leaf, const float* __restrict__ lbox, int n_top, const float* __restrict__ tbox,
                   const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, float bound0, int seed_own,
                   int k, int n_pad, int* __restrict__ lists, int* __restrict__ cnt_out) {
     constexpr int ROW = 64 * R;
@@ -255,9 +262,9 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
         wcnt = k;
         B = __uint_as_float(kb);
     };
-    // 64 targets, one per lane
-    auto eval_step = [&](int su, int step) {
-        const int pidx = su * 256 + step * 64 + lane;   // arrays are padded with +inf to a multiple of 256
+    // the 64 targets of one leaf, one per lane
+    auto eval_leaf = [&](int leaf) {
+        const int pidx = leaf * 64 + lane;   // arrays are padded with +inf to a multiple of 256
         float dx = sx[pidx] - qx, dy = sy[pidx] - qy, dz = sz[pidx] - qz;   // (points[i] - query)
         float d2 = dx * dx + (dy * dy + dz * dz);
         bool acc = pidx < n && d2 <= B;
@@ -274,25 +281,44 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
         wcnt += __popcll(am);
     };
 
-    const int own = sp >> 8;
+    const int own = sp >> 6;
+    const int seed_lo = seed_own ? max(0, own - SEED_SPAN) : 1, seed_hi = seed_own ? min(n_leaf - 1, own + SEED_SPAN) : 0;
     if (seed_own) {
-        // unbounded start: the 64 curve neighbours of the query give the first bound, the rest of its 256-point run follows
-        const int s0 = (sp >> 6) & 3;
-        eval_step(own, s0);
+        // unbounded start: the query's own leaf (its 64 curve neighbours) gives the first bound, its curve-adjacent
+        // leaves follow; the walk skips them
+        eval_leaf(own);
         if (wcnt >= k) compact();
-#pragma unroll 1
-        for (int step = 0; step < 4; ++step) if (step != s0) eval_step(own, step);
+        for (int l = seed_lo; l <= seed_hi; ++l) if (l != own) eval_leaf(l);
     }
-    for (int base = 0; base < n_super; base += 64) {
-        const int u = base + lane;
-        const float lb = u < n_super ? box_lower_bound(sbox, n_super, u, qp, qp) : INFINITY;
-        unsigned long long smask = __ballot(u < n_super && lb <= B && !(seed_own && u == own));
-        while (smask) {
-            const int b = __ffsll((long long)smask) - 1;
-            smask &= smask - 1;
-            if (__shfl(lb, b, 64) > B) continue;   // the bound may have dropped since the test
-#pragma unroll 1
-            for (int step = 0; step < 4; ++step) eval_step(base + b, step);
+    for (int tb = 0; tb < n_top; tb += 64) {
+        const int t = tb + lane;
+        const float lbt = t < n_top ? box_lower_bound(tbox, n_top, t, qp, qp) : INFINITY;
+        unsigned long long tmask = __ballot(lbt <= B);
+        while (tmask) {
+            const int bt = __ffsll((long long)tmask) - 1;
+            tmask &= tmask - 1;
+            if (__shfl(lbt, bt, 64) > B) continue;   // the bound may have dropped since the test
+            const int u = (tb + bt) * 64 + lane;
+            float lbl = (u < n_leaf && !(u >= seed_lo && u <= seed_hi)) ? box_lower_bound(lbox, n_leaf, u, qp, qp) : INFINITY;
+            if (BEST_FIRST && seed_own) {
+                while (true) {   // nearest leaf first: the bound tightens before the far leaves are looked at
+                    float m = lbl;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
+                    if (!(m <= B)) break;
+                    const int bl = __ffsll((long long)__ballot(lbl == m)) - 1;
+                    if (lane == bl) lbl = INFINITY;
+                    eval_leaf((tb + bt) * 64 + bl);
+                }
+            } else {
+                unsigned long long lmask = __ballot(lbl <= B);
+                while (lmask) {
+                    const int bl = __ffsll((long long)lmask) - 1;
+                    lmask &= lmask - 1;
+                    if (__shfl(lbl, bl, 64) > B) continue;
+                    eval_leaf((tb + bt) * 64 + bl);
+                }
+            }
         }
     }
     unsigned hi[R], lo[R];
@@ -448,7 +474,7 @@ ScanPlan make_scan_plan(int n) {
     return p;
 }
 
-struct Sorted { float *sx, *sy, *sz; int* orig; float *cbox, *sbox; int n_chunks16, n_super; };
+struct Sorted { float *sx, *sy, *sz; int* orig; float *lbox, *tbox; int n_leaf, n_top; };
 
 // Morton sort of the cloud: sorted SoA coordinates (padded with +inf) and the original index of each position
 int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sorted& so) {
@@ -473,13 +499,13 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     k_morton_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, bbox, bucket_of, hist);
     TDV_TRY(exclusive_scan_dev(ctx, hist, MORTON_BUCKETS, start, d_total));
     k_morton_scatter<<<(pad + 255) / 256, 256, 0, s>>>(d_xyz, n, pad, bucket_of, start, cursor, so.sx, so.sy, so.sz, so.orig);
-    // bounding boxes of the 16-target chunks and 256-target super-chunks (exact pruning of the scans)
-    so.n_chunks16 = (int)(align_up((size_t)n, 16) / 16);
-    so.n_super = (so.n_chunks16 + 15) / 16;
-    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_chunks16, &so.cbox));
-    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_super, &so.sbox));
-    k_chunk_boxes<<<(so.n_chunks16 + 255) / 256, 256, 0, s>>>(so.sx, so.sy, so.sz, so.n_chunks16, so.cbox);
-    k_super_boxes<<<(so.n_super + 255) / 256, 256, 0, s>>>(so.cbox, so.n_chunks16, so.n_super, so.sbox);
+    // bounding boxes of the 64-point leaves and of the 4096-point groups of 64 leaves (exact pruning of the searches)
+    so.n_leaf = (int)(align_up((size_t)n, 64) / 64);
+    so.n_top = (so.n_leaf + 63) / 64;
+    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_leaf, &so.lbox));
+    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_top, &so.tbox));
+    k_leaf_boxes<<<(so.n_leaf + 3) / 4, 256, 0, s>>>(so.sx, so.sy, so.sz, so.n_leaf, so.lbox);
+    k_top_boxes<<<(so.n_top + 255) / 256, 256, 0, s>>>(so.lbox, so.n_leaf, so.n_top, so.tbox);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
@@ -490,12 +516,9 @@ int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out
     const ScanPlan p = make_scan_plan(n);
     Sorted so;
     TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
-    out.sx = so.sx; out.sy = so.sy; out.sz = so.sz; out.orig = so.orig; out.cbox = so.cbox; out.sbox = so.sbox;
+    out.sx = so.sx; out.sy = so.sy; out.sz = so.sz; out.orig = so.orig; out.lbox = so.lbox; out.tbox = so.tbox;
     out.n = n; out.pad = std::max(p.n_pad, (int)align_up((size_t)p.nt_pad, 16));
-    out.n_chunks16 = so.n_chunks16; out.n_super = so.n_super; out.n_top = (so.n_super + 15) / 16;
-    TDV_TRY(ws_alloc(ctx, (size_t)6 * out.n_top, &out.tbox));
-    k_super_boxes<<<(out.n_top + 255) / 256, 256, 0, ctx->stream>>>(so.sbox, so.n_super, out.n_top, out.tbox);
-    TDV_CHECK_LAUNCH(ctx);
+    out.n_leaf = so.n_leaf; out.n_top = so.n_top;
     return TDV_OK;
 }
 
@@ -510,8 +533,8 @@ int query_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int
     hipStream_t s = ctx->stream;
     const unsigned grid = (unsigned)((nqq + QW_WAVES - 1) / QW_WAVES);
     ScopedTimer tm(ctx, timer);
-#define TDV_QW(RR) k_query_wave<RR><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_super, so.sbox, qsel, nqq, bound, bound0, \
-                                                            seed_own, k, p.n_pad, lists, cnt)
+#define TDV_QW(RR) k_query_wave<RR, QW_SEED_SPAN, QW_BEST_FIRST><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_leaf, so.lbox, so.n_top, so.tbox, \
+                                                            qsel, nqq, bound, bound0, seed_own, k, p.n_pad, lists, cnt)
     if (k <= 64) TDV_QW(2);
     else if (k <= 192) TDV_QW(4);
     else if (k <= 448) TDV_QW(8);

@@ -121,10 +121,10 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
 int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
 size_t sort_pow2(size_t n);
 int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_total);  // voxel.hip
-// Morton-sorted copy of a cloud with the bounding boxes of its 16-, 256- and 4096-point runs (workspace memory):
+// Morton-ordered copy of a cloud with the bounding boxes of its 64-point leaves and 4096-point groups (workspace memory):
 // sx/sy/sz are padded with +inf to `pad` (a multiple of 256), orig[i] = original index of sorted position i.
 // Box arrays are [6][count]: min x,y,z then max x,y,z.
-struct SortedCloud { float *sx, *sy, *sz; int* orig; float *cbox, *sbox, *tbox; int n, pad, n_chunks16, n_super, n_top; };
+struct SortedCloud { float *sx, *sy, *sz; int* orig; float *lbox, *tbox; int n, pad, n_leaf, n_top; };
 int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out);
 
 // normals + FPFH in one go, sharing one spatial sort and one radius scan (batch path; identical results)
