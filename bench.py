@@ -171,7 +171,7 @@ def main():
         sc_avg_ms = sc_ms / max(sc_launches, 1)
         bf_avg_ms = bf_ms / max(bf_launches, 1)
         hyps_total = float(args.steps) * HYPS_PER_STEP
-        pruned_default = n * n >= 2e9   # icp.hip: PRUNED_MIN_PAIRS
+        pruned_default = n >= 4096 and n * n >= 1e8   # icp.hip: PRUNED_MIN_TARGETS, PRUNED_MIN_PAIRS
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): taken from the
         # committed summary of the same command when it covers this workload, else null
         pm = None
