@@ -1,8 +1,8 @@
 set -e
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-python3 $R/bench.py > $O/bench_v3.json 2> $O/bench_v3.err
+python3 $R/bench.py > $O/bench_v4.json 2> $O/bench_v4.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_v3 -- python3 $R/bench.py --no-cpu-baseline > $O/prof_v3_bench.json 2> $O/prof_v3.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_v3 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/pmc_fetch_v3.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_v3 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/pmc_write_v3.err
-cat $O/bench_v3.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_v4 -- python3 $R/bench.py --no-cpu-baseline > $O/prof_v4_bench.json 2> $O/prof_v4.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_v4 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/pmc_fetch_v4.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_v4 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/pmc_write_v4.err
+cat $O/bench_v4.json
