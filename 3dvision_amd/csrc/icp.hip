@@ -20,8 +20,9 @@
 //  * icp_accumulate: one lane per source; resolves the index, applies the sqrt-free inclusive
 //    threshold, builds J = [p x n | n], r = (p-q).n (or the point-to-point moments) and reduces
 //    in a FIXED order (wave64 shuffles -> LDS -> one slab per block); f64 accumulators.
-//  * icp_solve: one block folds the slabs in fixed order, one lane solves the 6x6 system
-//    (pivoted LDL^T) or the 3x3 Kabsch SVD, updates T on the device and evaluates convergence.
+//    The block that finishes last (atomic ticket) folds the slabs in fixed order, one lane solves the 6x6 system
+//    (pivoted LDL^T) or the 3x3 Kabsch SVD, updates T on the device and evaluates convergence: two launches per
+//    iteration.
 //  * icp_nn_pruned (large clouds, same correspondences bit for bit): the target is put in Morton order once per
 //    call; ONE WAVE PER SOURCE POINT tests the target's 4096- and 64-point bounding boxes one per lane, visits them
 //    best-first, and evaluates the points of the boxes that can hold a neighbour within the bound one per lane
@@ -206,106 +207,9 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// MODE 0: point-to-plane (21 upper-triangular JtJ + 6 Jtr), MODE 1: point-to-point moments,
-// MODE 2: outputs only (no accumulation beyond count / error).
+// The update of one iteration from the folded sums tot[] (thread 0 of the folding block): registration.cpp:361-411.
 template <int MODE>
-__global__ __launch_bounds__(256)
-void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
-                      const float* __restrict__ tgt, const float* __restrict__ tgt_normals,
-                      const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
-                      int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk, int direct,
-                      const IcpState* __restrict__ st, float tau_accept,
-                      double* __restrict__ slabs,
-                      int* __restrict__ out_corr, float* __restrict__ out_d2, uint8_t* __restrict__ out_acc) {
-    if (st->done) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    double v[ACC_NV];
-#pragma unroll
-    for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
-    if (i < ns) {
-        float px, py, pz;
-        transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
-        float best = FLT_MAX; int bc = 0;
-        for (int s = 0; s < nsplit; ++s) {
-            float d = pd2[(size_t)s * ns_pad + i];
-            int c = pchunk[(size_t)s * ns_pad + i];
-            if (d < best) { best = d; bc = c; }
-        }
-        int idx = 0;
-        if (direct) {   // pruned search: pd2/pchunk already hold the final (d2, target index)
-            idx = bc;
-        } else if (best < FLT_MAX) {
-            idx = bc;
-#pragma unroll
-            for (int t = NN_CH - 1; t >= 0; --t) {
-                float dx = px - tx[bc + t], dy = py - ty[bc + t], dz = pz - tz[bc + t];
-                float d2 = dx * dx + (dy * dy + dz * dz);
-                if (d2 == best) idx = bc + t;
-            }
-        }
-        bool acc = best <= tau_accept;
-        if (out_corr) out_corr[i] = idx;
-        if (out_d2) out_d2[i] = best;
-        if (out_acc) out_acc[i] = acc ? 1 : 0;
-        if (acc) {
-            v[0] = 1.0; v[1] = (double)best;
-            float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
-            if (MODE == 0) {
-                float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
-                float J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
-                float ex = px - qx, ey = py - qy, ez = pz - qz;
-                float r = ex * nx + (ey * ny + ez * nz);
-                int k = 2;
-#pragma unroll
-                for (int a = 0; a < 6; ++a)
-#pragma unroll
-                    for (int b = a; b < 6; ++b) v[k++] = (double)(J[a] * J[b]);
-#pragma unroll
-                for (int a = 0; a < 6; ++a) v[k++] = (double)(J[a] * r);
-            } else if (MODE == 1) {
-                double P[3] = {px, py, pz}, Q[3] = {qx, qy, qz};
-                v[2] = P[0]; v[3] = P[1]; v[4] = P[2];
-                v[5] = Q[0]; v[6] = Q[1]; v[7] = Q[2];
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) v[8 + a * 3 + b] = P[a] * Q[b];
-            }
-        }
-    }
-    constexpr int NV = MODE == 0 ? 29 : (MODE == 1 ? 17 : 2);
-    __shared__ double red[4][ACC_NV];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double s = wave_sum(v[k]);
-        if (lane == 0) red[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < ACC_NV) {
-        double s = 0.0;
-        if (threadIdx.x < NV) s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        slabs[(size_t)blockIdx.x * ACC_NV + threadIdx.x] = s;
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256)
-void k_icp_solve(const double* __restrict__ slabs, int nblocks, int ns, IcpState* __restrict__ st, int fixed_iterations) {
-    if (st->done) return;
-    __shared__ double part[8][ACC_NV];
-    __shared__ double tot[ACC_NV];
-    const int v = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double s = 0.0;
-    for (int b = g; b < nblocks; b += 8) s += slabs[(size_t)b * ACC_NV + v];
-    part[g][v] = s;
-    __syncthreads();
-    if (threadIdx.x < ACC_NV) {
-        double t = ((part[0][v] + part[1][v]) + (part[2][v] + part[3][v])) + ((part[4][v] + part[5][v]) + (part[6][v] + part[7][v]));
-        tot[v] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+__device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_iterations) {
     const int n_corr = (int)(tot[0] + 0.5);
     const int iter = st->iter;
     st->iter = iter + 1;
@@ -354,24 +258,138 @@ void k_icp_solve(const double* __restrict__ slabs, int nblocks, int ns, IcpState
     if (!fixed_iterations && iter > 0 && fabsf(prev_rmse - rmse) < 1e-6f) st->done = 1;  // registration.cpp:406
 }
 
-__global__ void k_icp_count_only(const double* __restrict__ slabs, int nblocks, IcpState* __restrict__ st) {
-    // single block: total accepted count for the correspondence-only entry point
-    __shared__ double part[256];
-    double s = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) s += slabs[(size_t)b * ACC_NV];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
+
+// MODE 0: point-to-plane (21 upper-triangular JtJ + 6 Jtr), MODE 1: point-to-point moments,
+// MODE 2: outputs only (no accumulation beyond count / error).
+// One launch per iteration: every block reduces its points to one slab (fixed order: per lane -> wave64 shuffles ->
+// LDS); the block that finishes LAST (atomic ticket) folds all slabs in a fixed order, solves, and updates the state
+// on the device — the result does not depend on which block that is.
+template <int MODE, int ACC_PPT>   // ACC_PPT source points per thread (summed per lane in index order)
+__global__ __launch_bounds__(256)
+void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
+                      const float* __restrict__ tgt, const float* __restrict__ tgt_normals,
+                      const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                      int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk, int direct,
+                      IcpState* st, float tau_accept, int fixed_iterations,
+                      double* slabs, unsigned* ticket,
+                      int* __restrict__ out_corr, float* __restrict__ out_d2, uint8_t* __restrict__ out_acc) {
+    if (st->done) return;
+    double v[ACC_NV];
+#pragma unroll
+    for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
+    float T[12];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) T[c * 3 + r] = st->T[c * 4 + r];
+#pragma unroll 1
+    for (int q = 0; q < ACC_PPT; ++q) {
+        const int i = blockIdx.x * (256 * ACC_PPT) + q * 256 + threadIdx.x;
+        if (i >= ns) continue;
+        const float sx = src[3 * i], sy = src[3 * i + 1], sz = src[3 * i + 2];
+        // p = R*s + t with each row evaluated as r0*sx + (r1*sy + r2*sz), then + t (see transform_point)
+        const float px = (T[0] * sx + (T[3] * sy + T[6] * sz)) + T[9];
+        const float py = (T[1] * sx + (T[4] * sy + T[7] * sz)) + T[10];
+        const float pz = (T[2] * sx + (T[5] * sy + T[8] * sz)) + T[11];
+        float best = FLT_MAX; int bc = 0;
+        for (int s = 0; s < nsplit; ++s) {
+            float d = pd2[(size_t)s * ns_pad + i];
+            int c = pchunk[(size_t)s * ns_pad + i];
+            if (d < best) { best = d; bc = c; }
+        }
+        int idx = 0;
+        if (direct) {   // pruned search: pd2/pchunk already hold the final (d2, target index)
+            idx = bc;
+        } else if (best < FLT_MAX) {
+            idx = bc;
+#pragma unroll
+            for (int t = NN_CH - 1; t >= 0; --t) {
+                float dx = px - tx[bc + t], dy = py - ty[bc + t], dz = pz - tz[bc + t];
+                float d2 = dx * dx + (dy * dy + dz * dz);
+                if (d2 == best) idx = bc + t;
+            }
+        }
+        const bool acc = best <= tau_accept;
+        if (out_corr) out_corr[i] = idx;
+        if (out_d2) out_d2[i] = best;
+        if (out_acc) out_acc[i] = acc ? 1 : 0;
+        if (!acc) continue;
+        v[0] += 1.0; v[1] += (double)best;
+        const float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
+        if (MODE == 0) {
+            const float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
+            const float J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+            const float ex = px - qx, ey = py - qy, ez = pz - qz;
+            const float r = ex * nx + (ey * ny + ez * nz);
+            int k = 2;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) v[k++] += (double)(J[a] * J[b]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) v[k++] += (double)(J[a] * r);
+        } else if (MODE == 1) {
+            const double P[3] = {px, py, pz}, Q[3] = {qx, qy, qz};
+            v[2] += P[0]; v[3] += P[1]; v[4] += P[2];
+            v[5] += Q[0]; v[6] += Q[1]; v[7] += Q[2];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) v[8 + a * 3 + b] += P[a] * Q[b];
+        }
     }
-    if (threadIdx.x == 0) st->n_corr = (int)(part[0] + 0.5);
+    constexpr int NV = MODE == 0 ? 29 : (MODE == 1 ? 17 : 2);
+    __shared__ double red[8][ACC_NV];
+    __shared__ double tot[ACC_NV];
+    __shared__ bool is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < ACC_NV) {
+        double s = 0.0;
+        if (threadIdx.x < NV) s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        slabs[(size_t)blockIdx.x * ACC_NV + threadIdx.x] = s;
+    }
+    // ---- last block: fold, solve, update -----------------------------------------------------------------------
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int nblocks = gridDim.x;
+    const int vv = threadIdx.x & 31, g = threadIdx.x >> 5;
+    {
+        // slabs were written by other blocks of this launch: the agent-scope fence above makes them visible to plain loads
+        const double* sl = slabs;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int b2 = g;
+        for (; b2 + 24 < nblocks; b2 += 32) {
+            const double a0 = sl[(size_t)b2 * ACC_NV + vv], a1 = sl[(size_t)(b2 + 8) * ACC_NV + vv];
+            const double a2 = sl[(size_t)(b2 + 16) * ACC_NV + vv], a3 = sl[(size_t)(b2 + 24) * ACC_NV + vv];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; b2 < nblocks; b2 += 8) s0 += sl[(size_t)b2 * ACC_NV + vv];
+        red[g][vv] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (threadIdx.x < ACC_NV)
+        tot[vv] = ((red[0][vv] + red[1][vv]) + (red[2][vv] + red[3][vv])) + ((red[4][vv] + red[5][vv]) + (red[6][vv] + red[7][vv]));
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    *ticket = 0u;   // ready for the next launch (stream order)
+    if (MODE == 2) st->n_corr = (int)(tot[0] + 0.5);
+    else icp_update<MODE>(tot, ns, st, fixed_iterations);
 }
 
 namespace {
 
 struct NnPlan {
-    int ns_pad, nt_pad, n_chunks, blocks_x, nsplit, chunks_per_split, acc_blocks;
+    int ns_pad, nt_pad, n_chunks, blocks_x, nsplit, chunks_per_split, acc_blocks, acc_ppt;
 };
 
 NnPlan make_plan(int ns, int nt) {
@@ -386,12 +404,14 @@ NnPlan make_plan(int ns, int nt) {
     p.nsplit = std::max(1, std::min(std::min(want, max_split), 64));
     p.chunks_per_split = (p.n_chunks + p.nsplit - 1) / p.nsplit;
     p.nsplit = (p.n_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
-    p.acc_blocks = (ns + 255) / 256;
+    static const int ppt_env = getenv("TDV_ICP_PPT") ? atoi(getenv("TDV_ICP_PPT")) : 0;
+    p.acc_ppt = ppt_env ? ppt_env : 4;   // make_plan's default; the brute-force path (split partials, index recovery) uses 1
+    p.acc_blocks = (ns + 256 * p.acc_ppt - 1) / (256 * p.acc_ppt);
     return p;
 }
 
 struct IcpBuffers {
-    float *tx, *ty, *tz, *pd2; int* pchunk; double* slabs; IcpState* st;
+    float *tx, *ty, *tz, *pd2; int* pchunk; double* slabs; IcpState* st; unsigned* ticket;
 };
 
 int alloc_buffers(tdv_ctx* ctx, const NnPlan& p, IcpBuffers& b) {
@@ -402,6 +422,8 @@ int alloc_buffers(tdv_ctx* ctx, const NnPlan& p, IcpBuffers& b) {
     TDV_TRY(ws_alloc(ctx, (size_t)p.nsplit * p.ns_pad, &b.pchunk));
     TDV_TRY(ws_alloc(ctx, (size_t)p.acc_blocks * ACC_NV, &b.slabs));
     TDV_TRY(ws_alloc(ctx, 1, &b.st));
+    TDV_TRY(ws_alloc(ctx, 1, &b.ticket));
+    TDV_HIP(ctx, hipMemsetAsync(b.ticket, 0, 4, ctx->stream));
     return TDV_OK;
 }
 
@@ -425,6 +447,7 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     if (!(tau < FLT_MAX)) pruned = false;   // unbounded threshold: keep the scan's handling of overflowing distances
     NnPlan p = make_plan(ns, nt);
     if (pruned) p.nsplit = 1;
+    else if (!getenv("TDV_ICP_PPT")) { p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256; }   // measured: 50k x 10k brute 7.6k vs 6.4k iters/s
     IcpBuffers b;
     TDV_TRY(alloc_buffers(ctx, p, b));
     TDV_TRY(pin_reserve(ctx, sizeof(IcpState)));
@@ -458,13 +481,13 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
                                                             p.chunks_per_split, b.st, b.pd2, b.pchunk);
             }
             if (p2pl) {
-                k_icp_accumulate<0><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, d_tgt_normals, b.tx, b.ty, b.tz,
-                                                                 p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
-                k_icp_solve<0><<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, ns, b.st, fixed_iterations);
+#define TDV_ACC(MM, NRM) do { if (p.acc_ppt == 4) k_icp_accumulate<MM, 4><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \
+                                   p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, fixed_iterations, b.slabs, b.ticket, nullptr, nullptr, nullptr); \
+                               else k_icp_accumulate<MM, 1><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \
+                                   p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, fixed_iterations, b.slabs, b.ticket, nullptr, nullptr, nullptr); } while (0)
+                TDV_ACC(0, d_tgt_normals);
             } else {
-                k_icp_accumulate<1><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz,
-                                                                 p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, b.slabs, nullptr, nullptr, nullptr);
-                k_icp_solve<1><<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, ns, b.st, fixed_iterations);
+                TDV_ACC(1, nullptr);
             }
         }
         TDV_CHECK_LAUNCH(ctx);
@@ -483,6 +506,7 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
     if (!ctx || !d_src || !d_tgt || !T || ns <= 0 || nt <= 0) return TDV_ERR_BAD_ARG;
     TDV_HIP(ctx, hipSetDevice(ctx->device));
     NnPlan p = make_plan(ns, nt);
+    p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256;   // one point per thread in the outputs-only pass
     const bool pruned = ctx->icp_search == TDV_ICP_SEARCH_PRUNED && tau_le(thr) < FLT_MAX;
     if (pruned) p.nsplit = 1;
     IcpBuffers b;
@@ -504,9 +528,8 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
         k_icp_nn_scan<<<dim3(p.blocks_x, p.nsplit), NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
                                                                       p.chunks_per_split, b.st, b.pd2, b.pchunk);
     }
-    k_icp_accumulate<2><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz, p.nsplit,
-                                                     b.pd2, b.pchunk, pruned ? 1 : 0, b.st, tau, b.slabs, outs.corr, outs.d2, outs.accepted);
-    k_icp_count_only<<<1, 256, 0, s>>>(b.slabs, p.acc_blocks, b.st);
+    k_icp_accumulate<2, 1><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz, p.nsplit,
+                                                        b.pd2, b.pchunk, pruned ? 1 : 0, b.st, tau, 0, b.slabs, b.ticket, outs.corr, outs.d2, outs.accepted);
     TDV_CHECK_LAUNCH(ctx);
     TDV_HIP(ctx, hipMemcpyAsync(h, b.st, sizeof(IcpState), hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));

@@ -80,12 +80,11 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every 
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-// Curve order by counting sort: bucket = the top MORTON_BUCKET_BITS of the 30-bit Morton code (a 128^3 grid over the
-// cloud's bounding box).  Only locality matters for the searches (their results do not depend on the order, nor on
+// Curve order by counting sort: bucket = the top 12..21 bits (by cloud size) of the 30-bit Morton code (up to a 128^3
+// grid over the cloud's bounding box).  Only locality matters for the searches (their results do not depend on the order, nor on
 // the arbitrary order of the few points that share a bucket), so 5 small launches replace a ~60-launch full sort.
-constexpr int MORTON_BUCKET_BITS = 21;
-constexpr int MORTON_BUCKETS = 1 << MORTON_BUCKET_BITS;
-__device__ __forceinline__ int morton_bucket(const float* __restrict__ xyz, int i, const float* __restrict__ bbox) {
+constexpr int MORTON_MAX_BUCKET_BITS = 21;
+__device__ __forceinline__ int morton_bucket(const float* __restrict__ xyz, int i, const float* __restrict__ bbox, int bits) {
     unsigned q[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -96,13 +95,13 @@ __device__ __forceinline__ int morton_bucket(const float* __restrict__ xyz, int 
         q[c] = (unsigned)(t * 1023.f);
     }
     unsigned code = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
-    return (int)(code >> (30 - MORTON_BUCKET_BITS));
+    return (int)(code >> (30 - bits));
 }
-__global__ void k_morton_hist(const float* __restrict__ xyz, int n, const float* __restrict__ bbox, int* __restrict__ bucket_of,
+__global__ void k_morton_hist(const float* __restrict__ xyz, int n, const float* __restrict__ bbox, int bits, int* __restrict__ bucket_of,
                               int* __restrict__ hist) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int b = morton_bucket(xyz, i, bbox);
+    const int b = morton_bucket(xyz, i, bbox, bits);
     bucket_of[i] = b;
     atomicAdd(&hist[b], 1);
 }
@@ -484,20 +483,24 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     TDV_TRY(ws_alloc(ctx, (size_t)3 * pad, &soa));
     TDV_TRY(ws_alloc(ctx, (size_t)pad, &so.orig));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &bucket_of));
-    TDV_TRY(ws_alloc(ctx, (size_t)MORTON_BUCKETS, &hist));
-    TDV_TRY(ws_alloc(ctx, (size_t)MORTON_BUCKETS, &cursor));
-    TDV_TRY(ws_alloc(ctx, (size_t)MORTON_BUCKETS, &start));
+    // about 8 buckets per point for a surface sample (most cells of the grid are empty), a multiple of 3 bits
+    int bits = 12;
+    while (bits < MORTON_MAX_BUCKET_BITS && (1 << bits) < 8 * n) bits += 3;
+    const int nbuckets = 1 << bits;
+    TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &hist));
+    TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &cursor));
+    TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &start));
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
     const int bblocks = std::min(1024, (n + 255) / 256);
     TDV_TRY(ws_alloc(ctx, (size_t)bblocks * 6, &part));
     TDV_TRY(ws_alloc(ctx, 6, &bbox));
     so.sx = soa; so.sy = soa + pad; so.sz = soa + 2 * (size_t)pad;
-    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)MORTON_BUCKETS * 4, s));
-    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)MORTON_BUCKETS * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)nbuckets * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)nbuckets * 4, s));
     k_bbox_partial<<<bblocks, 256, 0, s>>>(d_xyz, n, part);
     k_bbox_final<<<1, 64, 0, s>>>(part, bblocks, bbox);
-    k_morton_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, bbox, bucket_of, hist);
-    TDV_TRY(exclusive_scan_dev(ctx, hist, MORTON_BUCKETS, start, d_total));
+    k_morton_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, bbox, bits, bucket_of, hist);
+    TDV_TRY(exclusive_scan_dev(ctx, hist, nbuckets, start, d_total));
     k_morton_scatter<<<(pad + 255) / 256, 256, 0, s>>>(d_xyz, n, pad, bucket_of, start, cursor, so.sx, so.sy, so.sz, so.orig);
     // bounding boxes of the 64-point leaves and of the 4096-point groups of 64 leaves (exact pruning of the searches)
     so.n_leaf = (int)(align_up((size_t)n, 64) / 64);
