@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--hyps", type=int, default=10000)
     ap.add_argument("--icp-iters", type=int, default=50)
     ap.add_argument("--voxel", type=float, default=0.0005)
+    ap.add_argument("--threads", type=int, default=1,
+                    help="host threads, one tdv_ctx (stream + workspace) each, sharing the instances — the reference's thread-pool shape")
     ap.add_argument("--matched", action="store_true",
                     help="scene and model voxelised at the same 1 mm (as pipeline.cpp does with one voxel_size): smaller clouds, "
                          "but the registration is well-posed, so angle_to_gt is meaningful")
@@ -65,21 +67,42 @@ def main():
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev)
     prm = tdv.batch_params(width=w, height=h, fx=f, fy=f, cx=cx, cy=cy, zmax=1.5, voxel_size=args.voxel,
                            ransac_max_iterations=args.hyps, ransac_confidence=2.0, icp_max_iterations=args.icp_iters, icp_distance_factor=4.0)
-    ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 1, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)  # warm-up
-    ctx.timing_enable(True)
+    import threading
+    nthr = max(1, args.threads)
+    ctxs = [ctx] + [tdv.Context(0) for _ in range(nthr - 1)]
+    share = [B // nthr + (1 if t < B % nthr else 0) for t in range(nthr)]
+    offs = [sum(share[:t]) for t in range(nthr)]
+    for c in ctxs:   # warm-up: arena growth, code load
+        c.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 1, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+    ctx.timing_enable(nthr == 1)
     for s in range(7):
         ctx.timing_read(s)
     torch.cuda.synchronize()
+    results = [None] * nthr
+
+    def work(t):
+        if share[t] == 0:
+            results[t] = []
+            return
+        mptr = d_masks.data_ptr() + offs[t] * h * w
+        results[t] = ctxs[t].register_batch_dev(d_depth.data_ptr(), None, mptr, share[t], prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+
     t0 = time.perf_counter()
-    res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), B, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+    if nthr == 1:
+        work(0)
+    else:
+        th = [threading.Thread(target=work, args=(t,)) for t in range(nthr)]
+        for x in th: x.start()
+        for x in th: x.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    res = [r for part in results for r in part]
     names = ["icp_nn", "ransac_score", "feature_match", "knn_scan", "radius_scan", "depth", "voxel"]
     stage = {n: ctx.timing_read(i)[0] / B for i, n in enumerate(names)}
     Tinv = np.linalg.inv(T.astype(np.float64))
     ang = [synth.rotation_angle(Tinv[:3, :3], r["T"][:3, :3]) for r in res]
     print(json.dumps(dict(config=("matched-resolution batch (1 mm): " if args.matched else "C4-style batch: ") + "%d instances x %d-px mask of one 1280x720 frame vs %d-pt model" % (B, int(hit.sum()), nm),
-                          instances=B, pixels_per_instance=int(hit.sum()), voxels_per_instance=res[0]["n_voxels"], model_points=nm,
+                          instances=B, host_threads=nthr, pixels_per_instance=int(hit.sum()), voxels_per_instance=res[0]["n_voxels"], model_points=nm,
                           wall_s=dt, instances_per_s=B / dt, ms_per_instance=dt / B * 1e3,
                           ransac_hyps_per_s=B * args.hyps / dt, icp_iters_per_s=sum(r["icp_iterations"] for r in res) / dt,
                           kernel_ms_per_instance=stage, icp_fitness=[float(r["fitness"]) for r in res[:3]],
