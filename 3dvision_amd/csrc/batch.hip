@@ -3,6 +3,9 @@
 // intermediate (cloud, voxels, normals, FPFH, correspondences) stays in the ctx workspace; per instance
 // the host only reads three scalars (point count, voxel count, results).  SURVEY.md 8f N1.
 #include "tdv_internal.hpp"
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -26,37 +29,66 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
                                           prm->mask_mode, prm->fx, prm->fy, prm->cx, prm->cy, prm->zmax, d_off, all_xyz, nullptr));
     }
     (void)d_bgr;  // colours do not enter the registration chain (voxelDownsample keeps them, nothing downstream reads them)
-    for (int b = 0; b < n_instances; ++b) {
+    // one instance: voxel -> normals + FPFH -> match -> RANSAC -> ICP on context c (its stream, its workspace)
+    auto run_instance = [&](tdv_ctx* c, int b) -> int {
         tdv_instance_result& r = results[b];
         std::memset(&r, 0, sizeof(r));
         for (int i = 0; i < 16; ++i) r.T[i] = (i % 5 == 0) ? 1.f : 0.f;
-        const WsMark mark = ws_mark(ctx);
+        const WsMark mark = ws_mark(c);
         int n = off[b + 1] - off[b];
         r.n_points = n;
-        if (n == 0) { r.status = 2; ws_rewind(ctx, mark); continue; }
+        if (n == 0) { r.status = 2; ws_rewind(c, mark); return TDV_OK; }
         float* xyz = all_xyz + (size_t)off[b] * 3;
         float* vx; int v = 0;
-        TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &vx));
-        TDV_TRY(voxel_downsample_dev(ctx, xyz, nullptr, n, prm->voxel_size, TDV_VOXEL_ORDER_FIRST, nullptr, vx, nullptr, n, &v));
+        TDV_TRY(ws_alloc(c, (size_t)n * 3, &vx));
+        TDV_TRY(voxel_downsample_dev(c, xyz, nullptr, n, prm->voxel_size, TDV_VOXEL_ORDER_FIRST, nullptr, vx, nullptr, n, &v));
         r.n_voxels = v;
         float *nrm, *fpfh; int* corr;
-        TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &nrm));
-        TDV_TRY(ws_alloc(ctx, (size_t)v * 33, &fpfh));
-        TDV_TRY(ws_alloc(ctx, (size_t)v, &corr));
-        TDV_TRY(normals_fpfh_dev(ctx, vx, v, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor, nrm, fpfh));
+        TDV_TRY(ws_alloc(c, (size_t)v * 3, &nrm));
+        TDV_TRY(ws_alloc(c, (size_t)v * 33, &fpfh));
+        TDV_TRY(ws_alloc(c, (size_t)v, &corr));
+        TDV_TRY(normals_fpfh_dev(c, vx, v, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor, nrm, fpfh));
         tdv_ransac_result coarse;
-        TDV_TRY(feature_match_dev(ctx, fpfh, v, d_model_fpfh, n_model, corr));
-        TDV_TRY(ransac_run_dev(ctx, vx, v, d_model_xyz, n_model, nullptr, nullptr, corr, prm->voxel_size, prm->ransac_max_iterations,
+        TDV_TRY(feature_match_dev(c, fpfh, v, d_model_fpfh, n_model, corr));
+        TDV_TRY(ransac_run_dev(c, vx, v, d_model_xyz, n_model, nullptr, nullptr, corr, prm->voxel_size, prm->ransac_max_iterations,
                                prm->ransac_confidence, prm->seed, &coarse, nullptr));
         r.coarse_fitness = coarse.fitness; r.coarse_inliers = coarse.inliers;
         tdv_icp_result fine;
         const float thr = prm->voxel_size * prm->icp_distance_factor;  // pipeline.cpp:104
-        TDV_TRY(icp_run_dev(ctx, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine));
+        TDV_TRY(icp_run_dev(c, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine));
         std::memcpy(r.T, fine.T, 64);
         r.fitness = fine.fitness; r.rmse = fine.rmse; r.icp_iterations = fine.iterations;
         r.status = 0;
-        ws_rewind(ctx, mark);
+        ws_rewind(c, mark);
+        return TDV_OK;
+    };
+    // Two lanes (the calling thread on ctx, one helper thread on ctx->helper: its own stream and workspace) take
+    // alternate instances, so that one lane's host syncs and small kernels overlap the other's work — the shape of
+    // the reference's thread pool (src/pipeline.cpp:321-327), inside one call.  Results do not depend on the lanes.
+    static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 2;
+    const bool two = lanes_env >= 2 && n_instances >= 2;
+    if (two && !ctx->helper) {
+        if (tdv_ctx_create(ctx->device, &ctx->helper) != TDV_OK) ctx->helper = nullptr;
     }
+    if (!two || !ctx->helper) {
+        for (int b = 0; b < n_instances; ++b) TDV_TRY(run_instance(ctx, b));
+        return TDV_OK;
+    }
+    tdv_ctx* h = ctx->helper;
+    h->timing = ctx->timing; h->icp_search = ctx->icp_search; h->err[0] = 0;
+    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the clouds are complete before the other stream reads them
+    int st_helper = TDV_OK;
+    std::thread worker([&]() {
+        if (hipSetDevice(h->device) != hipSuccess) { st_helper = TDV_ERR_NO_DEVICE; return; }
+        st_helper = ws_reset(h);
+        for (int b = 1; b < n_instances && st_helper == TDV_OK; b += 2) st_helper = run_instance(h, b);
+        if (st_helper == TDV_OK && hipStreamSynchronize(h->stream) != hipSuccess) st_helper = TDV_ERR_LAUNCH;
+    });
+    int st_main = TDV_OK;
+    for (int b = 0; b < n_instances && st_main == TDV_OK; b += 2) st_main = run_instance(ctx, b);
+    worker.join();
+    if (st_main != TDV_OK) return st_main;
+    if (st_helper != TDV_OK) { std::snprintf(ctx->err, sizeof(ctx->err), "batch lane 2: %s", h->err); return st_helper; }
     return TDV_OK;
 }
 

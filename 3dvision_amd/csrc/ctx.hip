@@ -216,6 +216,7 @@ int tdv_ctx_synchronize(tdv_ctx* ctx) {
 
 void tdv_ctx_destroy(tdv_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->helper) { tdv_ctx_destroy(ctx->helper); ctx->helper = nullptr; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->blocks) (void)hipFree(b.p);
@@ -244,6 +245,10 @@ int tdv_timing_read(tdv_ctx* ctx, int slot, double* total_ms, int* launches) {
         ctx->event_pool.push_back(p.first); ctx->event_pool.push_back(p.second);
     }
     t.pending.clear();
+    if (ctx->helper) {   // the batched pipeline's second lane times its kernels on its own stream
+        double hms = 0.0; int hl = 0;
+        if (tdv_timing_read(ctx->helper, slot, &hms, &hl) == TDV_OK) { t.total_ms += hms; t.launches += hl; }
+    }
     if (total_ms) *total_ms = t.total_ms;
     if (launches) *launches = t.launches;
     t.total_ms = 0.0; t.launches = 0;
