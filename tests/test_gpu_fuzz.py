@@ -1,0 +1,111 @@
+"""Randomised differential tests of the exact pruned searches (kNN lists, radius lists, ICP correspondences) against
+the CPU oracle's brute-force scans (reference src/registration.cpp:63-102, :325-359), on geometries chosen to stress
+the Morton order and the bounding-box bounds: flat and collinear clouds (zero extent on an axis), heavy duplication,
+tight clusters far apart, large coordinate offsets, tiny scales, and mixtures.  Every comparison is exact."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(kind, n, rng):
+    if kind == "uniform":
+        p = rng.random((n, 3))
+    elif kind == "flat":            # zero extent in z
+        p = rng.random((n, 3)); p[:, 2] = 0.25
+    elif kind == "line":            # zero extent in y and z
+        p = np.zeros((n, 3)); p[:, 0] = rng.random(n)
+    elif kind == "grid":            # massive exact distance ties
+        m = int(np.ceil(n ** (1 / 3)))
+        g = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), -1).reshape(-1, 3)[:n]
+        p = g * 0.01
+    elif kind == "dups":            # every point repeated several times
+        base = rng.random((max(1, n // 5), 3))
+        p = base[rng.integers(0, len(base), n)]
+    elif kind == "clusters":        # tight clusters far apart
+        c = rng.random((8, 3)) * 100.0
+        p = c[rng.integers(0, 8, n)] + rng.normal(0, 1e-3, (n, 3))
+    elif kind == "offset":          # large offset, small extent: coarse float spacing
+        p = 1000.0 + rng.random((n, 3)) * 0.05
+    elif kind == "tiny":
+        p = rng.random((n, 3)) * 1e-4
+    elif kind == "mixed":
+        a = rng.random((n // 2, 3)); b = np.full((n - n // 2, 3), 0.5) + rng.normal(0, 1e-6, (n - n // 2, 3))
+        p = np.concatenate([a, b], 0)[rng.permutation(n)]
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(p, np.float32)
+
+
+KINDS = ["uniform", "flat", "line", "grid", "dups", "clusters", "offset", "tiny", "mixed"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_knn_lists_fuzz(ctx, orc, kind):
+    rng = np.random.default_rng(zlib.crc32(kind.encode()))
+    for trial in range(3):
+        n = int(rng.integers(40, 2600))
+        k = int(rng.choice([1, 5, 16, 30, 31, 32, 40, 64, 100]))
+        pts = _make(kind, n, rng)
+        ref_n, ref_knn = orc.estimate_normals(pts, k, want_knn=True)
+        got_n, got_knn = ctx.estimate_normals(pts, k, want_knn=True)
+        assert np.array_equal(got_knn, ref_knn), (kind, n, k)
+        # normals come from an eigen-solver on the same sums: identical inputs -> identical bits (NaN rows compare as bytes)
+        assert got_n.tobytes() == ref_n.tobytes(), (kind, n, k)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_radius_lists_fuzz(ctx, orc, kind):
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + 1)
+    for trial in range(3):
+        n = int(rng.integers(40, 2200))
+        pts = _make(kind, n, rng)
+        ext = float(np.ptp(pts, axis=0).max()) or 1.0
+        radius = float(ext * rng.choice([0.01, 0.05, 0.2, 2.0]))   # from a handful of neighbours to everything (cap 100)
+        nrm = np.zeros_like(pts); nrm[:, 2] = 1.0
+        ref = orc.compute_fpfh(pts, nrm, radius, want_neighbors=True)
+        got = ctx.compute_fpfh(pts, nrm, radius, want_neighbors=True)
+        assert np.array_equal(got[2], ref[2]), (kind, n, radius)
+        assert np.array_equal(got[1], ref[1]), (kind, n, radius)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_icp_pruned_correspondences_fuzz(ctx, orc, synth, kind):
+    rng = np.random.default_rng(zlib.crc32(kind.encode()) + 2)
+    try:
+        ctx.set_icp_search("pruned")
+        for trial in range(3):
+            ns, nt = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+            tgt = _make(kind, nt, rng)
+            src = _make(kind, ns, rng)
+            ext = float(np.ptp(tgt, axis=0).max()) or 1.0
+            thr = float(ext * rng.choice([1e-3, 0.02, 0.3, 5.0]))
+            T = synth.make_transform(rng.normal(size=3), float(rng.uniform(0, 10)), tuple(rng.normal(0, 0.01 * ext, 3)))
+            ref = orc.icp_correspondences(src, tgt, None, T, thr, point_to_plane=False)
+            got = ctx.icp_correspondences(src, tgt, T, thr)
+            acc = ref["accepted"].astype(bool)
+            assert np.array_equal(got["accepted"], ref["accepted"]), (kind, ns, nt, thr)
+            assert np.array_equal(got["corr"][acc], ref["corr"][acc]), (kind, ns, nt, thr)
+            assert got["d2"][acc].tobytes() == ref["d2"][acc].tobytes(), (kind, ns, nt, thr)
+            assert got["n_corr"] == ref["n_corr"]
+    finally:
+        ctx.set_icp_search("auto")
+
+
+def test_feature_match_pruned_fuzz(ctx, orc):
+    """Descriptor rows with structure along the ordering key, exact duplicates, zeros and constant columns."""
+    rng = np.random.default_rng(77)
+    for trial in range(4):
+        ns, nt = int(rng.integers(4096, 7000)), int(rng.integers(2048, 4000))
+        base = rng.random((16, 33)).astype(np.float32)
+        ft = base[rng.integers(0, 16, nt)] + rng.normal(0, 10.0 ** -float(rng.integers(2, 7)), (nt, 33)).astype(np.float32)
+        fs = base[rng.integers(0, 16, ns)] + rng.normal(0, 1e-3, (ns, 33)).astype(np.float32)
+        ft = np.abs(ft); fs = np.abs(fs)
+        ft /= ft.sum(1, keepdims=True); fs /= fs.sum(1, keepdims=True)
+        ft[nt // 2: nt // 2 + 200] = ft[:200]          # duplicates: lowest index must win
+        fs[:100] = ft[nt // 2: nt // 2 + 100]
+        if trial == 3:
+            ft[:, 5] = 0; fs[:, 16] = 0
+        assert np.array_equal(ctx.feature_match(fs, ft), orc.feature_match(fs, ft)), trial
