@@ -36,6 +36,14 @@ namespace tdv {
 
 constexpr int KN_BLOCK = 256;
 
+// XCD-aware block order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8
+// XCDs, so block b of the launch takes the logical position that gives every XCD one CONTIGUOUS eighth of the curve-
+// ordered work: the rows a workgroup gathers are then mostly in its own XCD's 4 MiB L2.  A speed choice only.
+__device__ __forceinline__ int xcd_contiguous_block(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 // ------------------------------------------------------------------ spatial sort
 __global__ __launch_bounds__(256)
 void k_bbox_partial(const float* __restrict__ xyz, int n, float* __restrict__ part /* [blocks][6] */) {
@@ -225,18 +233,18 @@ __device__ __forceinline__ void load_sort_row(const unsigned long long* row, int
     wave_sort_keys<R>(hi, lo, sort_span(m), lane);
 }
 
-// lists[r * n_pad + original index] = the first min(k, found) targets in (d2, idx) order with d2 <= bound
+// lists[original index * stride + r] = the first min(k, found) targets in (d2, idx) order with d2 <= bound
 // (bound = bound[slot] if given, else bound0), cnt_out[original index] = their number.  Requires k <= 64*R - 64.
 template <int R, int SEED_SPAN, bool BEST_FIRST>
 __global__ __launch_bounds__(KN_BLOCK)
 void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
                   const int* __restrict__ orig, int n, int n_leaf, const float* __restrict__ lbox, int n_top, const float* __restrict__ tbox,
                   const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, float bound0, int seed_own,
-                  int k, int n_pad, int* __restrict__ lists, int* __restrict__ cnt_out) {
+                  int k, int stride, int* __restrict__ lists, int* __restrict__ cnt_out) {
     constexpr int ROW = 64 * R;
     __shared__ unsigned long long rows[QW_WAVES][ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int slot = blockIdx.x * QW_WAVES + wave;
+    const int slot = xcd_contiguous_block(blockIdx.x, gridDim.x) * QW_WAVES + wave;   // curve order: an XCD works on one stretch
     if (slot >= nqq) return;   // wave-uniform; no block-level barrier below
     unsigned long long* row = rows[wave];
     const int sp = qsel ? qsel[slot] : slot;
@@ -327,35 +335,55 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = r * 64 + lane;
-        if (e < c) lists[(size_t)e * n_pad + i0] = (int)lo[r];
+        if (e < c) lists[(size_t)i0 * stride + e] = (int)lo[r];   // a row per query: coalesced
     }
     if (lane == 0) cnt_out[i0] = c;
 }
 
 // ------------------------------------------------------------------ normals (registration.cpp:105-130)
-// One lane per point (original index).  The k nearest neighbours come from listsA when it holds at least k
-// entries (FPFH's radius list: sorted by (d2, idx), so its first k ARE the k nearest), else from listsB (kNN scan).
+// One lane per point, points taken in curve order (order[t], so that the lanes of a wave gather from the same
+// neighbourhood).  The k nearest neighbours come from listsA when it holds at least k entries (FPFH's radius list:
+// sorted by (d2, idx), so its first k ARE the k nearest), else from listsB (kNN search).  Lists are rows per point.
 __global__ __launch_bounds__(KN_BLOCK)
-void k_normals_from_lists(const float* __restrict__ xyz, int n, int n_pad, int k,
-                          const int* __restrict__ listsA, const int* __restrict__ cntA,
-                          const int* __restrict__ listsB, const int* __restrict__ cntB,
+void k_normals_from_lists(const float* __restrict__ xyz, int n, const int* __restrict__ order, int k,
+                          const int* __restrict__ listsA, int strideA, const int* __restrict__ cntA,
+                          const int* __restrict__ listsB, int strideB, const int* __restrict__ cntB,
                           float* __restrict__ normals, int* __restrict__ knn_out, int knn_stride) {
-    const int i = blockIdx.x * KN_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * KN_BLOCK + threadIdx.x;
+    const bool live = t < n;
+    const int i = order[live ? t : n - 1];
     const bool useA = listsA && cntA[i] >= k;
-    const int* __restrict__ L = useA ? listsA : listsB;
+    const int* __restrict__ Lg = useA ? listsA + (size_t)i * strideA : listsB + (size_t)i * strideB;
     const int cnt = useA ? k : cntB[i];
-    if (knn_out) for (int r = 0; r < knn_stride; ++r) knn_out[(size_t)i * knn_stride + r] = r < cnt ? L[(size_t)r * n_pad + i] : -1;
+    // Rows are contiguous per point: a wave reads its 64 rows coalesced (lane r of row q) into LDS, then every lane
+    // walks its own row there (k <= 32; longer lists are read in place).
+    __shared__ int srow[KN_BLOCK / 64][64][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool staged = k <= 32;
+    if (staged) {
+        const unsigned long long pbits = (unsigned long long)Lg;
+        for (int q = 0; q < 64; ++q) {
+            const unsigned lo32 = __shfl((unsigned)pbits, q, 64), hi32 = __shfl((unsigned)(pbits >> 32), q, 64);
+            const int* row = (const int*)(((unsigned long long)hi32 << 32) | lo32);
+            const int c = __shfl(cnt, q, 64);
+            if (lane < c) srow[wave][q][lane] = row[lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!live) return;
+    const int* L = staged ? &srow[wave][lane][0] : Lg;
+    if (knn_out) for (int r = 0; r < knn_stride; ++r) knn_out[(size_t)i * knn_stride + r] = r < cnt ? L[r] : -1;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     for (int r = 0; r < cnt; ++r) {
-        int j = L[(size_t)r * n_pad + i];
+        int j = L[r];
         cx += xyz[3 * (size_t)j]; cy += xyz[3 * (size_t)j + 1]; cz += xyz[3 * (size_t)j + 2];
     }
     const float fc = (float)cnt;
     cx /= fc; cy /= fc; cz /= fc;
     float c00 = 0.f, c10 = 0.f, c20 = 0.f, c11 = 0.f, c21 = 0.f, c22 = 0.f;
     for (int r = 0; r < cnt; ++r) {
-        int j = L[(size_t)r * n_pad + i];
+        int j = L[r];
         float dx = xyz[3 * (size_t)j] - cx, dy = xyz[3 * (size_t)j + 1] - cy, dz = xyz[3 * (size_t)j + 2] - cz;
         c00 += dx * dx; c10 += dy * dx; c20 += dz * dx; c11 += dy * dy; c21 += dz * dy; c22 += dz * dz;
     }
@@ -381,83 +409,111 @@ __global__ void k_compact_flagged(const int* __restrict__ flag, const int* __res
 // ------------------------------------------------------------------ FPFH (registration.cpp:133-201)
 constexpr int FP_MAXNN = 100;
 
+// SPFH (registration.cpp:137-170), ONE WAVE PER POINT in curve order, one neighbour per lane: the pair features
+// (incl. the f64 atan2) are computed in parallel, and the histogram is counted with ballots — the CPU loop adds 1.0f
+// per pair, and sums of ones are exact in any order, so counting is the same arithmetic.
 __global__ __launch_bounds__(KN_BLOCK)
-void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, int n_pad,
+void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, const int* __restrict__ order,
             const int* __restrict__ nbr, const int* __restrict__ nbr_cnt, float* __restrict__ spfh) {
-    __shared__ float hist[33][KN_BLOCK];
-    const int tid = threadIdx.x;
-    const int i = blockIdx.x * KN_BLOCK + tid;
-#pragma unroll
-    for (int b = 0; b < 33; ++b) hist[b][tid] = 0.f;
-    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * (KN_BLOCK / 64) + (threadIdx.x >> 6);
+    if (t >= n) return;   // wave-uniform
+    const int i = order[t];
     const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
     const float ux = nrm[3 * (size_t)i], uy = nrm[3 * (size_t)i + 1], uz = nrm[3 * (size_t)i + 2];
     const int cnt = nbr_cnt[i];
-    for (int r = 0; r < cnt; ++r) {
-        const int j = nbr[(size_t)r * n_pad + i];
-        if (j == i) continue;
-        float dx = xyz[3 * (size_t)j] - px, dy = xyz[3 * (size_t)j + 1] - py, dz = xyz[3 * (size_t)j + 2] - pz;
-        float dist = sqrtf(dx * dx + (dy * dy + dz * dz));
-        if (dist < 1e-8f) continue;
-        float ex = dx / dist, ey = dy / dist, ez = dz / dist;
-        float vx = uy * ez - uz * ey, vy = uz * ex - ux * ez, vz = ux * ey - uy * ex;   // v = u x d
-        float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;   // w = u x v
-        float njx = nrm[3 * (size_t)j], njy = nrm[3 * (size_t)j + 1], njz = nrm[3 * (size_t)j + 2];
-        float alpha = vx * njx + (vy * njy + vz * njz);
-        float phi = ux * ex + (uy * ey + uz * ez);
-        float wn = wx * njx + (wy * njy + wz * njz);
-        float un = ux * njx + (uy * njy + uz * njz);
-        float theta = (float)atan2((double)wn, (double)un);
-        int bin_a = min(max((int)((alpha + 1.0f) * 5.5f), 0), 10);
-        int bin_p = min(max((int)((phi + 1.0f) * 5.5f), 0), 10);
-        int bin_t = min(max((int)(((double)theta / 3.14159265358979323846 + (double)1.0f) * (double)5.5f), 0), 10);
-        hist[bin_a][tid] += 1.0f;
-        hist[11 + bin_p][tid] += 1.0f;
-        hist[22 + bin_t][tid] += 1.0f;
+    int mine = 0;   // lane b < 33 counts bin b
+    for (int r0 = 0; r0 < cnt; r0 += 64) {
+        const int r = r0 + lane;
+        const int j = r < cnt ? nbr[(size_t)i * FP_MAXNN + r] : i;
+        bool valid = r < cnt && j != i;
+        int bin_a = 0, bin_p = 0, bin_t = 0;
+        if (valid) {
+            float dx = xyz[3 * (size_t)j] - px, dy = xyz[3 * (size_t)j + 1] - py, dz = xyz[3 * (size_t)j + 2] - pz;
+            float dist = sqrtf(dx * dx + (dy * dy + dz * dz));
+            valid = !(dist < 1e-8f);
+            if (valid) {
+                float ex = dx / dist, ey = dy / dist, ez = dz / dist;
+                float vx = uy * ez - uz * ey, vy = uz * ex - ux * ez, vz = ux * ey - uy * ex;   // v = u x d
+                float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;   // w = u x v
+                float njx = nrm[3 * (size_t)j], njy = nrm[3 * (size_t)j + 1], njz = nrm[3 * (size_t)j + 2];
+                float alpha = vx * njx + (vy * njy + vz * njz);
+                float phi = ux * ex + (uy * ey + uz * ez);
+                float wn = wx * njx + (wy * njy + wz * njz);
+                float un = ux * njx + (uy * njy + uz * njz);
+                float theta = (float)atan2((double)wn, (double)un);
+                bin_a = min(max((int)((alpha + 1.0f) * 5.5f), 0), 10);
+                bin_p = min(max((int)((phi + 1.0f) * 5.5f), 0), 10);
+                bin_t = min(max((int)(((double)theta / 3.14159265358979323846 + (double)1.0f) * (double)5.5f), 0), 10);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 11; ++b) {
+            const int ca = __popcll(__ballot(valid && bin_a == b));
+            const int cp = __popcll(__ballot(valid && bin_p == b));
+            const int ct = __popcll(__ballot(valid && bin_t == b));
+            mine += lane == b ? ca : (lane == 11 + b ? cp : (lane == 22 + b ? ct : 0));
+        }
     }
+    const float hv = (float)mine;   // = the CPU's sum of 1.0f increments (counts stay far below 2^24)
     float sum = 0.f;
-#pragma unroll
-    for (int b = 0; b < 33; ++b) sum += hist[b][tid];
-#pragma unroll
-    for (int b = 0; b < 33; ++b) {
-        float v = hist[b][tid];
-        if (sum > 0.f) v /= sum;
-        spfh[(size_t)i * 33 + b] = v;
-    }
+    for (int b = 0; b < 33; ++b) sum += __shfl(hv, b, 64);
+    float v = hv;
+    if (sum > 0.f) v /= sum;
+    if (lane < 33) spfh[(size_t)i * 33 + lane] = v;
 }
 
+// FPFH (registration.cpp:176-197), ONE WAVE PER POINT in curve order: lane d < 33 owns bin d and adds
+// w_r * spfh[j_r][d] for r = 0, 1, ... in list order (the CPU loop's order per bin); every step reads one 132-byte
+// row coalesced, and the four points of a workgroup are spatial neighbours, so most rows come from L1/L2.
 __global__ __launch_bounds__(KN_BLOCK)
-void k_fpfh(const float* __restrict__ xyz, int n, int n_pad, const int* __restrict__ nbr, const int* __restrict__ nbr_cnt,
-            const float* __restrict__ spfh, float* __restrict__ desc, int* __restrict__ nbr_out /* [n][100] or null */) {
-    const int i = blockIdx.x * KN_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    float f[33];
-#pragma unroll
-    for (int d = 0; d < 33; ++d) f[d] = spfh[(size_t)i * 33 + d];
+void k_fpfh(const float* __restrict__ xyz, int n, const int* __restrict__ order, const int* __restrict__ nbr,
+            const int* __restrict__ nbr_cnt, const float* __restrict__ spfh, float* __restrict__ desc,
+            int* __restrict__ nbr_out /* [n][100] or null */) {
+    const int lane = threadIdx.x & 63;
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * (KN_BLOCK / 64) + (threadIdx.x >> 6);
+    if (t >= n) return;   // wave-uniform
+    const int i = order[t];
     const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
     const int cnt = nbr_cnt[i];
-    for (int r = 0; r < cnt; ++r) {
-        const int j = nbr[(size_t)r * n_pad + i];
-        if (nbr_out) nbr_out[(size_t)i * FP_MAXNN + r] = j;
-        if (j == i) continue;
-        float dx = xyz[3 * (size_t)j] - px, dy = xyz[3 * (size_t)j + 1] - py, dz = xyz[3 * (size_t)j + 2] - pz;
-        float dist = sqrtf(dx * dx + (dy * dy + dz * dz));
-        if (dist < 1e-8f) continue;
-        float w = 1.0f / dist;
-        const float* sj = spfh + (size_t)j * 33;
+    // neighbours r = lane and r = 64 + lane: index, weight 1/dist, or skipped (self, coincident point)
+    int j[2]; float w[2]; bool use[2];
 #pragma unroll
-        for (int d = 0; d < 33; ++d) f[d] += w * sj[d];
+    for (int h = 0; h < 2; ++h) {
+        const int r = h * 64 + lane;
+        j[h] = r < cnt ? nbr[(size_t)i * FP_MAXNN + r] : -1;
+        if (nbr_out && r < FP_MAXNN) nbr_out[(size_t)i * FP_MAXNN + r] = j[h];
+        use[h] = false; w[h] = 0.f;
+        if (j[h] >= 0 && j[h] != i) {
+            float dx = xyz[3 * (size_t)j[h]] - px, dy = xyz[3 * (size_t)j[h] + 1] - py, dz = xyz[3 * (size_t)j[h] + 2] - pz;
+            float dist = sqrtf(dx * dx + (dy * dy + dz * dz));
+            if (!(dist < 1e-8f)) { use[h] = true; w[h] = 1.0f / dist; }
+        }
     }
-    if (nbr_out) for (int r = cnt; r < FP_MAXNN; ++r) nbr_out[(size_t)i * FP_MAXNN + r] = -1;
+    const unsigned long long um0 = __ballot(use[0]), um1 = __ballot(use[1]);
+    const int d = min(lane, 32);
+    float f = spfh[(size_t)i * 33 + d];
+    // eight rows in flight per step (the gathers are latency-bound otherwise); the adds stay in list order
+    constexpr int FU = 8;
+    for (int r0 = 0; r0 < cnt; r0 += FU) {
+        float val[FU], wr[FU]; bool ok[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const int r = r0 + u;
+            const int h = (r >> 6) & 1, l = r & 63;
+            ok[u] = r < cnt && (((h ? um1 : um0) >> l) & 1ull);   // wave-uniform
+            const int jr = __shfl(h ? j[1] : j[0], l, 64);
+            wr[u] = __shfl(h ? w[1] : w[0], l, 64);
+            val[u] = ok[u] ? spfh[(size_t)jr * 33 + d] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) f = ok[u] ? f + wr[u] * val[u] : f;
+    }
     float sum = 0.f;
-#pragma unroll
-    for (int d = 0; d < 33; ++d) sum += f[d];
-#pragma unroll
-    for (int d = 0; d < 33; ++d) {
-        float v = f[d];
-        if (sum > 0.f) v /= sum;
-        desc[(size_t)i * 33 + d] = v;
-    }
+    for (int b = 0; b < 33; ++b) sum += __shfl(f, b, 64);   // d = 0..32 in order, as the CPU loop
+    float v = f;
+    if (sum > 0.f) v /= sum;
+    if (lane < 33) desc[(size_t)i * 33 + lane] = v;
 }
 
 namespace {
@@ -527,7 +583,7 @@ int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out
 
 namespace {
 
-// One k_query_wave launch: lists[r * p.n_pad + original index] / cnt[original index] for all n queries
+// One k_query_wave launch: lists[original index * k + r] / cnt[original index] for all n queries
 // (qsel == nullptr) or for the nsel sorted positions in qsel (device).
 int query_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int k, const float* bound, float bound0, int seed_own,
                    int timer, const int* qsel, int nsel, int* lists, int* cnt) {
@@ -537,7 +593,7 @@ int query_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int
     const unsigned grid = (unsigned)((nqq + QW_WAVES - 1) / QW_WAVES);
     ScopedTimer tm(ctx, timer);
 #define TDV_QW(RR) k_query_wave<RR, QW_SEED_SPAN, QW_BEST_FIRST><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_leaf, so.lbox, so.n_top, so.tbox, \
-                                                            qsel, nqq, bound, bound0, seed_own, k, p.n_pad, lists, cnt)
+                                                            qsel, nqq, bound, bound0, seed_own, k, k, lists, cnt)
     if (k <= 64) TDV_QW(2);
     else if (k <= 192) TDV_QW(4);
     else if (k <= 448) TDV_QW(8);
@@ -570,19 +626,19 @@ int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* 
     TDV_TRY(ws_alloc(ctx, (size_t)kk * p.n_pad, &lists));
     TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
     TDV_TRY(knn_to_lists(ctx, so, n, p, kk, nullptr, 0, lists, cnt));
-    k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, ctx->stream>>>(d_xyz, n, p.n_pad, kk, nullptr, nullptr, lists, cnt, d_normals, d_knn, k);
+    k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, ctx->stream>>>(d_xyz, n, so.orig, kk, nullptr, 0, nullptr, lists, kk, cnt, d_normals, d_knn, k);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
 
 namespace {
-int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, const ScanPlan& p, const int* nbr, const int* cnt,
+int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, const ScanPlan& p, const int* order, const int* nbr, const int* cnt,
                     float* d_desc, int* d_nbr, int* d_nbr_cnt) {
     float* spfh;
     TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
     hipStream_t s = ctx->stream;
-    k_spfh<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, d_normals, n, p.n_pad, nbr, cnt, spfh);
-    k_fpfh<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, nbr, cnt, spfh, d_desc, d_nbr);
+    k_spfh<<<(n + KN_BLOCK / 64 - 1) / (KN_BLOCK / 64), KN_BLOCK, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
+    k_fpfh<<<(n + KN_BLOCK / 64 - 1) / (KN_BLOCK / 64), KN_BLOCK, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
     TDV_CHECK_LAUNCH(ctx);
     if (d_nbr_cnt) TDV_HIP(ctx, hipMemcpyAsync(d_nbr_cnt, cnt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return TDV_OK;
@@ -600,7 +656,7 @@ int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, i
     TDV_TRY(ws_alloc(ctx, (size_t)FP_MAXNN * p.n_pad, &nbr));
     TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
     TDV_TRY(radius_to_lists(ctx, so, n, p, FP_MAXNN, r2, nbr, cnt));
-    return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, nbr, cnt, d_desc, d_nbr, d_nbr_cnt);
+    return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, so.orig, nbr, cnt, d_desc, d_nbr, d_nbr_cnt);
 }
 
 // estimateNormals(k) followed by computeFPFH(radius) on the same cloud (src/pipeline.cpp:93-95), sharing one
@@ -640,9 +696,9 @@ int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radiu
     const int nsel = *h_total;
     if (getenv("TDV_DEBUG")) fprintf(stderr, "[tdv] normals_fpfh: n=%d deficient=%d (k=%d)\n", n, nsel, kk);
     TDV_TRY(knn_to_lists(ctx, so, n, p, kk, qsel, nsel, listsK, cntK));
-    k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, n, p.n_pad, kk, nbr, cnt, listsK, cntK, d_normals, nullptr, 0);
+    k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, n, so.orig, kk, nbr, FP_MAXNN, cnt, listsK, kk, cntK, d_normals, nullptr, 0);
     TDV_CHECK_LAUNCH(ctx);
-    return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, nbr, cnt, d_desc, nullptr, nullptr);
+    return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, so.orig, nbr, cnt, d_desc, nullptr, nullptr);
 }
 
 }  // namespace tdv

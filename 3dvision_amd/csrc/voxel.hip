@@ -6,7 +6,7 @@
 // points IN ASCENDING INPUT INDEX divided by float(count); colours likewise; normals dropped.
 //
 // The reference groups with std::unordered_map and emits voxels in that container's iteration
-// order.  Here grouping is a sort, which is deterministic and needs no atomics:
+// order.  Here grouping is by hashing + tiny per-bucket sorts (below), with a full sort as the fallback:
 //   1. k_voxel_records   : record (kx, ky, kz, idx) per point
 //   2. bitonic sort      : ascending by (kx, ky, kz, idx) as unsigned words — members of a voxel
 //                          become one run, in ascending input index (LDS-tiled local passes,
@@ -19,6 +19,7 @@
 // to obtain its iteration order as a list of leader indices, and permutes the means on the device.
 #include "tdv_internal.hpp"
 #include <cmath>
+#include <cstdlib>
 #include <unordered_map>
 #include <vector>
 #include <algorithm>
@@ -115,6 +116,53 @@ int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2) {
     }
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
+}
+
+// ---- grouping by hashing (the default; the bitonic sort above is the fallback) -------------------------------------
+// Members of a voxel only have to become one run in ascending input index; the order of the runs is irrelevant
+// (positions come from the leader scan).  So: bucket = hash(cell) into >= 2n buckets (counting sort, integer atomics),
+// then every bucket — a handful of records, possibly of several colliding cells — is insertion-sorted by
+// (cell, index) by one lane.  A bucket larger than VX_MAX_BUCKET (a very coarse grid) raises a flag and the call is
+// redone with the full sort.
+constexpr int VX_MAX_BUCKET = 96;
+__device__ __forceinline__ unsigned voxel_hash(unsigned x, unsigned y, unsigned z) {
+    unsigned h = x * 73856093u ^ y * 19349663u ^ z * 83492791u;
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+    return h;
+}
+__global__ void k_voxel_hist(const float* __restrict__ xyz, int n, float inv, unsigned mask, uint4* __restrict__ rec_in, int* __restrict__ hist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 r;
+    r.x = (unsigned)(int)floorf(xyz[3 * i] * inv);
+    r.y = (unsigned)(int)floorf(xyz[3 * i + 1] * inv);
+    r.z = (unsigned)(int)floorf(xyz[3 * i + 2] * inv);
+    r.w = (unsigned)i;
+    rec_in[i] = r;
+    atomicAdd(&hist[voxel_hash(r.x, r.y, r.z) & mask], 1);
+}
+__global__ void k_voxel_scatter(const uint4* __restrict__ rec_in, int n, unsigned mask, const int* __restrict__ start, int* __restrict__ cursor,
+                                uint4* __restrict__ rec) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 r = rec_in[i];
+    const unsigned b = voxel_hash(r.x, r.y, r.z) & mask;
+    rec[start[b] + atomicAdd(&cursor[b], 1)] = r;
+}
+__global__ void k_voxel_bucket_sort(uint4* __restrict__ rec, const int* __restrict__ start, const int* __restrict__ hist, int nbuckets,
+                                    int* __restrict__ too_big) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    const int m = hist[b];
+    if (m <= 1) return;
+    if (m > VX_MAX_BUCKET) { *too_big = 1; return; }
+    uint4* a = rec + start[b];
+    for (int e = 1; e < m; ++e) {   // insertion sort by (x, y, z, index)
+        const uint4 key = a[e];
+        int f = e - 1;
+        while (f >= 0 && rec_less(key, a[f])) { a[f + 1] = a[f]; --f; }
+        a[f + 1] = key;
+    }
 }
 
 // leader[idx] = 1 for the smallest input index of each voxel
@@ -246,8 +294,16 @@ int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_
 
 size_t sort_pow2(size_t n) { size_t p = BT_TILE; while (p < n) p <<= 1; return p; }
 
+static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
+                                 const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort);
+
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
                          const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out) {
+    return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, h_xyz, d_out_xyz, d_out_rgb, capacity, n_out, false);
+}
+
+static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
+                                 const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort) {
     if (!ctx || !n_out || n < 0 || capacity < 0 || !(voxel > 0.f) || (n > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
     if (order == TDV_VOXEL_ORDER_REFERENCE && n > 0 && !h_xyz) return TDV_ERR_BAD_ARG;
     *n_out = 0;
@@ -265,8 +321,30 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
     TDV_TRY(pin_reserve(ctx, 64));
     ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
-    k_voxel_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, inv, rec);
-    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
+    static const bool force_sort = getenv("TDV_VOXEL_SORT") != nullptr;   // A/B knob: the full bitonic sort
+    bool hashed = !force_sort && !full_sort;
+    int* d_too_big = nullptr;
+    if (hashed) {
+        size_t nb = 4096;
+        while (nb < 2 * (size_t)n) nb <<= 1;
+        int *hist, *cursor, *start, *d_tot2; uint4* rec_in;
+        TDV_TRY(ws_alloc(ctx, nb, &hist));
+        TDV_TRY(ws_alloc(ctx, nb, &cursor));
+        TDV_TRY(ws_alloc(ctx, nb, &start));
+        TDV_TRY(ws_alloc(ctx, 1, &d_tot2));
+        TDV_TRY(ws_alloc(ctx, 1, &d_too_big));
+        TDV_TRY(ws_alloc(ctx, (size_t)n, &rec_in));
+        TDV_HIP(ctx, hipMemsetAsync(hist, 0, nb * 4, s));
+        TDV_HIP(ctx, hipMemsetAsync(cursor, 0, nb * 4, s));
+        TDV_HIP(ctx, hipMemsetAsync(d_too_big, 0, 4, s));
+        k_voxel_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, inv, (unsigned)(nb - 1), rec_in, hist);
+        TDV_TRY(exclusive_scan_dev(ctx, hist, (int)nb, start, d_tot2));
+        k_voxel_scatter<<<(n + 255) / 256, 256, 0, s>>>(rec_in, n, (unsigned)(nb - 1), start, cursor, rec);
+        k_voxel_bucket_sort<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(rec, start, hist, (int)nb, d_too_big);
+    } else {
+        k_voxel_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, inv, rec);
+        TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
+    }
     TDV_HIP(ctx, hipMemsetAsync(leader, 0, (size_t)n * 4, s));
     k_voxel_heads<<<(n + 255) / 256, 256, 0, s>>>(rec, n, leader);
     k_scan_reduce<<<sblocks, 1024, 0, s>>>(leader, n, sums);
@@ -274,8 +352,12 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     k_scan_local<<<sblocks, 1024, 0, s>>>(leader, n, sums, rank);
     TDV_CHECK_LAUNCH(ctx);
     int* h_total = reinterpret_cast<int*>(ctx->pin);
+    h_total[1] = 0;
     TDV_HIP(ctx, hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, s));
+    if (hashed) TDV_HIP(ctx, hipMemcpyAsync(h_total + 1, d_too_big, 4, hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
+    if (hashed && h_total[1])   // a bucket too large for the per-lane sort (very coarse grid): redo with the full sort
+        return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, h_xyz, d_out_xyz, d_out_rgb, capacity, n_out, true);
     const int v = *h_total;
     *n_out = v;
     if (v > capacity) return TDV_ERR_BAD_ARG;
