@@ -133,16 +133,36 @@ __device__ __forceinline__ int fm_bucket(const float* __restrict__ f) {
     int b = (k == k) ? (int)fminf(fmaxf(k, 0.f), (float)(FMP_BUCKETS - 1)) : 0;
     return b;
 }
-__global__ void k_fm_hist(const float* __restrict__ f, int n, int* __restrict__ hist) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&hist[fm_bucket(f + (size_t)i * FD)], 1);
+// Real descriptors crowd a few buckets, so both passes count in an LDS histogram first (one global atomic per
+// non-empty bucket and workgroup instead of one per row).
+constexpr int FMP_SORT_BLOCK = 1024;
+__global__ __launch_bounds__(FMP_SORT_BLOCK)
+void k_fm_hist(const float* __restrict__ f, int n, int* __restrict__ bucket_of, int* __restrict__ hist) {
+    __shared__ int h[FMP_BUCKETS];
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
+    if (i < n) {
+        const int b = fm_bucket(f + (size_t)i * FD);
+        bucket_of[i] = b;
+        atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) if (h[b]) atomicAdd(&hist[b], h[b]);
 }
-__global__ void k_fm_scatter(const float* __restrict__ f, int n, const int* __restrict__ start, int* __restrict__ cursor,
-                             int* __restrict__ perm) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int b = fm_bucket(f + (size_t)i * FD);
-    perm[start[b] + atomicAdd(&cursor[b], 1)] = i;   // order inside a bucket is irrelevant to the result
+__global__ __launch_bounds__(FMP_SORT_BLOCK)
+void k_fm_scatter(const int* __restrict__ bucket_of, int n, const int* __restrict__ start, int* __restrict__ cursor,
+                  int* __restrict__ perm) {
+    __shared__ int h[FMP_BUCKETS];      // rows of this workgroup per bucket, then the workgroup's base inside the bucket
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
+    int b = 0, local = 0;
+    if (i < n) { b = bucket_of[i]; local = atomicAdd(&h[b], 1); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < FMP_BUCKETS; c += FMP_SORT_BLOCK) if (h[c]) h[c] = atomicAdd(&cursor[c], h[c]);
+    __syncthreads();
+    if (i < n) perm[start[b] + h[b] + local] = i;   // order inside a bucket is irrelevant to the result
 }
 __global__ void k_fm_gather_targets(const float* __restrict__ ft, const int* __restrict__ perm, int nt, int nt_pad,
                                     float* __restrict__ T, int* __restrict__ torig) {
@@ -252,15 +272,17 @@ namespace {
 // counting sort of n descriptors by key bucket: perm (ordered position -> row) and, optionally, the bucket starts
 int fm_order(tdv_ctx* ctx, const float* d_f, int n, int* perm, int* start /* FMP_BUCKETS + 1 */) {
     hipStream_t s = ctx->stream;
-    int *hist, *cursor, *d_total;
+    int *hist, *cursor, *d_total, *bucket_of;
     TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &hist));
     TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &cursor));
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &bucket_of));
     TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
-    k_fm_hist<<<(n + 255) / 256, 256, 0, s>>>(d_f, n, hist);
+    const int blocks = (n + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
+    k_fm_hist<<<blocks, FMP_SORT_BLOCK, 0, s>>>(d_f, n, bucket_of, hist);
     TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
-    k_fm_scatter<<<(n + 255) / 256, 256, 0, s>>>(d_f, n, start, cursor, perm);
+    k_fm_scatter<<<blocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, n, start, cursor, perm);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
