@@ -3,10 +3,12 @@
 // Replaces Registration::ransacRegistration (/root/reference/src/registration.cpp:204-295), which
 // has no GPU entry point in the reference (src/pipeline.cpp:97-102 calls the CPU static directly).
 // Sub-steps and their kernels:
-//  (i)   feature correspondences (registration.cpp:216-232): k_feature_match_scan — 33-D squared
-//        distance accumulated in d order without FMA, strict <, lowest j wins; source descriptors
-//        live in VGPRs (FM_SPL per lane), target descriptors are broadcast through the scalar
-//        data path (wave-uniform s_load of 33 floats per target).  VALU-bound: 98 ops per pair.
+//  (i)   feature correspondences (registration.cpp:216-232): 33-D squared distance accumulated in d
+//        order without FMA, strict <, lowest j wins; source descriptors live in VGPRs, target
+//        descriptors are broadcast through the scalar data path (wave-uniform s_load of 33 floats
+//        per target), 98 VALU ops per pair.  k_feature_match_scan is the plain scan (small problems);
+//        k_feature_match_pruned visits key-ordered targets and skips 64-target boxes by an exact
+//        33-D lower bound (same correspondences).
 //  (ii)  index triples (registration.cpp:235-239): host, mt19937 + Lemire (ctx.hip), one batch at
 //        a time; a batch is uploaded as int4 (i0,i1,i2,valid).
 //  (iii) k_ransac_hypotheses: one lane per hypothesis — centroids, H = S_c T_c^T, Jacobi SVD,

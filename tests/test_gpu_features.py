@@ -92,9 +92,9 @@ def test_registration_operator_api_chain(tdv, orc, synth):
 
 
 def test_knn_massive_ties_exercise_the_fallbacks(ctx, orc, synth):
-    """More candidates at exactly the k-th distance than a candidate row holds (128): the collect scan overflows,
-    bound tightening cannot make progress on an exact tie, and the streaming scan must finish those queries.
-    (d2, idx) order still decides: the lowest indices win."""
+    """More candidates at exactly the k-th distance than a query's candidate row holds (128): the row overflows
+    repeatedly, and cutting it to the best k cannot lower the bound below the tie.  (d2, idx) order still decides:
+    the lowest indices win."""
     pts = _cloud(synth, 1200)
     dup = np.tile(pts[7], (300, 1))                       # 300 exact copies of point 7 (indices 1200..1499)
     pts = np.concatenate([pts, dup], 0).astype(np.float32)
