@@ -176,61 +176,64 @@ constexpr int QW_WAVES = KN_BLOCK / 64;
 constexpr int QW_SEED_SPAN = 1;
 constexpr bool QW_BEST_FIRST = true;
 
-__device__ __forceinline__ bool key_less(unsigned ahi, unsigned alo, unsigned bhi, unsigned blo) {
-    return ahi < bhi || (ahi == bhi && alo < blo);
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int j) {
+    const unsigned lo = __shfl_xor((unsigned)v, j, 64), hi = __shfl_xor((unsigned)(v >> 32), j, 64);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
-// ascending bitonic sort of the first nsort (64, 128, ... 64*R; wave-uniform) keys of a wave; element i = r*64 + lane.
-// Keys are distinct (distinct indices) except the ~0 padding, which sorts last.
-template <int R>
-__device__ __forceinline__ void wave_sort_keys(unsigned (&hi)[R], unsigned (&lo)[R], int nsort, int lane) {
-    for (int kk = 2; kk <= nsort; kk <<= 1) {
+// Ascending bitonic sort of the first NSORT (64, 128, ... 64*R) keys of a wave; element i = r*64 + lane.  The
+// network is fully unrolled (compile-time strides: the exchanges become DPP / swizzle / permute with constant
+// patterns and the direction masks fold to one bit test each).  Keys are distinct (distinct indices) except the ~0
+// padding, which sorts last.
+template <int R, int NSORT>
+__device__ __forceinline__ void wave_sort_keys_fixed(unsigned long long (&key)[R], int lane) {
+#pragma unroll
+    for (int kk = 2; kk <= NSORT; kk <<= 1) {
+#pragma unroll
         for (int j = kk >> 1; j >= 1; j >>= 1) {
             if (j >= 64) {   // partner is another key of the same lane
+                const int dr = j >> 6;
 #pragma unroll
-                for (int dr = R / 2; dr >= 1; dr >>= 1) {
-                    if (j != dr * 64) continue;
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        if ((r & dr) != 0 || (r + dr) * 64 >= nsort) continue;
-                        const bool asc = ((r * 64 + lane) & kk) == 0;
-                        const bool hi_less = key_less(hi[r + dr], lo[r + dr], hi[r], lo[r]);
-                        const bool swap = asc ? hi_less : !hi_less;
-                        const unsigned th = hi[r], tl = lo[r];
-                        hi[r] = swap ? hi[r + dr] : hi[r]; lo[r] = swap ? lo[r + dr] : lo[r];
-                        hi[r + dr] = swap ? th : hi[r + dr]; lo[r + dr] = swap ? tl : lo[r + dr];
-                    }
+                for (int r = 0; r < R; ++r) {
+                    if ((r & dr) != 0 || (r + dr) * 64 >= NSORT) continue;
+                    const bool asc = ((r * 64) & kk) == 0;   // kk >= 128 here: the bit lies in r, not in the lane
+                    const bool swap = asc == (key[r + dr] < key[r]);
+                    const unsigned long long a = key[r], c = key[r + dr];
+                    key[r] = swap ? c : a;
+                    key[r + dr] = swap ? a : c;
                 }
             } else {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
-                    if (r * 64 >= nsort) continue;
-                    const int i = r * 64 + lane;
-                    const unsigned phi = __shfl_xor(hi[r], j, 64), plo = __shfl_xor(lo[r], j, 64);
-                    const bool keep_min = ((i & kk) == 0) == ((i & j) == 0);
-                    const bool p_less = key_less(phi, plo, hi[r], lo[r]);
-                    const bool take = keep_min ? p_less : !p_less;
-                    hi[r] = take ? phi : hi[r]; lo[r] = take ? plo : lo[r];
+                    if (r * 64 >= NSORT) continue;
+                    const unsigned long long other = shfl_xor_u64(key[r], j);
+                    const bool keep_min = ((((r * 64) | lane) & kk) == 0) == ((lane & j) == 0);
+                    key[r] = ((other < key[r]) == keep_min) ? other : key[r];
                 }
             }
         }
     }
 }
-
-__device__ __forceinline__ int sort_span(int m) { int s = 64; while (s < m) s <<= 1; return s; }
+template <int R>
+__device__ __forceinline__ void wave_sort_keys(unsigned long long (&key)[R], int m, int lane) {
+    // the span is wave-uniform: the smallest power-of-two multiple of 64 that holds m keys
+    if (m <= 64) wave_sort_keys_fixed<R, 64>(key, lane);
+    else if (R >= 2 && m <= 128) wave_sort_keys_fixed<R, (R >= 2 ? 128 : 64)>(key, lane);
+    else if (R >= 4 && m <= 256) wave_sort_keys_fixed<R, (R >= 4 ? 256 : 64)>(key, lane);
+    else wave_sort_keys_fixed<R, 64 * R>(key, lane);
+}
 
 // row[0..m) -> registers, sorted ascending
 template <int R>
-__device__ __forceinline__ void load_sort_row(const unsigned long long* row, int m, int lane, unsigned (&hi)[R], unsigned (&lo)[R]) {
+__device__ __forceinline__ void load_sort_row(const unsigned long long* row, int m, int lane, unsigned long long (&key)[R]) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the row was written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = r * 64 + lane;
-        const unsigned long long key = e < m ? row[e] : ~0ull;
-        hi[r] = (unsigned)(key >> 32); lo[r] = (unsigned)key;
+        key[r] = e < m ? row[e] : ~0ull;
     }
-    wave_sort_keys<R>(hi, lo, sort_span(m), lane);
+    wave_sort_keys<R>(key, m, lane);
 }
 
 // lists[original index * stride + r] = the first min(k, found) targets in (d2, idx) order with d2 <= bound
@@ -255,14 +258,14 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
 
     // keep the best k of the row (needs wcnt >= k) and drop the bound to the k-th
     auto compact = [&]() {
-        unsigned hi[R], lo[R];
-        load_sort_row<R>(row, wcnt, lane, hi, lo);
+        unsigned long long key[R];
+        load_sort_row<R>(row, wcnt, lane, key);
         unsigned kb = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int e = r * 64 + lane;
-            if (e < k) row[e] = ((unsigned long long)hi[r] << 32) | lo[r];
-            if (r == ((k - 1) >> 6)) kb = __shfl(hi[r], (k - 1) & 63, 64);
+            if (e < k) row[e] = key[r];
+            if (r == ((k - 1) >> 6)) kb = __shfl((unsigned)(key[r] >> 32), (k - 1) & 63, 64);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -328,14 +331,14 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
             }
         }
     }
-    unsigned hi[R], lo[R];
-    load_sort_row<R>(row, wcnt, lane, hi, lo);
+    unsigned long long key[R];
+    load_sort_row<R>(row, wcnt, lane, key);
     const int i0 = orig[sp];
     const int c = min(k, wcnt);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = r * 64 + lane;
-        if (e < c) lists[(size_t)i0 * stride + e] = (int)lo[r];   // a row per query: coalesced
+        if (e < c) lists[(size_t)i0 * stride + e] = (int)(unsigned)key[r];   // a row per query: coalesced
     }
     if (lane == 0) cnt_out[i0] = c;
 }
