@@ -256,21 +256,53 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
     float B = bound ? bound[slot] : bound0;   // wave-uniform; only ever decreases
     int wcnt = 0;                             // wave-uniform fill of the row
 
-    // keep the best k of the row (needs wcnt >= k) and drop the bound to the k-th
+    // keep the best k of the row (needs wcnt >= k) and drop the bound to the k-th.  No sort: the k-th smallest key is
+    // found by bisection on its bits with ballot counts (distance bits first, then — only when several candidates tie
+    // at that distance — the index bits), and the survivors are packed by ballot prefix.
     auto compact = [&]() {
-        unsigned long long key[R];
-        load_sort_row<R>(row, wcnt, lane, key);
-        unsigned kb = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned hi[R], lo[R]; bool has[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int e = r * 64 + lane;
-            if (e < k) row[e] = key[r];
-            if (r == ((k - 1) >> 6)) kb = __shfl((unsigned)(key[r] >> 32), (k - 1) & 63, 64);
+            has[r] = e < wcnt;
+            const unsigned long long key = has[r] ? row[e] : ~0ull;
+            hi[r] = (unsigned)(key >> 32); lo[r] = (unsigned)key;
+        }
+        auto count_if = [&](auto pred) {
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) c += __popcll(__ballot(has[r] && pred(r)));
+            return c;
+        };
+        unsigned kd = 0;   // k-th smallest distance bits: count(hi < kd) < k <= count(hi <= kd)
+        for (int b = 31; b >= 0; --b) {
+            const unsigned cand = kd | (1u << b);
+            if (count_if([&](int r) { return hi[r] < cand; }) < k) kd = cand;
+        }
+        const int below = count_if([&](int r) { return hi[r] < kd; });
+        unsigned ki = 0xffffffffu;   // among the candidates AT that distance keep the (k - below) lowest indices
+        if (count_if([&](int r) { return hi[r] <= kd; }) > k) {
+            ki = 0;
+            const int need = k - below;
+            for (int b = 31; b >= 0; --b) {
+                const unsigned cand = ki | (1u << b);
+                if (count_if([&](int r) { return hi[r] == kd && lo[r] < cand; }) < need) ki = cand;
+            }
+        }
+        int base = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const bool keep = has[r] && (hi[r] < kd || (hi[r] == kd && lo[r] <= ki));
+            const unsigned long long km = __ballot(keep);
+            if (keep) row[base + __popcll(km & ((1ull << lane) - 1ull))] = ((unsigned long long)hi[r] << 32) | lo[r];
+            base += __popcll(km);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        wcnt = k;
-        B = __uint_as_float(kb);
+        wcnt = base;   // == k
+        B = __uint_as_float(kd);
     };
     // the 64 targets of one leaf, one per lane
     auto eval_leaf = [&](int leaf) {
