@@ -162,3 +162,48 @@ def test_empty_and_degenerate_inputs(ctx, tdv):
     assert len(ctx.feature_match(np.zeros((0, 33), np.float32), np.zeros((4, 33), np.float32))) == 0
     with pytest.raises(tdv.TdvError):
         ctx.voxel_downsample(one, None, 0.0, tdv.TDV_VOXEL_ORDER_FIRST)
+
+
+# ---- BASELINE config C5's scene size: 500k points (more than 64 groups of 4096: the group loop runs twice) --------
+
+def test_searches_500k_sampled(ctx, orc, synth):
+    """kNN lists, radius lists (cap 100) and ICP correspondences on a 500k-point cloud: sampled rows against a float32
+    numpy evaluation of the reference's expression with (d2, index) ordering; pruned ICP search against the scan."""
+    n = 500000
+    pts, nrm = synth.sample_object(n, 5)
+    rng = np.random.default_rng(9)
+    sel = rng.choice(n, 120, replace=False)
+    # kNN (k = 30)
+    _, knn = ctx.estimate_normals(pts, 30, want_knn=True)
+    for i in sel[:60]:
+        d2 = _d2_f32(pts, pts[i])
+        order = np.lexsort((np.arange(n), d2))[:30]
+        assert np.array_equal(knn[i], order), i
+    # radius lists
+    radius = float(synth.mean_spacing(n)) * 5.0
+    r2 = np.float32(radius) * np.float32(radius)
+    _, nb, cnt = ctx.compute_fpfh(pts, nrm, radius, want_neighbors=True)
+    for i in sel[60:]:
+        d2 = _d2_f32(pts, pts[i])
+        inside = np.nonzero(d2 <= r2)[0]
+        order = inside[np.lexsort((inside, d2[inside]))][:100]
+        assert cnt[i] == len(order), i
+        assert np.array_equal(nb[i][:cnt[i]], order), i
+    # ICP correspondences: pruned search == scan on every row; sampled rows == oracle
+    src, T_gt = synth.make_scene(n, 5)
+    T0 = synth.perturb(T_gt)
+    thr = 0.003
+    try:
+        ctx.set_icp_search("brute")
+        cb = ctx.icp_correspondences(src, pts, T0, thr)
+        ctx.set_icp_search("pruned")
+        cp = ctx.icp_correspondences(src, pts, T0, thr)
+    finally:
+        ctx.set_icp_search("auto")
+    acc = cb["accepted"].astype(bool)
+    assert acc.sum() > n // 4
+    assert np.array_equal(cp["accepted"], cb["accepted"]) and cp["n_corr"] == cb["n_corr"]
+    assert np.array_equal(cp["corr"][acc], cb["corr"][acc])
+    assert cp["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
+    ref = orc.icp_correspondences(src[sel], pts, None, T0, thr, point_to_plane=False)
+    assert np.array_equal(cb["corr"][sel], ref["corr"]) and cb["d2"][sel].tobytes() == ref["d2"].tobytes()
