@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--big", action="store_true", help="add the 500k-point size of BASELINE config C5 (normals, FPFH, ICP)")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     import torch
@@ -99,7 +100,7 @@ def main():
              algorithmic_bytes=nbytes, hbm_GBps=nbytes / (per_call_ms * 1e-3) / 1e9,
              bytes_incl_depth_rereads=2 * B * h * w * 3 + 12 * npts)
 
-    sizes = [50000] if args.quick else [50000, 100000, 200000]
+    sizes = [50000] if args.quick else [50000, 100000, 200000] + ([500000] if args.big else [])
     for n in sizes:
         cam, mdl, mnrm = cloud(n, 42)
         d_xyz = torch.from_numpy(cam).to(dev)
@@ -139,7 +140,7 @@ def main():
             emit(op="compute_fpfh", n=n, radius=radius, mean_neighbors=float(cntt.float().mean()), wall_ms=t * 1e3,
                  scan_kernel_ms=ms / max(l, 1), scan_Tops=9.0 * n * n / (ms / max(l, 1) * 1e-3) / 1e12)
         # ---------------- R5(i) feature match
-        if want("match"):
+        if want("match") and n <= 200000:
             # model descriptors: FPFH of the model cloud (real, clustered) and random rows (unstructured: nothing to prune)
             d_mx = torch.from_numpy(mdl).to(dev); d_mn = torch.empty_like(d_mx)
             d_mdesc = torch.empty((n, 33), dtype=torch.float32, device=dev)
@@ -157,14 +158,14 @@ def main():
                      bruteforce_equivalent_Tops=98.0 * n * n / (ms / max(l, 1) * 1e-3) / 1e12, algorithmic_bytes=132 * 2 * n + 4 * n)
     # ---------------- C2: ICP 50k x 10k
     if want("icp"):
-        for (ns, nt) in [(50000, 10000)] + ([] if args.quick else [(200000, 200000)]):
+        for (ns, nt) in [(50000, 10000)] + ([] if args.quick else [(200000, 200000)]) + ([(500000, 500000)] if args.big else []):
             tgt, nrm = synth.sample_object(nt, 42)
             src, T_gt = synth.make_scene(ns, 42)
             T0 = synth.perturb(T_gt)
             d_s = torch.from_numpy(src).to(dev); d_t = torch.from_numpy(tgt).to(dev); d_n = torch.from_numpy(nrm).to(dev)
             thr = float(synth.mean_spacing(nt)) * 4
             iters = 50
-            for search in ("brute", "pruned"):
+            for search in (("pruned",) if ns > 200000 else ("brute", "pruned")):
               ctx.set_icp_search(search)
               for mode in (True, False):
                 def f():
