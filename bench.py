@@ -188,11 +188,12 @@ def main():
             except Exception:
                 return None
 
-        # k_ransac_score: per hypothesis-point 18 ops transform + 3 sub + 5 squared norm + 1 compare + 1 count = 28 VALU ops;
-        # algorithmic HBM bytes per launch: the gathered pairs once (32 B per point) + 48 B per hypothesis in, 4 B out
+        # k_ransac_score: per hypothesis-point 18 ops transform + 3 sub + 5 squared norm + 1 compare + 1 count = 28 VALU ops
+        # (issued as packed f32 pairs); algorithmic HBM bytes per launch: the packed pairs once (24 B per point) + 48 B per
+        # hypothesis in, 4 B out
         sc_hyps_per_launch = hyps_total / max(sc_launches, 1)
         sc_tops = 28.0 * n * hyps_total / max(sc_ms * 1e-3, 1e-12) / 1e12
-        sc_bytes = 32.0 * n + 52.0 * sc_hyps_per_launch
+        sc_bytes = 24.0 * n + 52.0 * sc_hyps_per_launch
         score = {
             "kernel": "k_ransac_score", "bound": "valu_f32",
             "achieved": sc_tops, "peak": VALU_PEAK_TOPS, "unit": "Tops/s (f32 VALU, FMA contraction forbidden by parity; 28 ops per hypothesis-point)",
