@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
-    "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii",
+    "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii", "tdv_load_mask_png", "tdv_load_masks_from_dir",
     "tdv_depth_to_cloud_batch_dev",
 ]
 
@@ -438,6 +438,28 @@ def load_reference_model(path, capacity=1 << 20):
     if st != 0:
         return PointCloud()
     return PointCloud(points=xyz[:n.value].copy(), colors=(rgb[:n.value].copy() if hc.value else None))
+
+
+def load_mask_png(path):
+    """One mask file as Segmentation::loadMasksFromDir reads it (grey PNG, > 10 -> 255): uint8 [h, w], or None if the file
+    cannot be decoded here (colour / palette PNG, JPEG, missing)."""
+    w = C.c_int(); h = C.c_int()
+    if lib().tdv_load_mask_png(path.encode(), None, C.c_longlong(0), C.byref(w), C.byref(h)) != 0:
+        return None
+    out = np.zeros((h.value, w.value), np.uint8)
+    if lib().tdv_load_mask_png(path.encode(), _ptr(out), C.c_longlong(out.size), C.byref(w), C.byref(h)) != 0:
+        return None
+    return out
+
+
+def load_masks_from_dir(masks_dir, width, height):
+    """Segmentation::loadMasksFromDir (src/segmentation.cpp:12-42): (masks uint8 [n, height, width], n_skipped)."""
+    n = C.c_int(); sk = C.c_int()
+    _check(None, lib().tdv_load_masks_from_dir(masks_dir.encode(), width, height, None, 0, C.byref(n), C.byref(sk)), "tdv_load_masks_from_dir")
+    out = np.zeros((n.value, height, width), np.uint8)
+    if n.value:
+        _check(None, lib().tdv_load_masks_from_dir(masks_dir.encode(), width, height, _ptr(out), n.value, C.byref(n), C.byref(sk)), "tdv_load_masks_from_dir")
+    return out, sk.value
 
 
 def pose_compose(extrinsics, T):

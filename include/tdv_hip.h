@@ -296,6 +296,16 @@ int tdv_filter_duplicates(const float* poses, int n, float min_distance, float* 
  * (the reference returns an empty cloud there). */
 int tdv_load_ply_ascii(const char* path, float* out_xyz, float* out_rgb, int capacity, int* n_out, int* has_color);
 
+/* Segmentation::loadMasksFromDir (src/segmentation.cpp:12-42): every .png/.jpg/.jpeg of `dir` in sorted order, read
+ * as 8-bit grey and thresholded (> 10 -> 255, else 0).  Decodable here: non-interlaced greyscale PNGs (colour type 0 or
+ * 4, any bit depth); colour / palette PNGs and JPEGs are skipped and counted in *n_skipped (their grey conversion
+ * depends on the image library).  tdv_load_mask_png: out may be NULL to query the size; capacity in pixels.
+ * tdv_load_masks_from_dir: masks of exactly width x height are stacked into out[n][height][width] — the layout
+ * tdv_register_batch_dev and tdv_depth_to_cloud_batch_dev take; *n_out = masks found (may exceed capacity_masks when
+ * out is NULL: count query).  A missing directory yields 0 masks, as in the reference. */
+int tdv_load_mask_png(const char* path, uint8_t* out, long long capacity, int* width, int* height);
+int tdv_load_masks_from_dir(const char* dir, int width, int height, uint8_t* out, int capacity_masks, int* n_out, int* n_skipped);
+
 #ifdef __cplusplus
 }
 #endif

@@ -107,3 +107,87 @@ def test_ply_loader_keeps_the_reference_quirk(tdv, orc, tmp_path):
     c2 = tdv.load_reference_model(str(q))
     assert c2.size() == 3 and not c2.hasColors() and np.array_equal(c2.points[:2], [[4, 5, 6], [7, 8, 9]])
     assert tdv.load_reference_model(str(tmp_path / "missing.ply")).empty()
+
+
+# ---- mask-directory loader (Segmentation::loadMasksFromDir, src/segmentation.cpp:12-42) -----------------------------
+
+def _png_bytes(pix, depth=8, alpha=False, filters=None):
+    """Encode a grey image (uint values < 2**depth, [h, w]) as a PNG with the given bit depth and per-row filter types,
+    using only zlib: an encoder independent of the decoder under test."""
+    import struct, zlib
+    h, w = pix.shape
+    ch = 2 if alpha else 1
+    rows = []
+    for y in range(h):
+        if depth == 8:
+            row = np.zeros((w, ch), np.uint8); row[:, 0] = pix[y]
+            if alpha: row[:, 1] = 200
+            raw = row.tobytes()
+        elif depth == 16:
+            row = np.zeros((w, ch), ">u2"); row[:, 0] = pix[y]
+            if alpha: row[:, 1] = 40000
+            raw = row.tobytes()
+        else:
+            bits = np.zeros(((w * depth + 7) // 8) * 8, np.uint8)
+            for x in range(w):
+                for b in range(depth):
+                    bits[x * depth + b] = (int(pix[y, x]) >> (depth - 1 - b)) & 1
+            raw = np.packbits(bits).tobytes()
+        rows.append(bytearray(raw))
+    bpp = max(1, depth * ch // 8)
+    out = bytearray(); prev = bytearray(len(rows[0]))
+    for y, cur in enumerate(rows):
+        ft = filters[y % len(filters)] if filters else 0
+        enc = bytearray(len(cur))
+        for x in range(len(cur)):
+            a = cur[x - bpp] if x >= bpp else 0; b = prev[x]; c = prev[x - bpp] if x >= bpp else 0
+            if ft == 0: p = 0
+            elif ft == 1: p = a
+            elif ft == 2: p = b
+            elif ft == 3: p = (a + b) >> 1
+            else:
+                pp = a + b - c; pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            enc[x] = (cur[x] - p) & 255
+        out.append(ft); out += enc; prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    ihdr = struct.pack(">IIBBBBB", w, h, depth, 4 if alpha else 0, 0, 0, 0)
+    comp = zlib.compress(bytes(out), 6)
+    idat = chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:])   # split IDAT on purpose
+    return b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"tEXt", b"k\x00v") + idat + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("depth,alpha", [(8, False), (8, True), (1, False), (2, False), (4, False), (16, False), (16, True)])
+def test_mask_png_decoding_and_threshold(tdv, tmp_path, depth, alpha):
+    rng = np.random.default_rng(depth * 2 + alpha)
+    h, w = 37, 53                                   # odd sizes: partial bytes at sub-byte depths
+    pix = rng.integers(0, 2 ** depth, (h, w)).astype(np.uint32)
+    pix[:5] = np.arange(w)[None, :] % (2 ** depth)  # smooth rows make every filter type non-trivial
+    p = tmp_path / "m.png"
+    p.write_bytes(_png_bytes(pix, depth, alpha, filters=[0, 1, 2, 3, 4]))
+    got = tdv.load_mask_png(str(p))
+    grey = {1: pix * 255, 2: pix * 85, 4: pix * 17, 8: pix, 16: pix >> 8}[depth]
+    assert got is not None and got.shape == (h, w)
+    assert np.array_equal(got, np.where(grey > 10, 255, 0).astype(np.uint8))
+
+
+def test_masks_from_dir_order_and_skips(tdv, tmp_path):
+    h, w = 24, 32
+    d = tmp_path / "masks"; d.mkdir()
+    imgs = {}
+    for name in ["b_mask.png", "a_mask.PNG", "c_mask.png"]:
+        pix = np.random.default_rng(len(imgs)).integers(0, 256, (h, w)).astype(np.uint32)
+        (d / name).write_bytes(_png_bytes(pix, 8, False, filters=[4, 1]))
+        imgs[name] = np.where(pix > 10, 255, 0).astype(np.uint8)
+    (d / "wrong_size.png").write_bytes(_png_bytes(np.zeros((5, 5), np.uint32)))
+    (d / "photo.jpg").write_bytes(b"\xff\xd8\xff\xe0 not decodable here")
+    (d / "notes.txt").write_text("ignored by extension")
+    masks, skipped = tdv.load_masks_from_dir(str(d), w, h)
+    assert masks.shape == (3, h, w) and skipped == 2
+    for got, name in zip(masks, sorted(imgs)):      # std::sort on the paths: byte order, "a_mask.PNG" first
+        assert np.array_equal(got, imgs[name])
+    none, sk = tdv.load_masks_from_dir(str(tmp_path / "missing"), w, h)
+    assert none.shape == (0, h, w) and sk == 0
+    assert tdv.load_mask_png(str(d / "photo.jpg")) is None
