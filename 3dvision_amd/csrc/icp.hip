@@ -481,10 +481,9 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
                                                             p.chunks_per_split, b.st, b.pd2, b.pchunk);
             }
             if (p2pl) {
-#define TDV_ACC(MM, NRM) do { if (p.acc_ppt == 4) k_icp_accumulate<MM, 4><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \
-                                   p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, fixed_iterations, b.slabs, b.ticket, nullptr, nullptr, nullptr); \
-                               else k_icp_accumulate<MM, 1><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \
-                                   p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, fixed_iterations, b.slabs, b.ticket, nullptr, nullptr, nullptr); } while (0)
+#define TDV_ACC1(MM, PP, NRM) k_icp_accumulate<MM, PP><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \
+                                   p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, fixed_iterations, b.slabs, b.ticket, nullptr, nullptr, nullptr)
+#define TDV_ACC(MM, NRM) do { if (p.acc_ppt == 8) TDV_ACC1(MM, 8, NRM); else if (p.acc_ppt == 4) TDV_ACC1(MM, 4, NRM); else if (p.acc_ppt == 2) TDV_ACC1(MM, 2, NRM); else TDV_ACC1(MM, 1, NRM); } while (0)
                 TDV_ACC(0, d_tgt_normals);
             } else {
                 TDV_ACC(1, nullptr);
