@@ -128,25 +128,46 @@ __global__ void k_feature_match_combine(int ns, int ns_pad, int nparts, const fl
 // multiplication are monotone, so lb <= fl(dist) holds exactly and no margin is needed.  Targets are visited
 // inside-out from the wave's own key position; ties keep the lowest ORIGINAL target index, as the CPU scan does.
 // The order only affects speed: any key (and the arbitrary order inside a bucket) gives the same correspondences.
-constexpr int FMP_BUCKETS = 4096;
+constexpr int FMP_KEY_BITS = 7;                       // bits per key of the 2-D Morton bucket
+constexpr int FMP_BUCKETS = 1 << (2 * FMP_KEY_BITS);   // 16384 (64 KB of LDS counters in the ordering kernels)
 constexpr int FMP_BOX = 64;
+constexpr int FMP_TWO_KEYS_MAX_TARGETS = 32768;
 
-__device__ __forceinline__ int fm_bucket(const float* __restrict__ f) {
-    float k = (f[5] + (f[16] + f[27])) * (float)FMP_BUCKETS;   // descriptors sum to 1: the key lies in [0, 1]
-    int b = (k == k) ? (int)fminf(fmaxf(k, 0.f), (float)(FMP_BUCKETS - 1)) : 0;
-    return b;
+__device__ __forceinline__ int fm_bucket(const float* __restrict__ f, int two_keys) {
+    // key 1: the three centre bins (descriptors sum to 1, so it lies in [0, 1]); key 2: the first moment of the phi
+    // sub-histogram (in [0, 10]).  two_keys: FMP_KEY_BITS bits each, interleaved (a 128 x 128 Morton grid) — measured
+    // better against a small model (C4: 128k x 9.4k, 0.71 -> 0.60 ms); else key 1 alone at full resolution — better
+    // when the target side is large (100k x 100k: 8.3 vs 9.6 ms).  An offline study on real descriptors
+    // (tools/studies/feature_match_box_pruning.py) put this pair ahead of every other cheap pair.
+    const float c1 = f[5] + (f[16] + f[27]);
+    if (!two_keys) {
+        const float k = c1 * (float)FMP_BUCKETS;
+        return (k == k) ? (int)fminf(fmaxf(k, 0.f), (float)(FMP_BUCKETS - 1)) : 0;
+    }
+    constexpr float LEVELS = (float)(1 << FMP_KEY_BITS);
+    const float k1 = c1 * LEVELS;
+    float k2 = 0.f;
+#pragma unroll
+    for (int b = 1; b < 11; ++b) k2 += (float)b * f[11 + b];
+    k2 *= LEVELS * 0.1f;
+    const unsigned a = (k1 == k1) ? (unsigned)fminf(fmaxf(k1, 0.f), LEVELS - 1.f) : 0u;
+    const unsigned c = (k2 == k2) ? (unsigned)fminf(fmaxf(k2, 0.f), LEVELS - 1.f) : 0u;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < FMP_KEY_BITS; ++i) m |= (((a >> i) & 1u) << (2 * i + 1)) | (((c >> i) & 1u) << (2 * i));
+    return (int)m;
 }
 // Real descriptors crowd a few buckets, so both passes count in an LDS histogram first (one global atomic per
 // non-empty bucket and workgroup instead of one per row).
 constexpr int FMP_SORT_BLOCK = 1024;
 __global__ __launch_bounds__(FMP_SORT_BLOCK)
-void k_fm_hist(const float* __restrict__ f, int n, int* __restrict__ bucket_of, int* __restrict__ hist) {
+void k_fm_hist(const float* __restrict__ f, int n, int two_keys, int* __restrict__ bucket_of, int* __restrict__ hist) {
     __shared__ int h[FMP_BUCKETS];
     for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
     __syncthreads();
     const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
     if (i < n) {
-        const int b = fm_bucket(f + (size_t)i * FD);
+        const int b = fm_bucket(f + (size_t)i * FD, two_keys);
         bucket_of[i] = b;
         atomicAdd(&h[b], 1);
     }
@@ -197,7 +218,7 @@ __global__ __launch_bounds__(FM_BLOCK)
 void k_feature_match_pruned(const float* __restrict__ fs, const int* __restrict__ sperm, int ns, int ns_pad,
                             const float* __restrict__ T, const int* __restrict__ torig, int nbox,
                             const float* __restrict__ bmin, const float* __restrict__ bmax, const int* __restrict__ tstart,
-                            int nsplit, float* __restrict__ pd, int* __restrict__ pj) {
+                            int two_keys, int nsplit, float* __restrict__ pd, int* __restrict__ pj) {
     const int split = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wbase = (blockIdx.x * (FM_BLOCK / 64) + wave) * (64 * SPL);   // the wave's 64*SPL consecutive ordered sources
@@ -213,7 +234,7 @@ void k_feature_match_pruned(const float* __restrict__ fs, const int* __restrict_
         best[s] = INFINITY; bj[s] = INT_MAX;
     }
     // start where the targets with the wave's own key begin
-    const int c = min(nbox - 1, tstart[__builtin_amdgcn_readfirstlane(fm_bucket(f[0]))] / FMP_BOX);
+    const int c = min(nbox - 1, tstart[__builtin_amdgcn_readfirstlane(fm_bucket(f[0], two_keys))] / FMP_BOX);
     for (int v = split; v < nbox; v += nsplit) {
         const int b = visit_inside_out(v, c, nbox);
         const float* __restrict__ lo = bmin + (size_t)b * FD;   // wave-uniform -> scalar loads
@@ -273,7 +294,7 @@ __global__ void k_feature_match_combine_lex(int ns, int ns_pad, int nparts, cons
 
 namespace {
 // counting sort of n descriptors by key bucket: perm (ordered position -> row) and, optionally, the bucket starts
-int fm_order(tdv_ctx* ctx, const float* d_f, int n, int* perm, int* start /* FMP_BUCKETS + 1 */) {
+int fm_order(tdv_ctx* ctx, const float* d_f, int n, int two_keys, int* perm, int* start /* FMP_BUCKETS + 1 */) {
     hipStream_t s = ctx->stream;
     int *hist, *cursor, *d_total, *bucket_of;
     TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &hist));
@@ -283,7 +304,7 @@ int fm_order(tdv_ctx* ctx, const float* d_f, int n, int* perm, int* start /* FMP
     TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
     const int blocks = (n + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
-    k_fm_hist<<<blocks, FMP_SORT_BLOCK, 0, s>>>(d_f, n, bucket_of, hist);
+    k_fm_hist<<<blocks, FMP_SORT_BLOCK, 0, s>>>(d_f, n, two_keys, bucket_of, hist);
     TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
     k_fm_scatter<<<blocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, n, start, cursor, perm);
     TDV_CHECK_LAUNCH(ctx);
@@ -313,12 +334,13 @@ int feature_match_pruned_dev(tdv_ctx* ctx, const float* d_fs, int ns, const floa
     TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pd));
     TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pj));
     ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
-    TDV_TRY(fm_order(ctx, d_ft, nt, tperm, tstart));
-    TDV_TRY(fm_order(ctx, d_fs, ns, sperm, sstart));
+    const int two_keys = nt <= FMP_TWO_KEYS_MAX_TARGETS ? 1 : 0;
+    TDV_TRY(fm_order(ctx, d_ft, nt, two_keys, tperm, tstart));
+    TDV_TRY(fm_order(ctx, d_fs, ns, two_keys, sperm, sstart));
     k_fm_gather_targets<<<(unsigned)(((size_t)nt_pad * FD + 255) / 256), 256, 0, s>>>(d_ft, tperm, nt, nt_pad, T, torig);
     k_fm_boxes<<<(nbox * FD + 255) / 256, 256, 0, s>>>(T, nt, nbox, bmin, bmax);
     k_feature_match_pruned<FMP_SPL><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, sperm, ns, ns_pad, T, torig, nbox, bmin, bmax, tstart,
-                                                                               nsplit, pd, pj);
+                                                                               two_keys, nsplit, pd, pj);
     k_feature_match_combine_lex<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nsplit, pd, pj, d_corr);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
