@@ -4,6 +4,8 @@
 // (src/pipeline.cpp:108-121 falls back to the CPU ICP on any exception from the GPU ICP;
 // :146-149 turns any std::exception into "instance skipped").
 #include "tdv_registration.hpp"
+#include <algorithm>
+#include <filesystem>
 #include "tdv_hip.h"
 
 #include <cstring>
@@ -137,6 +139,32 @@ RegistrationResult Registration::icpRefine(const PointCloud& source, const Point
     out.fitness = r.fitness; out.rmse = r.rmse;
     std::cout << "ICP result: fitness=" << out.fitness << ", RMSE=" << out.rmse << "\n";  // :412
     return out;
+}
+
+std::vector<Image> Segmentation::loadMasksFromDir(const std::string& masks_dir) {  // src/segmentation.cpp:12-42
+    namespace fs = std::filesystem;
+    std::vector<Image> masks;
+    std::error_code ec;
+    if (!fs::is_directory(masks_dir, ec)) {
+        std::cerr << "Mask directory not found: " << masks_dir << "\n";
+        return masks;
+    }
+    std::vector<fs::path> files;
+    for (const auto& entry : fs::directory_iterator(masks_dir, ec)) {
+        std::string ext = entry.path().extension().string();
+        std::transform(ext.begin(), ext.end(), ext.begin(), ::tolower);
+        if (ext == ".png" || ext == ".jpg" || ext == ".jpeg") files.push_back(entry.path());
+    }
+    std::sort(files.begin(), files.end());
+    for (const auto& file : files) {
+        int w = 0, h = 0;
+        if (tdv_load_mask_png(file.string().c_str(), nullptr, 0, &w, &h) != TDV_OK || w <= 0 || h <= 0) continue;  // like an empty imread
+        Image m = Image::create(h, w, 1, 1);
+        if (tdv_load_mask_png(file.string().c_str(), m.ptr<uint8_t>(), (long long)w * h, &w, &h) != TDV_OK) continue;
+        masks.push_back(std::move(m));
+    }
+    std::cout << "Loaded " << masks.size() << " masks from " << masks_dir << "\n";
+    return masks;
 }
 
 Mat4f composePose(const Mat4f& extrinsics, const Mat4f& refined) {

@@ -104,6 +104,13 @@ public:
     static void setMaxDepth(float zmax);
 };
 
+class Segmentation {  // segmentation.hpp:10-13 (the mask-directory source; the SAM client is out of scope)
+public:
+    // every .png/.jpg/.jpeg of the directory in sorted order as a binary u8 mask (> 10 -> 255); files the backend cannot
+    // decode (colour / palette PNG, JPEG) are skipped like unreadable files are in the reference
+    static std::vector<Image> loadMasksFromDir(const std::string& masks_dir);
+};
+
 // Pose composition of src/pipeline.cpp:136-137: extrinsics * T^-1.
 Mat4f composePose(const Mat4f& camera_extrinsics, const Mat4f& refined);
 
