@@ -35,7 +35,10 @@ namespace tdv {
 
 // ------------------------------------------------------------------ feature match
 constexpr int FM_SPL = 2;
-constexpr int FM_BLOCK = 256;
+#ifndef FM_BLOCK_VALUE
+#define FM_BLOCK_VALUE 256
+#endif
+constexpr int FM_BLOCK = FM_BLOCK_VALUE;
 constexpr int FM_SRC_PER_BLOCK = FM_SPL * FM_BLOCK;
 constexpr int FD = 33;
 constexpr int FM_SEED = 256;   // targets of the seeding launch
