@@ -41,7 +41,13 @@ namespace tdv {
 
 constexpr int NN_SPL = 2;      // source points per lane
 constexpr int NN_CH = 16;      // targets per chunk (one s_load_dwordx16 per coordinate)
-constexpr int NN_BLOCK = 128;    // two waves per workgroup (no LDS, no barrier): many workgroups with few target splits,
+#ifndef NN_BLOCK_VALUE
+#define NN_BLOCK_VALUE 128
+#endif
+#ifndef NN_WG_TARGET
+#define NN_WG_TARGET 12288
+#endif
+constexpr int NN_BLOCK = NN_BLOCK_VALUE;    // two waves per workgroup (no LDS, no barrier): many workgroups with few target splits,
                                  // so the per-split partials (8 B per source per split) stay small
 constexpr int NN_SRC_PER_BLOCK = NN_SPL * NN_BLOCK;
 constexpr double PRUNED_MIN_PAIRS = 1e8;   // auto mode: pruned search from this many source x target pairs ...
@@ -399,7 +405,7 @@ NnPlan make_plan(int ns, int nt) {
     p.n_chunks = p.nt_pad / NN_CH;
     p.blocks_x = p.ns_pad / NN_SRC_PER_BLOCK;
     // aim for ~12k workgroups (48 per CU: measured best at 200k x 200k) but keep >= 16 chunks (256 targets) per split
-    int want = (12288 + p.blocks_x - 1) / p.blocks_x;
+    int want = (NN_WG_TARGET + p.blocks_x - 1) / p.blocks_x;
     int max_split = std::max(1, p.n_chunks / 16);
     p.nsplit = std::max(1, std::min(std::min(want, max_split), 64));
     p.chunks_per_split = (p.n_chunks + p.nsplit - 1) / p.nsplit;
