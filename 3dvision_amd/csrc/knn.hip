@@ -170,7 +170,10 @@ __device__ __forceinline__ float box_lower_bound(const float* __restrict__ box, 
 }
 
 // ------------------------------------------------------------------ one wave per query: walk, collect, select
-constexpr int QW_WAVES = KN_BLOCK / 64;
+#ifndef QW_WAVES_VALUE
+#define QW_WAVES_VALUE 1
+#endif
+constexpr int QW_WAVES = QW_WAVES_VALUE;   // queries (waves) per workgroup of k_query_wave (measured kNN 200k: 1: 0.383 ms, 4: 0.401, 16: 0.487)
 // kNN start, measured at 50k/100k/200k (k = 30): own leaf only 0.55/0.55/1.00 ms; own leaf +-1 0.23/0.41/0.61; with nearest-leaf-first
 // inside a group 0.19/0.37/0.67 (kept: it also protects clouds of uneven density); +-2 leaves no better
 constexpr int QW_SEED_SPAN = 1;
@@ -239,7 +242,7 @@ __device__ __forceinline__ void load_sort_row(const unsigned long long* row, int
 // lists[original index * stride + r] = the first min(k, found) targets in (d2, idx) order with d2 <= bound
 // (bound = bound[slot] if given, else bound0), cnt_out[original index] = their number.  Requires k <= 64*R - 64.
 template <int R, int SEED_SPAN, bool BEST_FIRST>
-__global__ __launch_bounds__(KN_BLOCK)
+__global__ __launch_bounds__(64 * QW_WAVES)
 void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
                   const int* __restrict__ orig, int n, int n_leaf, const float* __restrict__ lbox, int n_top, const float* __restrict__ tbox,
                   const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, float bound0, int seed_own,
@@ -443,15 +446,19 @@ __global__ void k_compact_flagged(const int* __restrict__ flag, const int* __res
 
 // ------------------------------------------------------------------ FPFH (registration.cpp:133-201)
 constexpr int FP_MAXNN = 100;
+#ifndef FP_WAVES_VALUE
+#define FP_WAVES_VALUE 4
+#endif
+constexpr int FP_WAVES = FP_WAVES_VALUE;   // points (waves) per workgroup of k_spfh / k_fpfh
 
 // SPFH (registration.cpp:137-170), ONE WAVE PER POINT in curve order, one neighbour per lane: the pair features
 // (incl. the f64 atan2) are computed in parallel, and the histogram is counted with ballots — the CPU loop adds 1.0f
 // per pair, and sums of ones are exact in any order, so counting is the same arithmetic.
-__global__ __launch_bounds__(KN_BLOCK)
+__global__ __launch_bounds__(64 * FP_WAVES)
 void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, const int* __restrict__ order,
             const int* __restrict__ nbr, const int* __restrict__ nbr_cnt, float* __restrict__ spfh) {
     const int lane = threadIdx.x & 63;
-    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * (KN_BLOCK / 64) + (threadIdx.x >> 6);
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * FP_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;   // wave-uniform
     const int i = order[t];
     const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
@@ -501,12 +508,12 @@ void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n,
 // FPFH (registration.cpp:176-197), ONE WAVE PER POINT in curve order: lane d < 33 owns bin d and adds
 // w_r * spfh[j_r][d] for r = 0, 1, ... in list order (the CPU loop's order per bin); every step reads one 132-byte
 // row coalesced, and the four points of a workgroup are spatial neighbours, so most rows come from L1/L2.
-__global__ __launch_bounds__(KN_BLOCK)
+__global__ __launch_bounds__(64 * FP_WAVES)
 void k_fpfh(const float* __restrict__ xyz, int n, const int* __restrict__ order, const int* __restrict__ nbr,
             const int* __restrict__ nbr_cnt, const float* __restrict__ spfh, float* __restrict__ desc,
             int* __restrict__ nbr_out /* [n][100] or null */) {
     const int lane = threadIdx.x & 63;
-    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * (KN_BLOCK / 64) + (threadIdx.x >> 6);
+    const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * FP_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;   // wave-uniform
     const int i = order[t];
     const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
@@ -627,7 +634,7 @@ int query_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int
     hipStream_t s = ctx->stream;
     const unsigned grid = (unsigned)((nqq + QW_WAVES - 1) / QW_WAVES);
     ScopedTimer tm(ctx, timer);
-#define TDV_QW(RR) k_query_wave<RR, QW_SEED_SPAN, QW_BEST_FIRST><<<grid, KN_BLOCK, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_leaf, so.lbox, so.n_top, so.tbox, \
+#define TDV_QW(RR) k_query_wave<RR, QW_SEED_SPAN, QW_BEST_FIRST><<<grid, 64 * QW_WAVES, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_leaf, so.lbox, so.n_top, so.tbox, \
                                                             qsel, nqq, bound, bound0, seed_own, k, k, lists, cnt)
     if (k <= 64) TDV_QW(2);
     else if (k <= 192) TDV_QW(4);
@@ -672,8 +679,8 @@ int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, in
     float* spfh;
     TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
     hipStream_t s = ctx->stream;
-    k_spfh<<<(n + KN_BLOCK / 64 - 1) / (KN_BLOCK / 64), KN_BLOCK, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
-    k_fpfh<<<(n + KN_BLOCK / 64 - 1) / (KN_BLOCK / 64), KN_BLOCK, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
+    k_spfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
+    k_fpfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
     TDV_CHECK_LAUNCH(ctx);
     if (d_nbr_cnt) TDV_HIP(ctx, hipMemcpyAsync(d_nbr_cnt, cnt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return TDV_OK;
