@@ -10,6 +10,8 @@
 #include "tdv_registration.hpp"
 
 #include <chrono>
+#include <vector>
+#include <utility>
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -33,21 +35,36 @@ static std::optional<Mat4f> processInstance(const Config& cfg, const Image& mask
                                             float fx, float fy, float cx, float cy, const PointCloud& ref_cloud,
                                             const FPFHFeatures& ref_features, int instance_id) {
     auto t0 = std::chrono::high_resolution_clock::now();
+    // per-stage wall time, printed on one extra line when TDV_DEMO_STAGES is set
+    const bool stages = std::getenv("TDV_DEMO_STAGES") != nullptr;
+    std::vector<std::pair<const char*, float>> stage_ms;
+    auto mark_t = t0;
+    auto mark = [&](const char* name) {
+        auto now = std::chrono::high_resolution_clock::now();
+        stage_ms.emplace_back(name, std::chrono::duration<float, std::milli>(now - mark_t).count());
+        mark_t = now;
+    };
     std::cout << "\n--- Processing instance " << instance_id << " ---\n";
     try {
         Image scaled_depth = GPUDepth::preprocess(depth, mask, cfg.scale_to_meters);             // pipeline.cpp:43-44
+        mark("preprocess");
         size_t nonzero = 0;
         for (size_t i = 0; i < (size_t)scaled_depth.rows * scaled_depth.cols; ++i) nonzero += scaled_depth.ptr<float>()[i] != 0.f;
         if (nonzero == 0) { std::cerr << "Instance " << instance_id << ": empty depth after masking\n"; return std::nullopt; }
         GPUPointCloud::setMaxDepth(cfg.clipping_max);                                             // CPU-branch clipping (pipeline.cpp:71)
         PointCloud pcd = GPUPointCloud::generate(scaled_depth, rgb, fx, fy, cx, cy);              // :65-66
+        mark("unproject");
         if (pcd.empty()) { std::cerr << "Instance " << instance_id << ": empty point cloud\n"; return std::nullopt; }
         std::cout << "Instance " << instance_id << ": " << pcd.size() << " points\n";
         PointCloud source_down = Registration::voxelDownsample(pcd, cfg.voxel_size);              // :92
+        mark("voxel");
         Registration::estimateNormals(source_down, 30);                                           // :93
+        mark("normals");
         FPFHFeatures source_features = Registration::computeFPFH(source_down, cfg.voxel_size * 5.0f);  // :94-95
+        mark("fpfh");
         RegistrationResult coarse = Registration::ransacRegistration(source_down, ref_cloud, source_features, ref_features,
                                                                      cfg.voxel_size, cfg.ransac_max_iterations, cfg.ransac_confidence);
+        mark("ransac");
         float icp_threshold = cfg.voxel_size * cfg.icp_distance_factor;                           // :104
         RegistrationResult refined;
         if (GPURegistration::isCudaAvailable()) {
@@ -57,11 +74,17 @@ static std::optional<Mat4f> processInstance(const Config& cfg, const Image& mask
                 throw;  // the reference falls back to its CPU ICP here (:114-120); this backend has no CPU path
             }
         }
+        mark("icp");
         if (refined.fitness < cfg.min_fitness) std::cerr << "Instance " << instance_id << ": low fitness " << refined.fitness << "\n";
         Mat4f T_world_object = composePose(cfg.camera_extrinsics, refined.transformation);        // :136-137
         auto t1 = std::chrono::high_resolution_clock::now();
         float ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
         std::cout << "Instance " << instance_id << " done in " << ms << " ms (fitness=" << refined.fitness << ")\n";
+        if (stages) {
+            std::cout << "Stages [ms]:";
+            for (auto& st : stage_ms) std::cout << " " << st.first << "=" << st.second;
+            std::cout << "\n";
+        }
         return T_world_object;
     } catch (const std::exception& e) {
         std::cerr << "Instance " << instance_id << " error: " << e.what() << "\n";
