@@ -60,7 +60,15 @@ PointCloud GPUPointCloud::generate(const Image& depth, const Image& rgb, float f
     if (!device_available()) return {};  // src/gpu_impl.cpp:126
     tdv_ctx* c = ctx_or_throw();
     PointCloud pcd;
-    const int cap = depth.rows * depth.cols;
+    // exact output size from one pass over the host image (the test of src/pipeline.cpp:71), so that the by-value result
+    // is not a 22 MB zero-filled worst-case buffer
+    int cap = 0;
+    {
+        const float* z = depth.ptr<float>();
+        const size_t px = (size_t)depth.rows * depth.cols;
+        for (size_t i = 0; i < px; ++i) cap += (z[i] > 0.f && z[i] <= g_tls.zmax) ? 1 : 0;
+    }
+    if (cap == 0) return pcd;
     pcd.points.resize(cap);
     if (!rgb.empty()) pcd.colors.resize(cap);
     int n = 0;
