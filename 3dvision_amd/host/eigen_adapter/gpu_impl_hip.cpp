@@ -58,11 +58,18 @@ PointCloud GPUPointCloud::generate(const cv::Mat& depth, const cv::Mat& rgb, flo
     cv::Mat d = depth.isContinuous() ? depth : depth.clone();
     cv::Mat col = (rgb.empty() || rgb.isContinuous()) ? rgb : rgb.clone();
     PointCloud pcd;
-    const int cap = d.rows * d.cols;
+    const float max_depth = 10.0f;                                            // src/gpu_impl.cpp:97
+    // exact output size from one pass over the host image instead of a zero-filled worst-case buffer (rows * cols)
+    int cap = 0;
+    {
+        const float* z = d.ptr<float>();
+        const size_t px = (size_t)d.rows * d.cols;
+        for (size_t i = 0; i < px; ++i) cap += (z[i] > 0.f && z[i] <= max_depth) ? 1 : 0;
+    }
+    if (cap == 0) return pcd;
     pcd.points.resize(cap);
     pcd.colors.resize(cap);
     int n = 0;
-    const float max_depth = 10.0f;                                            // src/gpu_impl.cpp:97
     check(tdv_deproject(c, d.ptr<float>(), col.empty() ? nullptr : col.ptr<uint8_t>(), d.cols, d.rows, fx, fy, cx, cy, max_depth,
                         pcd.points[0].data(), col.empty() ? nullptr : pcd.colors[0].data(), cap, &n), "GPUPointCloud::generate");
     pcd.points.resize(n);
