@@ -18,6 +18,7 @@
 // reference's container on the host (same key, same hash, std::unordered_map of this libstdc++)
 // to obtain its iteration order as a list of leader indices, and permutes the means on the device.
 #include "tdv_internal.hpp"
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <unordered_map>
@@ -175,6 +176,12 @@ __global__ void k_voxel_heads(const uint4* __restrict__ rec, int n, int* __restr
     if (head) leader[r.w] = 1;
 }
 
+// leaders[rank[i]] = i for every leader i: the first point of each voxel, in input (= first-occurrence) order
+__global__ void k_voxel_leader_list(const int* __restrict__ leader, const int* __restrict__ rank, int n, int* __restrict__ leaders) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && leader[i]) leaders[rank[i]] = i;
+}
+
 // exclusive scan of n ints: per-block (1024) reduce, single-block scan of the sums, local scan
 __global__ __launch_bounds__(1024)
 void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums) {
@@ -276,6 +283,60 @@ struct VoxelKeyHash {  // the reference's combiner (registration.cpp:20-27)
         return h;
     }
 };
+
+// Iteration order of a libstdc++ std::unordered_map (unique keys, std::__detail::_Mod_range_hashing, the library's own
+// _Prime_rehash_policy object) after inserting DISTINCT keys in a given sequence — the same node-list manipulation as
+// _Hashtable::_M_insert_unique_node / _M_insert_bucket_begin / _M_rehash_aux(unique) of <bits/hashtable.h>, on index
+// arrays instead of heap nodes.  Only first occurrences change a container, so replaying the leaders (first point of
+// every voxel, in input order) reproduces the reference's voxel order exactly, at a fraction of the cost of building
+// the real map over all points; tests compare it with the real container.
+class LibstdcxxInsertionOrder {
+public:
+    explicit LibstdcxxInsertionOrder(size_t expected) { next_.reserve(expected); code_.reserve(expected); buckets_.assign(1, EMPTY); }
+    void insert(size_t code) {   // a key not inserted before
+        const int node = (int)next_.size();
+        next_.push_back(NONE); code_.push_back(code);
+        const auto saved = policy_._M_state();
+        const std::pair<bool, std::size_t> rh = policy_._M_need_rehash(buckets_.size(), (size_t)node, 1);
+        if (rh.first) { try { rehash(rh.second); } catch (...) { policy_._M_reset(saved); throw; } }
+        const size_t bkt = code % buckets_.size();
+        if (buckets_[bkt] != EMPTY) {          // after the bucket's "before" node: the new node becomes the bucket's first
+            int& after = link(buckets_[bkt]);
+            next_[node] = after; after = node;
+        } else {                               // at the very beginning of the list
+            next_[node] = head_; head_ = node;
+            if (next_[node] != NONE) buckets_[code_[next_[node]] % buckets_.size()] = node;
+            buckets_[bkt] = BEFORE_BEGIN;
+        }
+    }
+    template <class F> void for_each(F&& f) const { for (int p = head_; p != NONE; p = next_[p]) f(p); }   // p = insertion rank
+private:
+    static constexpr int NONE = -1, EMPTY = -1, BEFORE_BEGIN = -2;
+    int& link(int before) { return before == BEFORE_BEGIN ? head_ : next_[before]; }
+    void rehash(size_t n) {
+        std::vector<int> nb(n, EMPTY);
+        int p = head_; head_ = NONE;
+        size_t bbegin_bkt = 0;
+        while (p != NONE) {
+            const int nxt = next_[p];
+            const size_t bkt = code_[p] % n;
+            if (nb[bkt] == EMPTY) {
+                next_[p] = head_; head_ = p;
+                nb[bkt] = BEFORE_BEGIN;
+                if (next_[p] != NONE) nb[bbegin_bkt] = p;
+                bbegin_bkt = bkt;
+            } else {
+                int& after = nb[bkt] == BEFORE_BEGIN ? head_ : next_[nb[bkt]];
+                next_[p] = after; after = p;
+            }
+            p = nxt;
+        }
+        buckets_.swap(nb);
+    }
+    std::vector<int> next_; std::vector<size_t> code_; std::vector<int> buckets_;
+    int head_ = NONE;
+    std::__detail::_Prime_rehash_policy policy_;
+};
 }  // namespace
 
 // exclusive scan of n ints on the ctx stream; *d_total receives the sum (device pointer)
@@ -373,19 +434,45 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     TDV_TRY(ws_alloc(ctx, (size_t)v, &d_order));
     k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, v, tmp_xyz, tmp_rgb);
     TDV_CHECK_LAUNCH(ctx);
-    std::unordered_map<VoxelKey, int, VoxelKeyHash> grid;
-    for (int i = 0; i < n; ++i) {
-        VoxelKey key{static_cast<int>(std::floor(h_xyz[3 * (size_t)i] * inv)),
-                     static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 1] * inv)),
-                     static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 2] * inv))};
-        grid.emplace(key, i);  // keeps the first index; inserts in first-occurrence order like grid[key]
-    }
-    if ((int)grid.size() != v) {
-        snprintf(ctx->err, sizeof(ctx->err), "voxel: host replay found %zu voxels, device %d", grid.size(), v);
-        return TDV_ERR_INTERNAL;
-    }
+    // leaders (first point of every voxel) in input order, from the device; the host only replays those
+    int* d_leaders;
+    TDV_TRY(ws_alloc(ctx, (size_t)v, &d_leaders));
+    k_voxel_leader_list<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, n, d_leaders);
+    TDV_CHECK_LAUNCH(ctx);
+    std::vector<int> leaders((size_t)v);
+    TDV_HIP(ctx, hipMemcpyAsync(leaders.data(), d_leaders, (size_t)v * 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    static const bool real_map = getenv("TDV_VOXEL_REAL_MAP") != nullptr;   // A/B knob: the real std::unordered_map over all points
+    const auto t_host0 = std::chrono::steady_clock::now();
     std::vector<int> order_first; order_first.reserve(v);
-    for (auto& kv : grid) order_first.push_back(kv.second);
+    if (real_map) {
+        std::unordered_map<VoxelKey, int, VoxelKeyHash> grid;
+        for (int i = 0; i < n; ++i) {
+            VoxelKey key{static_cast<int>(std::floor(h_xyz[3 * (size_t)i] * inv)),
+                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 1] * inv)),
+                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 2] * inv))};
+            grid.emplace(key, i);  // keeps the first index; inserts in first-occurrence order like grid[key]
+        }
+        if ((int)grid.size() != v) {
+            snprintf(ctx->err, sizeof(ctx->err), "voxel: host replay found %zu voxels, device %d", grid.size(), v);
+            return TDV_ERR_INTERNAL;
+        }
+        for (auto& kv : grid) order_first.push_back(kv.second);
+    } else {
+        LibstdcxxInsertionOrder order((size_t)v);
+        VoxelKeyHash hasher;
+        for (int r = 0; r < v; ++r) {
+            const int i = leaders[r];
+            if (i < 0 || i >= n) { snprintf(ctx->err, sizeof(ctx->err), "voxel: bad leader index %d", i); return TDV_ERR_INTERNAL; }
+            VoxelKey key{static_cast<int>(std::floor(h_xyz[3 * (size_t)i] * inv)),
+                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 1] * inv)),
+                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 2] * inv))};
+            order.insert(hasher(key));
+        }
+        order.for_each([&](int r) { order_first.push_back(leaders[r]); });
+    }
+    if (getenv("TDV_DEBUG")) fprintf(stderr, "[tdv] voxel reference order: %d leaders replayed in %.3f ms (%s)\n", v,
+                                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), real_map ? "std::unordered_map over all points" : "emulation");
     TDV_HIP(ctx, hipMemcpyAsync(d_order, order_first.data(), (size_t)v * 4, hipMemcpyHostToDevice, s));
     k_voxel_permute<<<(v + 255) / 256, 256, 0, s>>>(tmp_xyz, tmp_rgb, rank, d_order, v, d_out_xyz, d_out_rgb);
     TDV_CHECK_LAUNCH(ctx);

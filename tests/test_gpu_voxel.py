@@ -70,3 +70,16 @@ def test_voxel_full_size_properties(ctx, synth, tdv):
     assert (np.abs(okeys - exp) <= 1).all()
     w = counts[np.argsort(first_idx)][:, None].astype(np.float64)
     assert np.allclose((out.astype(np.float64) * w).sum(0) / len(pts), pts.astype(np.float64).mean(0), atol=1e-6)
+
+
+@pytest.mark.parametrize("n,voxel", [(200000, 0.0008), (120000, 0.003), (7, 0.001), (100000, 1e-5)])
+def test_reference_order_emulation_at_size(ctx, orc, synth, tdv, n, voxel):
+    """The container-order emulation (libstdc++ node-list manipulation replayed on the leaders only) against the
+    oracle's real std::unordered_map over all points, across many rehashes (up to 200k distinct voxels), negative keys
+    and heavy sharing (many points per voxel)."""
+    pts, _ = synth.sample_object(n, 11)
+    pts = pts - np.float32(0.07)
+    ref_xyz, _, _ = orc.voxel_downsample(pts, None, voxel)
+    got_xyz, _ = ctx.voxel_downsample(pts, None, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
+    assert len(got_xyz) == len(ref_xyz)
+    assert got_xyz.tobytes() == ref_xyz.tobytes()
