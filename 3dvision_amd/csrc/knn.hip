@@ -581,9 +581,10 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     TDV_TRY(ws_alloc(ctx, (size_t)3 * pad, &soa));
     TDV_TRY(ws_alloc(ctx, (size_t)pad, &so.orig));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &bucket_of));
-    // about 8 buckets per point for a surface sample (most cells of the grid are empty), a multiple of 3 bits
+    // a few buckets per point for a surface sample (most cells of the grid are empty)
+    static const int per_point = getenv("TDV_MORTON_BUCKETS_PER_POINT") ? atoi(getenv("TDV_MORTON_BUCKETS_PER_POINT")) : 8;
     int bits = 12;
-    while (bits < MORTON_MAX_BUCKET_BITS && (1 << bits) < 8 * n) bits += 3;
+    while (bits < MORTON_MAX_BUCKET_BITS && (1ll << bits) < (long long)per_point * n) bits += 1;
     const int nbuckets = 1 << bits;
     TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &hist));
     TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &cursor));
