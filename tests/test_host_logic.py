@@ -191,3 +191,49 @@ def test_masks_from_dir_order_and_skips(tdv, tmp_path):
     none, sk = tdv.load_masks_from_dir(str(tmp_path / "missing"), w, h)
     assert none.shape == (0, h, w) and sk == 0
     assert tdv.load_mask_png(str(d / "photo.jpg")) is None
+
+
+# ---- the exactness argument of the pruned searches, checked on the CPU in IEEE float32 ------------------------------
+
+def _f32(x):
+    return np.asarray(x, np.float32)
+
+
+@pytest.mark.parametrize("scale", [1e-6, 1.0, 1e3, 1e15])
+def test_box_lower_bound_never_exceeds_a_distance(scale):
+    """csrc/knn.hip box_lower_bound / csrc/icp.hip point_box_lb: per-axis gap by ONE float subtraction, then the
+    reference's expression gx*gx + (gy*gy + gz*gz).  Float -, *, + are monotone under round-to-nearest, so the bound
+    can never exceed fl(d2) of a point inside the box — with no safety margin.  Millions of random cases, including
+    points on the box faces, queries inside the box, tiny and huge magnitudes."""
+    rng = np.random.default_rng(int(np.log10(scale) * 7) % 1000 + 5)
+    n = 400000
+    lo = _f32((rng.random((n, 3)) - 0.5) * 2 * scale)
+    ext = _f32(rng.random((n, 3)) * scale * rng.choice([0.0, 1e-7, 1e-3, 0.3], (n, 1)))
+    hi = _f32(lo + ext)
+    u = rng.random((n, 3)); u[rng.random((n, 3)) < 0.2] = 0.0; u[rng.random((n, 3)) < 0.2] = 1.0   # faces and corners too
+    t = np.minimum(np.maximum(_f32(lo + _f32(u) * (hi - lo)), lo), hi)                                 # a target inside the box
+    q = _f32((rng.random((n, 3)) - 0.5) * 3 * scale)
+    q[: n // 10] = t[: n // 10]                                                                         # queries inside / on the target
+    g = np.maximum(_f32(0), np.maximum(_f32(lo - q), _f32(q - hi)))
+    lb = _f32(g[:, 0] * g[:, 0]) + _f32(_f32(g[:, 1] * g[:, 1]) + _f32(g[:, 2] * g[:, 2]))
+    for sign in (1, -1):   # (points[i] - query) in the neighbour searches, (query - target) in ICP: same squares
+        d = _f32(sign * (t - q))
+        d2 = _f32(d[:, 0] * d[:, 0]) + _f32(_f32(d[:, 1] * d[:, 1]) + _f32(d[:, 2] * d[:, 2]))
+        assert lb.dtype == np.float32 and d2.dtype == np.float32
+        assert (lb <= d2).all()
+
+
+def test_descriptor_box_bound_never_exceeds_a_distance():
+    """k_feature_match_pruned: the same argument in 33-D with the sequential summation order of the distance loop."""
+    rng = np.random.default_rng(3)
+    n = 60000
+    lo = _f32(rng.random((n, 33)) * 0.1); hi = _f32(lo + _f32(rng.random((n, 33)) * rng.choice([0.0, 1e-6, 0.05], (n, 1))))
+    t = np.minimum(np.maximum(_f32(lo + _f32(rng.random((n, 33))) * (hi - lo)), lo), hi)
+    f = _f32(rng.random((n, 33)) * 0.15)
+    lb = np.zeros(n, np.float32); d2 = np.zeros(n, np.float32)
+    for d in range(33):
+        g = np.maximum(_f32(0), np.maximum(_f32(lo[:, d] - f[:, d]), _f32(f[:, d] - hi[:, d])))
+        lb = _f32(lb + _f32(g * g))
+        diff = _f32(f[:, d] - t[:, d])
+        d2 = _f32(d2 + _f32(diff * diff))
+    assert (lb <= d2).all()
