@@ -79,10 +79,15 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the clouds are complete before the other stream reads them
     int st_helper = TDV_OK;
     std::thread worker([&]() {
-        if (hipSetDevice(h->device) != hipSuccess) { st_helper = TDV_ERR_NO_DEVICE; return; }
-        st_helper = ws_reset(h);
-        for (int b = 1; b < n_instances && st_helper == TDV_OK; b += 2) st_helper = run_instance(h, b);
-        if (st_helper == TDV_OK && hipStreamSynchronize(h->stream) != hipSuccess) st_helper = TDV_ERR_LAUNCH;
+        try {
+            if (hipSetDevice(h->device) != hipSuccess) { st_helper = TDV_ERR_NO_DEVICE; return; }
+            st_helper = ws_reset(h);
+            for (int b = 1; b < n_instances && st_helper == TDV_OK; b += 2) st_helper = run_instance(h, b);
+            if (st_helper == TDV_OK && hipStreamSynchronize(h->stream) != hipSuccess) st_helper = TDV_ERR_LAUNCH;
+        } catch (...) {   // nothing may escape a thread
+            std::snprintf(h->err, sizeof(h->err), "exception in the helper lane");
+            st_helper = TDV_ERR_INTERNAL;
+        }
     });
     int st_main = TDV_OK;
     for (int b = 0; b < n_instances && st_main == TDV_OK; b += 2) st_main = run_instance(ctx, b);
