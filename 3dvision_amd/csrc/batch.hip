@@ -90,7 +90,12 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         }
     });
     int st_main = TDV_OK;
-    for (int b = 0; b < n_instances && st_main == TDV_OK; b += 2) st_main = run_instance(ctx, b);
+    try {
+        for (int b = 0; b < n_instances && st_main == TDV_OK; b += 2) st_main = run_instance(ctx, b);
+    } catch (...) {   // the worker must be joined whatever happens here
+        std::snprintf(ctx->err, sizeof(ctx->err), "exception in the batch lane");
+        st_main = TDV_ERR_INTERNAL;
+    }
     worker.join();
     if (st_main != TDV_OK) return st_main;
     if (st_helper != TDV_OK) { std::snprintf(ctx->err, sizeof(ctx->err), "batch lane 2: %s", h->err); return st_helper; }
