@@ -252,7 +252,7 @@ def main():
             "result_check": {"icp_fitness": float(r_icp.fitness), "icp_rmse": float(r_icp.rmse), "ransac_inliers": int(r_rs.inliers),
                              "ransac_iterations_run": int(r_rs.iterations_run)},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             from oracle import pyoracle as orc
             out["cpu_baseline"] = cpu_baseline(orc, src_np, model[:, :3].cpu().numpy(), model[:, 3:].cpu().numpy(), corr_np, T0, icp_thr, voxel, args.cpu_budget_s)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
