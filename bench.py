@@ -108,7 +108,7 @@ def main():
     model = sharding.broadcast_model(pack, n, dev)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t_b0) * 1e3
-    d_tgt = model[:, :3].contiguous(); d_nrm = model[:, 3:].contiguous()
+    d_tgt = model[:, :3].contiguous(); d_nrm = model[:, 3:6].contiguous()
     # --- this rank's scene instance ---------------------------------------------------------------
     src_np, T_gt = synth.make_scene(n, 42 + rank)
     T0 = synth.perturb(T_gt, 42 + rank)
@@ -254,7 +254,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             from oracle import pyoracle as orc
-            out["cpu_baseline"] = cpu_baseline(orc, src_np, model[:, :3].cpu().numpy(), model[:, 3:].cpu().numpy(), corr_np, T0, icp_thr, voxel, args.cpu_budget_s)
+            out["cpu_baseline"] = cpu_baseline(orc, src_np, model[:, :3].cpu().numpy(), model[:, 3:6].cpu().numpy(), corr_np, T0, icp_thr, voxel, args.cpu_budget_s)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out))
     ctx.close()
