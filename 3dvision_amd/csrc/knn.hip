@@ -335,28 +335,33 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
         if (wcnt >= k) compact();
         for (int l = seed_lo; l <= seed_hi; ++l) if (l != own) eval_leaf(l);
     }
+    // Validity is tracked explicitly (never through "+inf <= bound"): the bound itself is +inf while an unbounded
+    // search has seen fewer than k points, or for an unbounded radius.
     for (int tb = 0; tb < n_top; tb += 64) {
         const int t = tb + lane;
-        const float lbt = t < n_top ? box_lower_bound(tbox, n_top, t, qp, qp) : INFINITY;
-        unsigned long long tmask = __ballot(lbt <= B);
+        const bool t_valid = t < n_top;
+        const float lbt = t_valid ? box_lower_bound(tbox, n_top, t, qp, qp) : INFINITY;
+        unsigned long long tmask = __ballot(t_valid && lbt <= B);
         while (tmask) {
             const int bt = __ffsll((long long)tmask) - 1;
             tmask &= tmask - 1;
             if (__shfl(lbt, bt, 64) > B) continue;   // the bound may have dropped since the test
             const int u = (tb + bt) * 64 + lane;
-            float lbl = (u < n_leaf && !(u >= seed_lo && u <= seed_hi)) ? box_lower_bound(lbox, n_leaf, u, qp, qp) : INFINITY;
+            bool pending = u < n_leaf && !(u >= seed_lo && u <= seed_hi);   // a leaf of this group not evaluated yet
+            const float lbl = pending ? box_lower_bound(lbox, n_leaf, u, qp, qp) : INFINITY;
             if (BEST_FIRST && seed_own) {
                 while (true) {   // nearest leaf first: the bound tightens before the far leaves are looked at
-                    float m = lbl;
+                    const bool cand = pending && lbl <= B;
+                    if (!__any(cand)) break;
+                    float m = cand ? lbl : INFINITY;
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-                    if (!(m <= B)) break;
-                    const int bl = __ffsll((long long)__ballot(lbl == m)) - 1;
-                    if (lane == bl) lbl = INFINITY;
+                    const int bl = __ffsll((long long)__ballot(cand && lbl == m)) - 1;
+                    if (lane == bl) pending = false;
                     eval_leaf((tb + bt) * 64 + bl);
                 }
             } else {
-                unsigned long long lmask = __ballot(lbl <= B);
+                unsigned long long lmask = __ballot(pending && lbl <= B);
                 while (lmask) {
                     const int bl = __ffsll((long long)lmask) - 1;
                     lmask &= lmask - 1;

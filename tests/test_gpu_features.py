@@ -109,3 +109,32 @@ def test_knn_massive_ties_exercise_the_fallbacks(ctx, orc, synth):
     ref_d, ref_nb, ref_cnt = orc.compute_fpfh(pts, np.nan_to_num(ref_n), 0.01, want_neighbors=True)
     got_d, got_nb, got_cnt = ctx.compute_fpfh(pts, np.nan_to_num(ref_n), 0.01, want_neighbors=True)
     assert np.array_equal(got_cnt, ref_cnt) and np.array_equal(got_nb, ref_nb) and got_cnt.max() == 100
+
+
+@pytest.mark.parametrize("n,k", [(700, 200), (900, 255), (300, 255), (1500, 193)])
+def test_knn_very_large_k(ctx, orc, synth, n, k):
+    """k above 192 takes the widest candidate row (512 keys per query); k above n is clamped like the CPU's
+    std::min(k, dists.size())."""
+    pts = _cloud(synth, n, seed=9)
+    pts[5] = pts[2]
+    ref_n, ref_knn = orc.estimate_normals(pts, k, want_knn=True)
+    got_n, got_knn = ctx.estimate_normals(pts, k, want_knn=True)
+    assert np.array_equal(got_knn, ref_knn)
+    assert got_n.tobytes() == ref_n.tobytes()
+
+
+def test_unbounded_searches_small_clouds(ctx, orc, synth):
+    """Bounds that stay +inf: kNN with fewer points than k, and a radius so large that r*r overflows to +inf
+    (every point is a neighbour; the cap of 100 by (d2, idx) decides)."""
+    for n, k in ((100, 255), (64, 100), (65, 64), (3, 30)):
+        pts = _cloud(synth, n, seed=4)
+        ref_n, ref_knn = orc.estimate_normals(pts, k, want_knn=True)
+        got_n, got_knn = ctx.estimate_normals(pts, k, want_knn=True)
+        assert np.array_equal(got_knn, ref_knn), (n, k)
+    pts = _cloud(synth, 700, seed=6)
+    nrm = orc.estimate_normals(pts, 30)
+    for radius in (1e20, 1e30):
+        ref_d, ref_nb, ref_cnt = orc.compute_fpfh(pts, nrm, radius, want_neighbors=True)
+        got_d, got_nb, got_cnt = ctx.compute_fpfh(pts, nrm, radius, want_neighbors=True)
+        assert (got_cnt == 100).all() and np.array_equal(got_cnt, ref_cnt)
+        assert np.array_equal(got_nb, ref_nb)
