@@ -191,3 +191,22 @@ def test_icp_pruned_and_brute_identical_bits(ctx, synth, p2plane, thr):
     assert a.transformation.tobytes() == b.transformation.tobytes()
     assert (a.iterations, a.n_corr) == (b.iterations, b.n_corr)
     assert a.rmse == b.rmse and a.fitness == b.fitness
+
+
+@pytest.mark.parametrize("thr", [0.0, -1.0, 1e-30, 1e18])
+def test_pruned_search_threshold_edges(pruned, orc, synth, thr):
+    """Zero, negative, denormal-square and huge thresholds: the accepted set and its correspondences match the scan.
+    (A threshold whose inclusive bound is not finite falls back to the scan inside the library.)"""
+    _, tgt, nrm, _ = _pair(synth, 10, 1500)
+    src = np.concatenate([tgt[:300], tgt[300:600] + np.float32(1e-4)], 0)   # exact hits and near misses
+    T = np.eye(4, dtype=np.float32)
+    ref = orc.icp_correspondences(src, tgt, None, T, thr, point_to_plane=False)
+    got = pruned.icp_correspondences(src, tgt, T, thr)
+    acc = ref["accepted"].astype(bool)
+    assert np.array_equal(got["accepted"], ref["accepted"]) and got["n_corr"] == ref["n_corr"]
+    assert np.array_equal(got["corr"][acc], ref["corr"][acc])
+    assert got["d2"][acc].tobytes() == ref["d2"][acc].tobytes()
+    if thr == 0.0:
+        assert acc[:300].all()          # d2 = 0 passes the inclusive test
+    if thr < 0:
+        assert not acc.any()
