@@ -149,3 +149,17 @@ def test_ransac_full_size_properties(ctx, synth):
     assert valid.max() <= ns and valid.min() >= 3
     assert a.inliers >= 0.99 * ns  # some well-spread triple recovers the rigid motion
     assert synth.rotation_angle(T[:3, :3], a.transformation[:3, :3]) < 1e-3
+
+
+def test_feature_match_pruned_degenerate_rows(ctx, orc, synth):
+    """Identical descriptors everywhere (every distance ties at 0: index 0 wins), and NaN rows on either side (a NaN
+    distance never beats the running best; a NaN source keeps the CPU loop's initial index 0)."""
+    ns, nt = 4500, 2100
+    one = synth.random_features(1, 8)
+    assert (ctx.feature_match(np.repeat(one, ns, 0), np.repeat(one, nt, 0)) == 0).all()
+    fs = synth.random_features(ns, 1); ft = synth.random_features(nt, 2)
+    ft[0] = np.nan; ft[77, 5] = np.nan; fs[3] = np.nan; fs[10, 20] = np.nan
+    got = ctx.feature_match(fs, ft)
+    ref = orc.feature_match(fs, ft)
+    assert np.array_equal(got, ref)
+    assert got[3] == 0 and got[10] == 0 and not np.isin(got[np.arange(ns) != 3], [77]).any()
