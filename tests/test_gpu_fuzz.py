@@ -31,6 +31,8 @@ def _make(kind, n, rng):
         p = 1000.0 + rng.random((n, 3)) * 0.05
     elif kind == "tiny":
         p = rng.random((n, 3)) * 1e-4
+    elif kind == "identical":       # one point repeated n times: every distance ties at 0, zero-size boxes
+        p = np.tile(rng.random((1, 3)), (n, 1))
     elif kind == "mixed":
         a = rng.random((n // 2, 3)); b = np.full((n - n // 2, 3), 0.5) + rng.normal(0, 1e-6, (n - n // 2, 3))
         p = np.concatenate([a, b], 0)[rng.permutation(n)]
@@ -39,7 +41,7 @@ def _make(kind, n, rng):
     return np.ascontiguousarray(p, np.float32)
 
 
-KINDS = ["uniform", "flat", "line", "grid", "dups", "clusters", "offset", "tiny", "mixed"]
+KINDS = ["uniform", "flat", "line", "grid", "dups", "clusters", "offset", "tiny", "mixed", "identical"]
 
 
 @pytest.mark.parametrize("kind", KINDS)
