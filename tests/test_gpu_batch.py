@@ -133,3 +133,19 @@ def test_all_instance_clouds_odd_frame_scalar_path(ctx, orc):
     for b in range(B):
         ref_xyz, ref_rgb = orc.unproject(orc.depth_preprocess(raw, masks[b], 1000.0), bgr, 500, 500, 65, 48, 1.2)
         assert xyz[off[b]:off[b + 1]].tobytes() == ref_xyz.tobytes() and rgb[off[b]:off[b + 1]].tobytes() == ref_rgb.tobytes()
+
+
+@pytest.mark.parametrize("n,voxel,k", [(3, 0.01, 30), (40, 0.002, 30), (200, 0.004, 30), (3000, 0.002, 8), (5000, 0.01, 64)])
+def test_model_prep_small_clouds(ctx, tdv, synth, n, voxel, k):
+    """tdv_prepare_model_dev (one radius search shared by normals and FPFH, kNN only for the deficient points) equals
+    the three stagewise operators on clouds smaller than a leaf, smaller than k, and with k above 32."""
+    dev = torch.device("cuda", 0)
+    raw, _ = synth.sample_object(n, 13)
+    d_raw = torch.from_numpy(raw).to(dev)
+    d_mx = torch.empty_like(d_raw); d_mn = torch.empty_like(d_raw); d_mf = torch.empty((n, 33), dtype=torch.float32, device=dev)
+    nm = ctx.prepare_model_dev(d_raw.data_ptr(), n, voxel, k, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr())
+    ex, _ = ctx.voxel_downsample(raw, None, voxel, tdv.TDV_VOXEL_ORDER_FIRST)
+    assert nm == len(ex) and d_mx[:nm].cpu().numpy().tobytes() == ex.tobytes()
+    en = ctx.estimate_normals(ex, k)
+    assert d_mn[:nm].cpu().numpy().tobytes() == en.tobytes()
+    assert d_mf[:nm].cpu().numpy().tobytes() == ctx.compute_fpfh(ex, en, voxel * 5.0).tobytes()
