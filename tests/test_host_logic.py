@@ -237,3 +237,26 @@ def test_descriptor_box_bound_never_exceeds_a_distance():
         diff = _f32(f[:, d] - t[:, d])
         d2 = _f32(d2 + _f32(diff * diff))
     assert (lb <= d2).all()
+
+
+def test_mask_png_malformed_inputs_are_rejected(tdv, tmp_path):
+    """Truncated files, corrupt zlib streams, wrong signatures and unsupported colour types return None (no crash)."""
+    import struct, zlib
+    good = _png_bytes(np.random.default_rng(0).integers(0, 256, (20, 30)).astype(np.uint32), 8, False, filters=[1, 4])
+    cases = {
+        "empty.png": b"",
+        "sig_only.png": good[:8],
+        "truncated.png": good[: len(good) // 2],
+        "bad_sig.png": b"\x89PNX" + good[4:],
+        "corrupt_idat.png": good[:60] + bytes(50) + good[110:],
+    }
+    # colour type 2 (RGB) is well-formed but unsupported here
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    rgb = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 2, 2, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(2 * (1 + 6)))) + chunk(b"IEND", b"")
+    cases["rgb.png"] = rgb
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        assert tdv.load_mask_png(str(p)) is None, name
+    assert tdv.load_mask_png(str(tmp_path / "does_not_exist.png")) is None
