@@ -170,12 +170,12 @@ void k_icp_nn_pruned(const float* __restrict__ src, int ns,
             float m = lbt;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) m = fminf(m, __shfl_xor(m, off, 64));
-            if (!(m <= B)) break;
+            if (!(m <= B) || m == INFINITY) break;   // +inf marks visited / absent boxes whatever the bound is
             const int tl = __ffsll((long long)__ballot(lbt == m)) - 1;   // wave-uniform lane of that box
             if (lane == tl) lbt = INFINITY;                               // visited
             const int u = (tb + tl) * 64 + lane;
             const float lbl = u < n_leaf ? point_box_lb(lbox, n_leaf, u, px, py, pz) : INFINITY;
-            unsigned long long lmask = __ballot(lbl <= B);
+            unsigned long long lmask = __ballot(u < n_leaf && lbl <= B);
             while (lmask) {
                 const int bl = __ffsll((long long)lmask) - 1;
                 lmask &= lmask - 1;
