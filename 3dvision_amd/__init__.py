@@ -66,7 +66,8 @@ class BatchParamsC(C.Structure):
                 ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float), ("zmax", C.c_float),
                 ("voxel_size", C.c_float), ("normals_k", C.c_int), ("fpfh_radius_factor", C.c_float),
                 ("ransac_max_iterations", C.c_int), ("ransac_confidence", C.c_float), ("icp_distance_factor", C.c_float),
-                ("icp_max_iterations", C.c_int), ("point_to_plane", C.c_int), ("seed", C.c_uint32)]
+                ("icp_max_iterations", C.c_int), ("point_to_plane", C.c_int), ("seed", C.c_uint32),
+                ("voxel_order", C.c_int), ("n_frames", C.c_int), ("frame_of_instance", C.c_void_p)]
 
 
 class InstanceResultC(C.Structure):
@@ -363,19 +364,26 @@ class Context:
                                                      _ptr(d_xyz), _ptr(d_rgb), capacity, C.byref(n)), "tdv_depth_to_cloud_dev")
         return n.value
 
-    def voxel_downsample_dev(self, d_xyz, d_rgb, n, voxel, d_out_xyz, d_out_rgb, capacity):
+    def voxel_downsample_dev(self, d_xyz, d_rgb, n, voxel, d_out_xyz, d_out_rgb, capacity, order=TDV_VOXEL_ORDER_FIRST):
         m = C.c_int()
-        _check(self._h, lib().tdv_voxel_downsample_dev(self._h, _ptr(d_xyz), _ptr(d_rgb), n, C.c_float(voxel), _ptr(d_out_xyz),
+        _check(self._h, lib().tdv_voxel_downsample_dev(self._h, _ptr(d_xyz), _ptr(d_rgb), n, C.c_float(voxel), order, _ptr(d_out_xyz),
                                                        _ptr(d_out_rgb), capacity, C.byref(m)), "tdv_voxel_downsample_dev")
         return m.value
 
 
 def batch_params(width=1280, height=720, scale_to_meters=1000.0, mask_mode=TDV_MASK_THRESHOLD10, fx=900.0, fy=900.0, cx=640.0,
                  cy=360.0, zmax=1.5, voxel_size=0.001, normals_k=30, fpfh_radius_factor=5.0, ransac_max_iterations=100000,
-                 ransac_confidence=0.999, icp_distance_factor=0.4, icp_max_iterations=200, point_to_plane=True, seed=42):
-    """Defaults = include/pipeline_config.hpp + config/pipeline_config.yaml of the reference."""
-    return BatchParamsC(width, height, scale_to_meters, mask_mode, fx, fy, cx, cy, zmax, voxel_size, normals_k, fpfh_radius_factor,
-                        ransac_max_iterations, ransac_confidence, icp_distance_factor, icp_max_iterations, int(point_to_plane), seed)
+                 ransac_confidence=0.999, icp_distance_factor=0.4, icp_max_iterations=200, point_to_plane=True, seed=42,
+                 voxel_order=TDV_VOXEL_ORDER_REFERENCE, n_frames=1, frame_of_instance=None):
+    """Defaults = include/pipeline_config.hpp + config/pipeline_config.yaml of the reference; voxel_order defaults to the
+    reference's container order (the poses of Pipeline::processInstance).  frame_of_instance: int array or None."""
+    p = BatchParamsC(width, height, scale_to_meters, mask_mode, fx, fy, cx, cy, zmax, voxel_size, normals_k, fpfh_radius_factor,
+                     ransac_max_iterations, ransac_confidence, icp_distance_factor, icp_max_iterations, int(point_to_plane), seed,
+                     voxel_order, n_frames, None)
+    if frame_of_instance is not None:
+        p._frame_map = np.ascontiguousarray(frame_of_instance, np.int32)   # kept alive by the struct object
+        p.frame_of_instance = p._frame_map.ctypes.data
+    return p
 
 
 def _register_batch_dev(self, d_raw, d_bgr, d_masks, n_instances, params, d_model_xyz, d_model_normals, d_model_fpfh, n_model):
@@ -393,18 +401,19 @@ def _register_batch_dev(self, d_raw, d_bgr, d_masks, n_instances, params, d_mode
     return out
 
 
-def _prepare_model_dev(self, d_xyz, n, voxel, k, radius_factor, d_out_xyz, d_out_normals, d_out_fpfh):
+def _prepare_model_dev(self, d_xyz, n, voxel, k, radius_factor, d_out_xyz, d_out_normals, d_out_fpfh, order=TDV_VOXEL_ORDER_REFERENCE):
     m = C.c_int()
-    _check(self._h, lib().tdv_prepare_model_dev(self._h, _ptr(d_xyz), n, C.c_float(voxel), k, C.c_float(radius_factor), _ptr(d_out_xyz),
+    _check(self._h, lib().tdv_prepare_model_dev(self._h, _ptr(d_xyz), n, C.c_float(voxel), order, k, C.c_float(radius_factor), _ptr(d_out_xyz),
                                                 _ptr(d_out_normals), _ptr(d_out_fpfh), C.byref(m)), "tdv_prepare_model_dev")
     return m.value
 
 
 def _depth_to_cloud_batch_dev(self, d_raw, d_masks, d_bgr, n_instances, w, h, scale, fx, fy, cx, cy, zmax, d_xyz, d_rgb, capacity,
-                              mask_format=0, mask_mode=TDV_MASK_THRESHOLD10):
-    """All instances of one frame -> clouds back to back; returns the offsets array (n_instances + 1)."""
+                              mask_format=0, mask_mode=TDV_MASK_THRESHOLD10, n_frames=1, frame_of_instance=None):
+    """All instances of a scene -> clouds back to back; returns the offsets array (n_instances + 1)."""
     off = np.zeros(n_instances + 1, np.int32)
-    st = lib().tdv_depth_to_cloud_batch_dev(self._h, _ptr(d_raw), _ptr(d_masks), _ptr(d_bgr), n_instances, mask_format, w, h,
+    fmap = None if frame_of_instance is None else np.ascontiguousarray(frame_of_instance, np.int32)
+    st = lib().tdv_depth_to_cloud_batch_dev(self._h, _ptr(d_raw), _ptr(d_masks), _ptr(d_bgr), n_instances, mask_format, n_frames, _ptr(fmap), w, h,
                                             C.c_float(scale), mask_mode, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
                                             C.c_float(zmax), _ptr(d_xyz), _ptr(d_rgb), C.c_longlong(capacity), _ptr(off))
     _check(self._h, st, "tdv_depth_to_cloud_batch_dev")

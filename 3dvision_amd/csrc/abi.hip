@@ -126,7 +126,7 @@ int tdv_voxel_downsample(tdv_ctx* ctx, const float* xyz, const float* rgb, int n
     const int cap = std::min(capacity, n);
     if (cap) TDV_TRY(ws_alloc(ctx, (size_t)cap * 3, &d_oxyz));
     if (rgb && out_rgb && cap) TDV_TRY(ws_alloc(ctx, (size_t)cap * 3, &d_orgb));
-    int st = voxel_downsample_dev(ctx, d_xyz, d_rgb, n, voxel_size, order, xyz, d_oxyz, d_orgb, cap, n_out);
+    int st = voxel_downsample_dev(ctx, d_xyz, d_rgb, n, voxel_size, order, d_oxyz, d_orgb, cap, n_out);
     if (st != TDV_OK) return st;
     TDV_TRY(download(ctx, out_xyz, d_oxyz, (size_t)*n_out * 3));
     TDV_TRY(download(ctx, out_rgb, d_orgb, (size_t)*n_out * 3));
@@ -266,10 +266,10 @@ int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d
     return depth_to_cloud_dev(ctx, d_raw, nullptr, d_mask, d_bgr, width, height, scale, mask_mode, fx, fy, cx, cy, zmax,
                               d_xyz, d_rgb, capacity, n_out);
 }
-int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel_size,
+int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel_size, int order,
                              float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out) {
     TDV_TRY(begin(ctx));
-    return voxel_downsample_dev(ctx, d_xyz, d_rgb, n, voxel_size, TDV_VOXEL_ORDER_FIRST, nullptr, d_out_xyz, d_out_rgb, capacity, n_out);
+    return voxel_downsample_dev(ctx, d_xyz, d_rgb, n, voxel_size, order, d_out_xyz, d_out_rgb, capacity, n_out);
 }
 
 }  // extern "C"

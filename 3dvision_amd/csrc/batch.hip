@@ -18,14 +18,17 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     if (n_model > 0 && (!d_model_xyz || !d_model_fpfh)) return TDV_ERR_BAD_ARG;
     if (n_instances == 0) return TDV_OK;
     // all clouds of the frame in two launches (count + emit), back to back in one buffer
+    if (prm->voxel_order != TDV_VOXEL_ORDER_FIRST && prm->voxel_order != TDV_VOXEL_ORDER_REFERENCE) return TDV_ERR_BAD_ARG;
     std::vector<int> off((size_t)n_instances + 1, 0);
     int* d_off = nullptr;
-    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_masks, n_instances, 1, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
+    const int* d_frame_of = nullptr;
+    TDV_TRY(frame_map_dev(ctx, n_instances, prm->n_frames, prm->frame_of_instance, &d_frame_of));
+    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_frame_of, d_masks, n_instances, 1, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
                                        prm->zmax, &d_off, off.data()));
     float *all_xyz = nullptr;
     if (off[n_instances] > 0) {
         TDV_TRY(ws_alloc(ctx, (size_t)off[n_instances] * 3, &all_xyz));
-        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_masks, nullptr, n_instances, 1, prm->width, prm->height, prm->scale_to_meters,
+        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_frame_of, d_masks, nullptr, n_instances, 1, prm->width, prm->height, prm->scale_to_meters,
                                           prm->mask_mode, prm->fx, prm->fy, prm->cx, prm->cy, prm->zmax, d_off, all_xyz, nullptr));
     }
     (void)d_bgr;  // colours do not enter the registration chain (voxelDownsample keeps them, nothing downstream reads them)
@@ -41,7 +44,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         float* xyz = all_xyz + (size_t)off[b] * 3;
         float* vx; int v = 0;
         TDV_TRY(ws_alloc(c, (size_t)n * 3, &vx));
-        TDV_TRY(voxel_downsample_dev(c, xyz, nullptr, n, prm->voxel_size, TDV_VOXEL_ORDER_FIRST, nullptr, vx, nullptr, n, &v));
+        TDV_TRY(voxel_downsample_dev(c, xyz, nullptr, n, prm->voxel_size, prm->voxel_order, vx, nullptr, n, &v));
         r.n_voxels = v;
         float *nrm, *fpfh; int* corr;
         TDV_TRY(ws_alloc(c, (size_t)v * 3, &nrm));
@@ -119,26 +122,30 @@ int tdv_register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d
 }
 
 int tdv_depth_to_cloud_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr,
-                                 int n_instances, int mask_format, int width, int height, float scale, int mask_mode,
+                                 int n_instances, int mask_format, int n_frames, const int* h_frame_of_instance,
+                                 int width, int height, float scale, int mask_mode,
                                  float fx, float fy, float cx, float cy, float zmax,
                                  float* d_xyz, float* d_rgb, long long capacity, int* h_offsets) {
     if (!ctx || !d_raw || !d_masks || !h_offsets || n_instances < 0 || width < 0 || height < 0 || capacity < 0) return TDV_ERR_BAD_ARG;
+    if (mask_format != 0 && n_frames > 1) return TDV_ERR_BAD_ARG;   // a label image belongs to one frame
     TDV_HIP(ctx, hipSetDevice(ctx->device));
     ctx->err[0] = 0;
     TDV_TRY(ws_reset(ctx));
     h_offsets[0] = 0;
     if (n_instances == 0 || (size_t)width * height == 0) { for (int b = 0; b <= n_instances; ++b) h_offsets[b] = 0; return TDV_OK; }
     int* d_off = nullptr;
-    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_masks, n_instances, mask_format == 0, width, height, scale, mask_mode, zmax, &d_off, h_offsets));
+    const int* d_frame_of = nullptr;
+    TDV_TRY(frame_map_dev(ctx, n_instances, n_frames, h_frame_of_instance, &d_frame_of));
+    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_frame_of, d_masks, n_instances, mask_format == 0, width, height, scale, mask_mode, zmax, &d_off, h_offsets));
     if ((long long)h_offsets[n_instances] > capacity || (h_offsets[n_instances] > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
     if (h_offsets[n_instances] > 0)
-        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_masks, d_bgr, n_instances, mask_format == 0, width, height, scale, mask_mode,
+        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_frame_of, d_masks, d_bgr, n_instances, mask_format == 0, width, height, scale, mask_mode,
                                           fx, fy, cx, cy, zmax, d_off, d_xyz, d_rgb));
     TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TDV_OK;
 }
 
-int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_size, int normals_k, float fpfh_radius_factor,
+int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_size, int voxel_order, int normals_k, float fpfh_radius_factor,
                           float* d_out_xyz, float* d_out_normals, float* d_out_fpfh, int* n_out) {
     if (!ctx || !n_out || n < 0 || (n > 0 && (!d_xyz || !d_out_xyz || !d_out_normals || !d_out_fpfh))) return TDV_ERR_BAD_ARG;
     TDV_HIP(ctx, hipSetDevice(ctx->device));
@@ -147,7 +154,7 @@ int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_s
     *n_out = 0;
     if (n == 0) return TDV_OK;
     int v = 0;
-    TDV_TRY(voxel_downsample_dev(ctx, d_xyz, nullptr, n, voxel_size, TDV_VOXEL_ORDER_FIRST, nullptr, d_out_xyz, nullptr, n, &v));
+    TDV_TRY(voxel_downsample_dev(ctx, d_xyz, nullptr, n, voxel_size, voxel_order, d_out_xyz, nullptr, n, &v));
     TDV_TRY(normals_fpfh_dev(ctx, d_out_xyz, v, normals_k, voxel_size * fpfh_radius_factor, d_out_normals, d_out_fpfh));
     TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_out = v;

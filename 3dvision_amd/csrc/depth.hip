@@ -16,6 +16,7 @@
 #include <cmath>
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 namespace tdv {
 
@@ -224,9 +225,11 @@ int bilateral_filter_dev(tdv_ctx* ctx, const float* d_in, float* d_out, int w, i
 // back to back, each in row-major pixel order.  Grid = (pixel blocks, instances); the depth image is re-read from
 // L2 / Infinity Cache by every instance, the masks and the output stream through HBM once.
 __global__ __launch_bounds__(DP_BLOCK)
-void k_valid_count_batch(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ masks, size_t n, int stacked,
+void k_valid_count_batch(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, size_t n, int stacked,
                          float inv_scale, int mask_mode, float zmax, int* __restrict__ block_counts) {
     const int b = blockIdx.y;
+    const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
+    const uint16_t* __restrict__ raw = raw0 + frame * n;
     const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
     const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
     const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
@@ -248,11 +251,14 @@ void k_valid_count_batch(const uint16_t* __restrict__ raw, const uint8_t* __rest
 }
 
 __global__ __launch_bounds__(DP_BLOCK)
-void k_emit_batch(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ masks, const uint8_t* __restrict__ bgr,
+void k_emit_batch(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, const uint8_t* __restrict__ bgr0,
                   int width, size_t n, int stacked, float inv_scale, int mask_mode,
                   float fx, float fy, float cx, float cy, float zmax,
                   const int* __restrict__ offsets, float* __restrict__ xyz, float* __restrict__ rgb) {
     const int b = blockIdx.y;
+    const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
+    const uint16_t* __restrict__ raw = raw0 + frame * n;
+    const uint8_t* __restrict__ bgr = bgr0 ? bgr0 + frame * n * 3 : nullptr;
     const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
     const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
     const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
@@ -324,9 +330,11 @@ __device__ __forceinline__ unsigned valid_mask16(const uint16_t* __restrict__ ra
 }
 
 __global__ __launch_bounds__(DP_BLOCK)
-void k_valid_count_batch_v(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ masks, size_t n, int stacked,
+void k_valid_count_batch_v(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, size_t n, int stacked,
                            float inv_scale, int mask_mode, float zmax, int* __restrict__ block_counts) {
     const int b = blockIdx.y;
+    const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
+    const uint16_t* __restrict__ raw = raw0 + frame * n;
     const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
     const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
     const size_t i0 = (size_t)blockIdx.x * DV_PX_PER_BLOCK + (size_t)threadIdx.x * DV_PX;
@@ -341,13 +349,16 @@ void k_valid_count_batch_v(const uint16_t* __restrict__ raw, const uint8_t* __re
 }
 
 __global__ __launch_bounds__(DP_BLOCK)
-void k_emit_batch_v(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ masks, const uint8_t* __restrict__ bgr,
+void k_emit_batch_v(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, const uint8_t* __restrict__ bgr0,
                     int width, size_t n, int stacked, float inv_scale, int mask_mode,
                     float fx, float fy, float cx, float cy, float zmax,
                     const int* __restrict__ offsets, float* __restrict__ xyz, float* __restrict__ rgb) {
     __shared__ float stage[DV_PX_PER_BLOCK * 3];   // 48 KB: the workgroup's compacted points (then colours)
     __shared__ int wsum[DP_BLOCK / 64];
     const int b = blockIdx.y;
+    const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
+    const uint16_t* __restrict__ raw = raw0 + frame * n;
+    const uint8_t* __restrict__ bgr = bgr0 ? bgr0 + frame * n * 3 : nullptr;
     const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
     const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
     const size_t i0 = (size_t)blockIdx.x * DV_PX_PER_BLOCK + (size_t)threadIdx.x * DV_PX;
@@ -410,7 +421,24 @@ static bool batch_vectorisable(const uint16_t* d_raw, const uint8_t* d_masks, si
 }
 
 // pass 1 (count + scan): returns the per-instance start offsets (host, n_inst + 1 entries) and keeps the device scan
-int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, int n_inst, int stacked, int w, int h,
+// Device copy of the instance -> frame map (nullptr when every instance reads frame 0).
+int frame_map_dev(tdv_ctx* ctx, int n_inst, int n_frames, const int* h_frame_of, const int** d_frame_of) {
+    *d_frame_of = nullptr;
+    if (n_frames <= 1 || n_inst <= 0) return TDV_OK;
+    std::vector<int> f((size_t)n_inst);
+    for (int b = 0; b < n_inst; ++b) {
+        f[b] = h_frame_of ? h_frame_of[b] : (int)((long long)b * n_frames / n_inst);
+        if (f[b] < 0 || f[b] >= n_frames) return TDV_ERR_BAD_ARG;
+    }
+    int* d;
+    TDV_TRY(ws_alloc(ctx, (size_t)n_inst, &d));
+    TDV_HIP(ctx, hipMemcpyAsync(d, f.data(), (size_t)n_inst * 4, hipMemcpyHostToDevice, ctx->stream));
+    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // f is a host temporary
+    *d_frame_of = d;
+    return TDV_OK;
+}
+
+int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, int n_inst, int stacked, int w, int h,
                                float scale, int mask_mode, float zmax, int** d_offsets_out, int* h_offsets) {
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
@@ -424,8 +452,8 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_
     hipStream_t s = ctx->stream;
     {
         ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-        if (vec) k_valid_count_batch_v<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
-        else k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
+        if (vec) k_valid_count_batch_v<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
+        else k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
     }
     TDV_CHECK_LAUNCH(ctx);
     TDV_TRY(exclusive_scan_dev(ctx, counts, blocks * n_inst, offsets, d_total));
@@ -440,7 +468,7 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_
 }
 
 // pass 2 (emit) into buffers sized from pass 1
-int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr, int n_inst, int stacked,
+int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, const uint8_t* d_bgr, int n_inst, int stacked,
                               int w, int h, float scale, int mask_mode, float fx, float fy, float cx, float cy, float zmax,
                               const int* d_offsets, float* d_xyz, float* d_rgb) {
     const size_t n = (size_t)w * h;
@@ -448,9 +476,9 @@ int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t
     const bool vec = batch_vectorisable(d_raw, d_masks, n);
     const int blocks = (int)((n + (vec ? DV_PX_PER_BLOCK : DP_PX_PER_BLOCK) - 1) / (vec ? DV_PX_PER_BLOCK : DP_PX_PER_BLOCK));
     ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-    if (vec) k_emit_batch_v<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
+    if (vec) k_emit_batch_v<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
                                                                                 fx, fy, cx, cy, zmax, d_offsets, d_xyz, d_rgb);
-    else k_emit_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
+    else k_emit_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
                                                                           fx, fy, cx, cy, zmax, d_offsets, d_xyz, d_rgb);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;

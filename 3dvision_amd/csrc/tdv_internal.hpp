@@ -107,17 +107,17 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
                        const uint8_t* d_bgr, int w, int h, float scale, int mask_mode,
                        float fx, float fy, float cx, float cy, float zmax,
                        float* d_xyz, float* d_rgb, int capacity, int* n_out);
-int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, int n_inst, int stacked, int w, int h,
+int frame_map_dev(tdv_ctx* ctx, int n_inst, int n_frames, const int* h_frame_of, const int** d_frame_of);
+int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, int n_inst, int stacked, int w, int h,
                                float scale, int mask_mode, float zmax, int** d_offsets_out, int* h_offsets);
-int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr, int n_inst, int stacked,
+int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, const uint8_t* d_bgr, int n_inst, int stacked,
                               int w, int h, float scale, int mask_mode, float fx, float fy, float cx, float cy, float zmax,
                               const int* d_offsets, float* d_xyz, float* d_rgb);
 int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* d_normals, int* d_knn);
 int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
                      float* d_desc, int* d_nbr, int* d_nbr_cnt);
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                         const float* h_xyz_for_reference_order, float* d_out_xyz, float* d_out_rgb, int capacity,
-                         int* n_out);
+                         float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out);
 
 int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
 size_t sort_pow2(size_t n);

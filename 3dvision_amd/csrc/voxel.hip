@@ -15,8 +15,10 @@
 //   4. exclusive scan    : rank of every leader index = voxel position in FIRST-OCCURRENCE order
 //   5. k_voxel_means     : one lane per run, sequential sum in run order -> mean -> out[rank]
 // TDV_VOXEL_ORDER_FIRST stops here.  TDV_VOXEL_ORDER_REFERENCE additionally replays the
-// reference's container on the host (same key, same hash, std::unordered_map of this libstdc++)
-// to obtain its iteration order as a list of leader indices, and permutes the means on the device.
+// reference's container on the host (same key, same hash, the node-list manipulation of this libstdc++'s
+// std::unordered_map) to obtain its iteration order, and permutes the means on the device.  Only the first
+// point of every voxel changes a container, so the host receives 16 B per VOXEL (cell + input index) from the
+// device and nothing else: the cloud stays in HBM, which is what lets the batched chain run in the reference's order.
 #include "tdv_internal.hpp"
 #include <chrono>
 #include <cmath>
@@ -176,10 +178,14 @@ __global__ void k_voxel_heads(const uint4* __restrict__ rec, int n, int* __restr
     if (head) leader[r.w] = 1;
 }
 
-// leaders[rank[i]] = i for every leader i: the first point of each voxel, in input (= first-occurrence) order
-__global__ void k_voxel_leader_list(const int* __restrict__ leader, const int* __restrict__ rank, int n, int* __restrict__ leaders) {
+// For every leader i (the first point of each voxel), at its first-occurrence rank: its input index and its integer
+// cell — all the host needs to replay the reference's container (the cloud itself never leaves the device).
+__global__ void k_voxel_leader_list(const int* __restrict__ leader, const int* __restrict__ rank, const float* __restrict__ xyz, float inv,
+                                    int n, int4* __restrict__ leaders) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && leader[i]) leaders[rank[i]] = i;
+    if (i < n && leader[i])
+        leaders[rank[i]] = make_int4((int)floorf(xyz[3 * (size_t)i] * inv), (int)floorf(xyz[3 * (size_t)i + 1] * inv),
+                                     (int)floorf(xyz[3 * (size_t)i + 2] * inv), i);
 }
 
 // exclusive scan of n ints: per-block (1024) reduce, single-block scan of the sums, local scan
@@ -356,17 +362,17 @@ int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_
 size_t sort_pow2(size_t n) { size_t p = BT_TILE; while (p < n) p <<= 1; return p; }
 
 static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                                 const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort);
+                                 float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort);
 
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                         const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out) {
-    return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, h_xyz, d_out_xyz, d_out_rgb, capacity, n_out, false);
+                         float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out) {
+    return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false);
 }
 
 static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                                 const float* h_xyz, float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort) {
+                                 float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort) {
     if (!ctx || !n_out || n < 0 || capacity < 0 || !(voxel > 0.f) || (n > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
-    if (order == TDV_VOXEL_ORDER_REFERENCE && n > 0 && !h_xyz) return TDV_ERR_BAD_ARG;
+    if (order != TDV_VOXEL_ORDER_FIRST && order != TDV_VOXEL_ORDER_REFERENCE) return TDV_ERR_BAD_ARG;
     *n_out = 0;
     if (n == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
@@ -418,7 +424,7 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     if (hashed) TDV_HIP(ctx, hipMemcpyAsync(h_total + 1, d_too_big, 4, hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
     if (hashed && h_total[1])   // a bucket too large for the per-lane sort (very coarse grid): redo with the full sort
-        return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, h_xyz, d_out_xyz, d_out_rgb, capacity, n_out, true);
+        return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, true);
     const int v = *h_total;
     *n_out = v;
     if (v > capacity) return TDV_ERR_BAD_ARG;
@@ -434,25 +440,24 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     TDV_TRY(ws_alloc(ctx, (size_t)v, &d_order));
     k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, v, tmp_xyz, tmp_rgb);
     TDV_CHECK_LAUNCH(ctx);
-    // leaders (first point of every voxel) in input order, from the device; the host only replays those
-    int* d_leaders;
+    // leaders (first point of every voxel: cell + input index) in input order, from the device; the host only replays those
+    int4* d_leaders;
     TDV_TRY(ws_alloc(ctx, (size_t)v, &d_leaders));
-    k_voxel_leader_list<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, n, d_leaders);
+    k_voxel_leader_list<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, d_xyz, inv, n, d_leaders);
     TDV_CHECK_LAUNCH(ctx);
-    std::vector<int> leaders((size_t)v);
-    TDV_HIP(ctx, hipMemcpyAsync(leaders.data(), d_leaders, (size_t)v * 4, hipMemcpyDeviceToHost, s));
+    std::vector<int4> leaders((size_t)v);
+    TDV_HIP(ctx, hipMemcpyAsync(leaders.data(), d_leaders, (size_t)v * sizeof(int4), hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
-    static const bool real_map = getenv("TDV_VOXEL_REAL_MAP") != nullptr;   // A/B knob: the real std::unordered_map over all points
+    const bool real_map = getenv("TDV_VOXEL_REAL_MAP") != nullptr;   // A/B knob: a real std::unordered_map instead of the emulation
     const auto t_host0 = std::chrono::steady_clock::now();
     std::vector<int> order_first; order_first.reserve(v);
+    for (int r = 0; r < v; ++r)
+        if (leaders[r].w < 0 || leaders[r].w >= n) { snprintf(ctx->err, sizeof(ctx->err), "voxel: bad leader index %d", leaders[r].w); return TDV_ERR_INTERNAL; }
     if (real_map) {
+        // later members of a voxel never change the container (grid[key] finds the node), so inserting the first
+        // occurrences in input order builds exactly the reference's table
         std::unordered_map<VoxelKey, int, VoxelKeyHash> grid;
-        for (int i = 0; i < n; ++i) {
-            VoxelKey key{static_cast<int>(std::floor(h_xyz[3 * (size_t)i] * inv)),
-                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 1] * inv)),
-                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 2] * inv))};
-            grid.emplace(key, i);  // keeps the first index; inserts in first-occurrence order like grid[key]
-        }
+        for (int r = 0; r < v; ++r) grid.emplace(VoxelKey{leaders[r].x, leaders[r].y, leaders[r].z}, leaders[r].w);
         if ((int)grid.size() != v) {
             snprintf(ctx->err, sizeof(ctx->err), "voxel: host replay found %zu voxels, device %d", grid.size(), v);
             return TDV_ERR_INTERNAL;
@@ -461,18 +466,11 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     } else {
         LibstdcxxInsertionOrder order((size_t)v);
         VoxelKeyHash hasher;
-        for (int r = 0; r < v; ++r) {
-            const int i = leaders[r];
-            if (i < 0 || i >= n) { snprintf(ctx->err, sizeof(ctx->err), "voxel: bad leader index %d", i); return TDV_ERR_INTERNAL; }
-            VoxelKey key{static_cast<int>(std::floor(h_xyz[3 * (size_t)i] * inv)),
-                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 1] * inv)),
-                         static_cast<int>(std::floor(h_xyz[3 * (size_t)i + 2] * inv))};
-            order.insert(hasher(key));
-        }
-        order.for_each([&](int r) { order_first.push_back(leaders[r]); });
+        for (int r = 0; r < v; ++r) order.insert(hasher(VoxelKey{leaders[r].x, leaders[r].y, leaders[r].z}));
+        order.for_each([&](int r) { order_first.push_back(leaders[r].w); });
     }
     if (getenv("TDV_DEBUG")) fprintf(stderr, "[tdv] voxel reference order: %d leaders replayed in %.3f ms (%s)\n", v,
-                                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), real_map ? "std::unordered_map over all points" : "emulation");
+                                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), real_map ? "std::unordered_map" : "emulation");
     TDV_HIP(ctx, hipMemcpyAsync(d_order, order_first.data(), (size_t)v * 4, hipMemcpyHostToDevice, s));
     k_voxel_permute<<<(v + 255) / 256, 256, 0, s>>>(tmp_xyz, tmp_rgb, rank, d_order, v, d_out_xyz, d_out_rgb);
     TDV_CHECK_LAUNCH(ctx);

@@ -129,3 +129,109 @@ def rotation_angle(Ra, Rb):
     s = 0.5 * np.array([M[2, 1] - M[1, 2], M[0, 2] - M[2, 0], M[1, 0] - M[0, 1]])
     c = (np.trace(M) - 1) / 2
     return float(np.arctan2(np.linalg.norm(s), c))
+
+
+# --------------------------------------------------------------------------------------------------
+# Relief part: the workload of the FULL chain (voxel -> normals -> FPFH -> match -> RANSAC -> ICP).
+#
+# The cuboid above is fine for ICP- or scoring-only runs, but its faces are flat: FPFH descriptors are
+# identical over most of the surface, the reference's nearest-descriptor matching (src/registration.cpp:216-232)
+# returns arbitrary points there and no 3-point hypothesis ever collects inliers.  A part that the reference's own
+# chain can register needs local shape everywhere at the scale of the FPFH radius (5 voxels): a plate whose top is
+# a sum of anisotropic Gaussian bumps and dents of irregular size, position and orientation.  The reference model
+# is a SCAN of that part (rendered at a canonical pose and unprojected), as in a bin-picking cell: the reference
+# flips every normal towards the origin (registration.cpp:125-127), so model and scene normals only agree when both
+# clouds are seen from a viewpoint at their origin.
+class ReliefPart:
+    """Height field z = h(x, y) over [-L/2, L/2] x [-W/2, W/2] (metres), bumps drawn from PCG64(seed).
+    `feature` is the typical bump radius; keep it at 3-9 voxels of the registration's voxel size."""
+
+    def __init__(self, seed=3, L=0.12, W=0.08, feature=0.011, density=0.09):
+        rng = _rng(seed)
+        self.L, self.W = float(L), float(W)
+        nb = max(4, int(round(density * L * W / (feature * feature))))
+        b = np.empty((nb, 6))
+        for i in range(nb):  # one draw order, so that (seed, nb) fixes the part
+            bx = (rng.random() - 0.5) * L * 0.8
+            by = (rng.random() - 0.5) * W * 0.8
+            amp = (0.55 + 1.1 * rng.random()) * feature * (1.0 if rng.random() < 0.7 else -0.6)
+            sx = (0.55 + 0.9 * rng.random()) * feature
+            sy = (0.55 + 0.9 * rng.random()) * feature
+            b[i] = (bx, by, amp, sx, sy, rng.random() * np.pi)
+        self.bumps = b
+
+    def height_grid(self, step):
+        """(xs, ys, Z[len(ys), len(xs)]) on a regular grid; each bump is accumulated inside its 4.5-sigma window."""
+        xs = np.arange(-self.L / 2, self.L / 2 + 1e-9, step)
+        ys = np.arange(-self.W / 2, self.W / 2 + 1e-9, step)
+        Z = np.zeros((len(ys), len(xs)))
+        for bx, by, amp, sx, sy, rot in self.bumps:
+            r = 4.5 * max(sx, sy)
+            i0, i1 = np.searchsorted(xs, [bx - r, bx + r]); j0, j1 = np.searchsorted(ys, [by - r, by + r])
+            X, Y = np.meshgrid(xs[i0:i1], ys[j0:j1])
+            c, s = np.cos(rot), np.sin(rot)
+            u = (X - bx) * c + (Y - by) * s; v = -(X - bx) * s + (Y - by) * c
+            Z[j0:j1, i0:i1] += amp * np.exp(-0.5 * ((u / sx) ** 2 + (v / sy) ** 2))
+        return xs, ys, Z
+
+    def surface_points(self, step):
+        """Dense float64 [n,3] samples of the top surface (render input; `step` well below the pixel footprint)."""
+        xs, ys, Z = self.height_grid(step)
+        X, Y = np.meshgrid(xs, ys)
+        return np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1)
+
+
+def scan_pose(distance=0.5):
+    """Pose (part frame -> camera frame) of the reference scan: the part's top faces a camera at the origin."""
+    return make_transform([1.0, 0.0, 0.0], 180.0, (0.0, 0.0, distance)).astype(np.float64)
+
+
+def instance_pose(b, distance=0.5, tilt_deg=30.0, seed=42):
+    """Pose of instance b in the camera frame: the scan pose, tilted by up to `tilt_deg` about an in-plane axis, turned
+    by any angle about the viewing axis and shifted by a few centimetres.  Deterministic in (b, seed)."""
+    rng = _rng(seed * 7919 + b)
+    a = rng.random() * 2 * np.pi
+    tilt = make_transform([np.cos(a), np.sin(a), 0.0], tilt_deg * rng.random(), (0, 0, 0)).astype(np.float64)
+    spin = make_transform([0.0, 0.0, 1.0], 360.0 * rng.random(), (0, 0, 0)).astype(np.float64)
+    shift = np.eye(4); shift[:3, 3] = [(rng.random() - 0.5) * 0.04, (rng.random() - 0.5) * 0.04, distance * (1.0 + 0.08 * (rng.random() - 0.5))]
+    M0 = make_transform([1.0, 0.0, 0.0], 180.0, (0, 0, 0)).astype(np.float64)
+    return shift @ spin @ tilt @ M0
+
+
+def render_depth(points, pose, fx, fy, cx, cy, width, height, scale_to_meters):
+    """z-buffer splat of dense surface samples: uint16 depth (units of 1/scale_to_meters m) and the 0/255 mask of the
+    pixels hit.  Numpy; the bench renders the same way with torch on the GPU."""
+    p = points @ pose[:3, :3].T + pose[:3, 3]
+    u = np.round(p[:, 0] / p[:, 2] * fx + cx).astype(np.int64)
+    v = np.round(p[:, 1] / p[:, 2] * fy + cy).astype(np.int64)
+    ok = (u >= 0) & (u < width) & (v >= 0) & (v < height) & (p[:, 2] > 0)
+    z = np.full(height * width, np.inf)
+    np.minimum.at(z, v[ok] * width + u[ok], p[ok, 2])
+    z = z.reshape(height, width)
+    hit = np.isfinite(z)
+    depth = np.zeros((height, width), np.uint16)
+    depth[hit] = np.round(z[hit] * scale_to_meters).astype(np.uint16)
+    return depth, np.where(hit, 255, 0).astype(np.uint8)
+
+
+def pose_error(T_est, T_gt):
+    """(rotation angle in rad, translation distance in m) between two 4x4 transforms."""
+    return rotation_angle(np.asarray(T_gt)[:3, :3], np.asarray(T_est)[:3, :3]), float(
+        np.linalg.norm(np.asarray(T_gt, np.float64)[:3, 3] - np.asarray(T_est, np.float64)[:3, 3]))
+
+
+def render_depth_torch(points_t, pose, fx, fy, cx, cy, width, height, scale_to_meters):
+    """render_depth on the GPU (torch, float64): same splat, same rounding; returns (int16-viewed uint16 depth tensor
+    [H, W], uint8 mask tensor [H, W]) on the device of points_t.  Used by the benches to build hundreds of frames."""
+    import torch
+    T = torch.as_tensor(np.asarray(pose, np.float64), device=points_t.device)
+    p = points_t @ T[:3, :3].T + T[:3, 3]
+    u = torch.round(p[:, 0] / p[:, 2] * fx + cx).to(torch.int64)
+    v = torch.round(p[:, 1] / p[:, 2] * fy + cy).to(torch.int64)
+    ok = (u >= 0) & (u < width) & (v >= 0) & (v < height) & (p[:, 2] > 0)
+    z = torch.full((height * width,), float("inf"), dtype=torch.float64, device=points_t.device)
+    z.scatter_reduce_(0, (v[ok] * width + u[ok]), p[ok, 2], reduce="amin")
+    hit = torch.isfinite(z)
+    d = torch.where(hit, torch.round(z * scale_to_meters), torch.zeros_like(z)).to(torch.int32)
+    depth = torch.where(d > 32767, d - 65536, d).to(torch.int16)   # uint16 bits in an int16 tensor (torch has no uint16 arithmetic)
+    return depth.reshape(height, width), (hit.to(torch.uint8) * 255).reshape(height, width)

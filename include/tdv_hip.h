@@ -117,14 +117,18 @@ int tdv_depth_to_cloud(tdv_ctx* ctx, const uint16_t* raw, const uint8_t* mask, c
                        float fx, float fy, float cx, float cy, float zmax,
                        float* out_xyz, float* out_rgb, int capacity, int* n_out);
 
-/* All instances of one frame in two launches: n_instances masks — stacked u8 images
- * (mask_format 0, mask_mode as above) or ONE u8 label image with label b+1 for instance b (mask_format 1) — of the
- * same depth/colour frame give n_instances clouds stored back to back, each in row-major pixel order.
- * All pointers are device pointers except h_offsets (host, n_instances + 1 entries): instance b occupies points
- * [h_offsets[b], h_offsets[b+1]).  capacity = room in d_xyz/d_rgb in points; if the total exceeds it the call
- * returns TDV_ERR_BAD_ARG with h_offsets filled (so the caller can size the buffers and call again). */
+/* All instances of a scene in two launches: n_instances masks — stacked u8 images
+ * (mask_format 0, mask_mode as above) or ONE u8 label image with label b+1 for instance b (mask_format 1; one frame
+ * only) — give n_instances clouds stored back to back, each in row-major pixel order.
+ * Frames: d_raw (and d_bgr) hold n_frames images back to back (n_frames <= 1: one frame shared by every instance, the
+ * reference's case, src/pipeline.cpp:321-327); instance b reads frame h_frame_of_instance[b] (host array), or, when that
+ * is NULL, frame b * n_frames / n_instances (equal contiguous groups; n_frames == n_instances: one frame each).
+ * All pointers are device pointers except h_frame_of_instance and h_offsets (host, n_instances + 1 entries): instance b
+ * occupies points [h_offsets[b], h_offsets[b+1]).  capacity = room in d_xyz/d_rgb in points; if the total exceeds it
+ * the call returns TDV_ERR_BAD_ARG with h_offsets filled (so the caller can size the buffers and call again). */
 int tdv_depth_to_cloud_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_masks, const uint8_t* d_bgr,
-                                 int n_instances, int mask_format, int width, int height, float scale, int mask_mode,
+                                 int n_instances, int mask_format, int n_frames, const int* h_frame_of_instance,
+                                 int width, int height, float scale, int mask_mode,
                                  float fx, float fy, float cx, float cy, float zmax,
                                  float* d_xyz, float* d_rgb, long long capacity, int* h_offsets);
 
@@ -223,7 +227,9 @@ int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d
                            int width, int height, float scale, int mask_mode,
                            float fx, float fy, float cx, float cy, float zmax,
                            float* d_xyz, float* d_rgb, int capacity, int* n_out /* host */);
-int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel_size,
+/* order: TDV_VOXEL_ORDER_FIRST or TDV_VOXEL_ORDER_REFERENCE; for the latter the host receives 16 B per voxel (cell and
+ * input index of its first point) to replay the reference's container — the cloud itself stays on the device. */
+int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel_size, int order,
                              float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out /* host */);
 
 /* ---- batched, device-resident Pipeline::processInstance ------------------------
@@ -237,9 +243,12 @@ int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rg
  * the model (points, normals, FPFH) is what Pipeline::run prepares once (src/pipeline.cpp:291-294);
  * results is a HOST array of n_instances entries.  Instances whose mask leaves no depth / no points
  * get status 1 / 2 (the reference returns nullopt there, src/pipeline.cpp:57-60, :86-89).
- * Voxel order is first-occurrence (TDV_VOXEL_ORDER_FIRST): the reference's container order would
- * need the cloud on the host.  The RANSAC index stream is seeded per instance exactly as the
- * reference does (mt19937(42) restarted for every ransacRegistration call). */
+ * voxel_order: TDV_VOXEL_ORDER_REFERENCE gives, per instance, exactly what the chain of host-buffer operators (and
+ * the reference's processInstance) gives — RANSAC's mt19937 index stream picks points by position, so the pose depends
+ * on the order of the downsampled cloud; TDV_VOXEL_ORDER_FIRST skips the host replay of the reference's container
+ * (16 B per voxel over PCIe + ~15 ns per voxel of host time) and yields a different, equally valid, coarse pose.
+ * The RANSAC index stream is seeded per instance exactly as the reference does (mt19937(42) restarted for every
+ * ransacRegistration call).  Frames: as tdv_depth_to_cloud_batch_dev (n_frames, frame_of_instance). */
 typedef struct tdv_batch_params {
     int width, height;
     float scale_to_meters;      /* depth.scale_to_meters      (include/pipeline_config.hpp:18) */
@@ -254,6 +263,9 @@ typedef struct tdv_batch_params {
     int icp_max_iterations;     /* registration.icp_max_iterations                                */
     int point_to_plane;         /* registration.use_point_to_plane                                */
     uint32_t seed;              /* 42                        (src/registration.cpp:235)           */
+    int voxel_order;            /* TDV_VOXEL_ORDER_FIRST / TDV_VOXEL_ORDER_REFERENCE                */
+    int n_frames;               /* depth frames stored back to back at d_raw_depth (0 or 1: one)    */
+    const int* frame_of_instance; /* HOST array [n_instances] or NULL (b * n_frames / n_instances)   */
 } tdv_batch_params;
 
 typedef struct tdv_instance_result {
@@ -271,10 +283,10 @@ int tdv_register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw_depth, const uint
                            const uint8_t* d_masks, int n_instances, const tdv_batch_params* params,
                            const float* d_model_xyz, const float* d_model_normals, const float* d_model_fpfh, int n_model,
                            tdv_instance_result* results);
-/* Model preparation of src/pipeline.cpp:291-294 on device buffers: voxelDownsample(first-occurrence
- * order) -> estimateNormals(k) -> computeFPFH(voxel * radius_factor).  Outputs have capacity n. */
-int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_size, int normals_k, float fpfh_radius_factor,
-                          float* d_out_xyz, float* d_out_normals, float* d_out_fpfh, int* n_out /* host */);
+/* Model preparation of src/pipeline.cpp:291-294 on device buffers: voxelDownsample(voxel_order) ->
+ * estimateNormals(k) -> computeFPFH(voxel * radius_factor).  Outputs have capacity n. */
+int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_size, int voxel_order, int normals_k,
+                          float fpfh_radius_factor, float* d_out_xyz, float* d_out_normals, float* d_out_fpfh, int* n_out /* host */);
 
 /* ---- host-side helpers that are part of the path's semantics -------------------------------- */
 /* The RANSAC index stream: count triples from mt19937(seed) + Lemire uniform over [0, n-1]

@@ -1,6 +1,7 @@
 """the batched, device-resident Pipeline::processInstance (tdv_register_batch_dev) must return
 exactly what the same chain gives when each operator is called on its own through the host-buffer ABI
-(which the other test modules pin against the oracle), instance by instance."""
+(which the other test modules pin against the oracle), instance by instance — here in first-occurrence voxel order on
+the cuboid; tests/test_gpu_chain.py compares the batch in the reference's order with the oracle's whole chain."""
 import numpy as np
 import pytest
 import torch
@@ -31,14 +32,14 @@ def _scene(synth, orc, n_inst=3, w=640, h=480):
 def test_batch_equals_stagewise_chain(ctx, tdv, synth, orc):
     depth, masks, intr = _scene(synth, orc)
     voxel = 0.004
-    prm = tdv.batch_params(voxel_size=voxel, zmax=1.5, ransac_max_iterations=4000, icp_max_iterations=30, **intr)
+    prm = tdv.batch_params(voxel_size=voxel, zmax=1.5, ransac_max_iterations=4000, icp_max_iterations=30, voxel_order=tdv.TDV_VOXEL_ORDER_FIRST, **intr)
     dev = torch.device("cuda", 0)
     # model: prepared once on the device (voxel -> normals -> FPFH), as Pipeline::run does
     model_raw, _ = synth.sample_object(20000, 7)
     d_model_raw = torch.from_numpy(model_raw).to(dev)
     d_mx = torch.empty_like(d_model_raw); d_mn = torch.empty_like(d_model_raw)
     d_mf = torch.empty((len(model_raw), 33), dtype=torch.float32, device=dev)
-    nm = ctx.prepare_model_dev(d_model_raw.data_ptr(), len(model_raw), voxel, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr())
+    nm = ctx.prepare_model_dev(d_model_raw.data_ptr(), len(model_raw), voxel, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), order=tdv.TDV_VOXEL_ORDER_FIRST)
     mx = d_mx[:nm].cpu().numpy(); mn = d_mn[:nm].cpu().numpy(); mf = d_mf[:nm].cpu().numpy()
     # the model prep itself equals the stagewise ops
     ex, _ = ctx.voxel_downsample(model_raw, None, voxel, tdv.TDV_VOXEL_ORDER_FIRST)
@@ -143,7 +144,7 @@ def test_model_prep_small_clouds(ctx, tdv, synth, n, voxel, k):
     raw, _ = synth.sample_object(n, 13)
     d_raw = torch.from_numpy(raw).to(dev)
     d_mx = torch.empty_like(d_raw); d_mn = torch.empty_like(d_raw); d_mf = torch.empty((n, 33), dtype=torch.float32, device=dev)
-    nm = ctx.prepare_model_dev(d_raw.data_ptr(), n, voxel, k, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr())
+    nm = ctx.prepare_model_dev(d_raw.data_ptr(), n, voxel, k, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), order=tdv.TDV_VOXEL_ORDER_FIRST)
     ex, _ = ctx.voxel_downsample(raw, None, voxel, tdv.TDV_VOXEL_ORDER_FIRST)
     assert nm == len(ex) and d_mx[:nm].cpu().numpy().tobytes() == ex.tobytes()
     en = ctx.estimate_normals(ex, k)

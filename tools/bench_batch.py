@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""Config C4 (BASELINE.json configs[3]) on one MI355X: batched bin-picking through tdv_register_batch_dev —
-B instances, each a ~200k-pixel mask of one 1280x720 depth frame, registered against one shared model:
-depth->cloud -> voxel -> normals(k=30) -> FPFH -> feature match -> RANSAC -> ICP, all device-resident.
-Prints one JSON line (instances/s, per-stage kernel times, aggregate hyps/s and ICP iters/s).
+"""Config C4 (BASELINE.json configs[3]) on one MI355X: batched bin-picking through tdv_register_batch_dev.
 
-    python tools/bench_batch.py [--instances 16] [--model-points 10000] [--hyps 10000] [--icp-iters 50]
+B DISTINCT instances — the relief part of 3dvision_amd/synth.py at B different poses, each in its own 1280x720 depth
+frame with its own ~200k-pixel mask — are registered against one shared model (a scan of the same part, voxelised at
+the same voxel size, as Pipeline::run does, src/pipeline.cpp:291-294):
+depth->cloud -> voxel -> normals(k=30) -> FPFH -> descriptor match -> RANSAC -> ICP, all device-resident.
+Every instance's refined pose is compared with its ground truth; the run FAILS (exit 1) if any instance is further than
+--max-angle (1e-2 rad) from it, so instances/s is only ever reported for a workload that registers.
+Prints one JSON line (instances/s, per-stage kernel times, hypotheses/s, ICP iterations actually run).
+
+    python tools/bench_batch.py [--instances 32] [--hyps 10000] [--icp-iters 50] [--voxel-px 1.2] [--order first|reference]
 """
 import argparse
 import importlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -18,62 +24,77 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+W, H, F = 1280, 720, 1500.0
+CX, CY = W / 2.0, H / 2.0
+DIST = 0.45
+SCALE = 50000.0          # depth.scale_to_meters: 0.02 mm units (z = 0.45 m -> 22,500)
+ZMAX = 1.3
 
-def render(synth, model, T, f, cx, cy, w, h):
-    p = model.astype(np.float64) @ T[:3, :3].astype(np.float64).T + T[:3, 3]
-    u = np.round(p[:, 0] / p[:, 2] * f + cx).astype(int); v = np.round(p[:, 1] / p[:, 2] * f + cy).astype(int)
-    ok = (u >= 0) & (u < w) & (v >= 0) & (v < h) & (p[:, 2] > 0)
-    z = np.full((h, w), np.inf)
-    np.minimum.at(z, (v[ok], u[ok]), p[ok, 2])
-    return z
+
+def build_workload(tdv, synth, ctx, B, voxel_px, part_px, seed, order, dev):
+    """Frames, masks, ground truths and the prepared model, all on the device."""
+    import torch
+    px = DIST / F                                  # pixel footprint at the working distance (0.3 mm)
+    voxel = voxel_px * px
+    side = part_px * px                            # 448 px -> 134 mm
+    part = synth.ReliefPart(seed, L=side, W=side, feature=6.0 * voxel, density=0.09)
+    dense = torch.from_numpy(part.surface_points(px / 2.5)).to(dev)
+    M = synth.scan_pose(DIST)
+    md, mm = synth.render_depth_torch(dense, M, F, F, CX, CY, W, H, SCALE)
+    d_depth = torch.empty((B, H, W), dtype=torch.int16, device=dev)
+    d_masks = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    T_gt = []
+    for b in range(B):
+        S = synth.instance_pose(b, DIST, 30.0)
+        d_depth[b], d_masks[b] = synth.render_depth_torch(dense, S, F, F, CX, CY, W, H, SCALE)
+        T_gt.append(M @ np.linalg.inv(S))
+    # model: scan -> cloud -> voxel -> normals -> FPFH (Pipeline::run :291-294)
+    n_px = int((mm > 0).sum())
+    d_mraw = torch.empty((n_px, 3), dtype=torch.float32, device=dev)
+    n_raw = ctx.depth_to_cloud_dev(md.data_ptr(), mm.data_ptr(), None, W, H, SCALE, F, F, CX, CY, ZMAX, d_mraw.data_ptr(), None, n_px)
+    d_mx = torch.empty_like(d_mraw); d_mn = torch.empty_like(d_mraw); d_mf = torch.empty((n_raw, 33), dtype=torch.float32, device=dev)
+    nm = ctx.prepare_model_dev(d_mraw.data_ptr(), n_raw, voxel, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), order=order)
+    return dict(depth=d_depth, masks=d_masks, T_gt=T_gt, model=(d_mx, d_mn, d_mf, nm), voxel=voxel, bumps=len(part.bumps),
+                mask_px=[int(x) for x in (d_masks > 0).sum((1, 2)).tolist()])
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--instances", type=int, default=16)
-    ap.add_argument("--model-points", type=int, default=10000)
+    ap.add_argument("--instances", type=int, default=32)
     ap.add_argument("--hyps", type=int, default=10000)
     ap.add_argument("--icp-iters", type=int, default=50)
-    ap.add_argument("--voxel", type=float, default=0.0005)
-    ap.add_argument("--threads", type=int, default=1,
-                    help="host threads, one tdv_ctx (stream + workspace) each, sharing the instances — the reference's thread-pool shape")
-    ap.add_argument("--matched", action="store_true",
-                    help="scene and model voxelised at the same 1 mm (as pipeline.cpp does with one voxel_size): smaller clouds, "
-                         "but the registration is well-posed, so angle_to_gt is meaningful")
+    ap.add_argument("--voxel-px", type=float, default=1.2, help="voxel size in pixel footprints (the reference's demo: 1 mm / 0.89 mm = 1.12)")
+    ap.add_argument("--part-px", type=int, default=448, help="side of the part in pixels at the working distance (448^2 = 200,704 px)")
+    ap.add_argument("--icp-factor", type=float, default=0.4, help="registration.icp_distance_factor (include/pipeline_config.hpp:28)")
+    ap.add_argument("--confidence", type=float, default=0.999)
+    ap.add_argument("--order", choices=["first", "reference"], default="reference")
+    ap.add_argument("--threads", type=int, default=1, help="host threads, one tdv_ctx each, sharing the instances (the reference's thread pool)")
+    ap.add_argument("--max-angle", type=float, default=1e-2)
+    ap.add_argument("--seed", type=int, default=3)
     args = ap.parse_args()
-    if args.matched:
-        args.voxel = 0.001
     import torch
     tdv = importlib.import_module("3dvision_amd")
     synth = importlib.import_module("3dvision_amd.synth")
     dev = torch.device("cuda", 0)
     ctx = tdv.Context(0)
-    w, h, f = 1280, 720, 1500.0
-    cx, cy = w / 2.0, h / 2.0
-    # one object filling ~448x448 px: dense surface samples rendered through a z-buffer, holes closed by oversampling
-    dense, _ = synth.sample_object(3000000, 42)
-    T = synth.make_transform([0.2, 1.0, 0.3], 35.0, (0.0, 0.0, 0.45))
-    z = render(synth, dense, T, f, cx, cy, w, h)
-    hit = np.isfinite(z)
-    depth = np.zeros((h, w), np.uint16); depth[hit] = np.round(z[hit] * 1000.0).astype(np.uint16)
-    mask = np.where(hit, 255, 0).astype(np.uint8)
     B = args.instances
-    masks = np.repeat(mask[None], B, 0)
-    model_raw, _ = synth.sample_object(600000 if args.matched else args.model_points * 3, 7)
-    d_raw = torch.from_numpy(model_raw).to(dev)
-    d_mx = torch.empty_like(d_raw); d_mn = torch.empty_like(d_raw); d_mf = torch.empty((len(model_raw), 33), dtype=torch.float32, device=dev)
-    mvox = args.voxel if args.matched else float(synth.mean_spacing(args.model_points))
-    nm = ctx.prepare_model_dev(d_raw.data_ptr(), len(model_raw), mvox, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr())
-    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev)
-    prm = tdv.batch_params(width=w, height=h, fx=f, fy=f, cx=cx, cy=cy, zmax=1.5, voxel_size=args.voxel,
-                           ransac_max_iterations=args.hyps, ransac_confidence=2.0, icp_max_iterations=args.icp_iters, icp_distance_factor=4.0)
-    import threading
+    order = tdv.TDV_VOXEL_ORDER_REFERENCE if args.order == "reference" else tdv.TDV_VOXEL_ORDER_FIRST
+    t_build = time.perf_counter()
+    wl = build_workload(tdv, synth, ctx, B, args.voxel_px, args.part_px, args.seed, order, dev)
+    t_build = time.perf_counter() - t_build
+    d_mx, d_mn, d_mf, nm = wl["model"]
     nthr = max(1, args.threads)
     ctxs = [ctx] + [tdv.Context(0) for _ in range(nthr - 1)]
     share = [B // nthr + (1 if t < B % nthr else 0) for t in range(nthr)]
     offs = [sum(share[:t]) for t in range(nthr)]
+
+    def params(n):
+        return tdv.batch_params(width=W, height=H, scale_to_meters=SCALE, fx=F, fy=F, cx=CX, cy=CY, zmax=ZMAX, voxel_size=wl["voxel"],
+                                ransac_max_iterations=args.hyps, ransac_confidence=args.confidence, icp_max_iterations=args.icp_iters,
+                                icp_distance_factor=args.icp_factor, voxel_order=order, n_frames=n)
+
     for c in ctxs:   # warm-up: arena growth, code load
-        c.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 1, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+        c.register_batch_dev(wl["depth"].data_ptr(), None, wl["masks"].data_ptr(), min(2, B), params(min(2, B)), d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
     ctx.timing_enable(nthr == 1)
     for s in range(7):
         ctx.timing_read(s)
@@ -84,8 +105,9 @@ def main():
         if share[t] == 0:
             results[t] = []
             return
-        mptr = d_masks.data_ptr() + offs[t] * h * w
-        results[t] = ctxs[t].register_batch_dev(d_depth.data_ptr(), None, mptr, share[t], prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+        dptr = wl["depth"].data_ptr() + offs[t] * H * W * 2
+        mptr = wl["masks"].data_ptr() + offs[t] * H * W
+        results[t] = ctxs[t].register_batch_dev(dptr, None, mptr, share[t], params(share[t]), d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
 
     t0 = time.perf_counter()
     if nthr == 1:
@@ -99,15 +121,28 @@ def main():
     res = [r for part in results for r in part]
     names = ["icp_nn", "ransac_score", "feature_match", "knn_scan", "radius_scan", "depth", "voxel"]
     stage = {n: ctx.timing_read(i)[0] / B for i, n in enumerate(names)}
-    Tinv = np.linalg.inv(T.astype(np.float64))
-    ang = [synth.rotation_angle(Tinv[:3, :3], r["T"][:3, :3]) for r in res]
-    print(json.dumps(dict(config=("matched-resolution batch (1 mm): " if args.matched else "C4-style batch: ") + "%d instances x %d-px mask of one 1280x720 frame vs %d-pt model" % (B, int(hit.sum()), nm),
-                          instances=B, host_threads=nthr, pixels_per_instance=int(hit.sum()), voxels_per_instance=res[0]["n_voxels"], model_points=nm,
-                          wall_s=dt, instances_per_s=B / dt, ms_per_instance=dt / B * 1e3,
-                          ransac_hyps_per_s=B * args.hyps / dt, icp_iters_per_s=sum(r["icp_iterations"] for r in res) / dt,
-                          kernel_ms_per_instance=stage, icp_fitness=[float(r["fitness"]) for r in res[:3]],
-                          coarse_inliers=[r["coarse_inliers"] for r in res[:3]], angle_to_gt_rad=ang[:3])))
+    err = [synth.pose_error(r["T"], T) for r, T in zip(res, wl["T_gt"])]
+    ang = np.array([e[0] for e in err]); tr = np.array([e[1] for e in err])
+    icp_total = int(sum(r["icp_iterations"] for r in res))
+    bad = [int(b) for b in np.nonzero(~(ang <= args.max_angle))[0]]
+    out = dict(config="C4: %d distinct instances (own pose, own 1280x720 frame, own mask) vs one %d-pt model; voxel %.3f mm = %.2f px"
+                      % (B, nm, wl["voxel"] * 1e3, args.voxel_px),
+               instances=B, host_threads=nthr, voxel_order=args.order, bumps=wl["bumps"],
+               mask_pixels=dict(min=min(wl["mask_px"]), mean=float(np.mean(wl["mask_px"])), max=max(wl["mask_px"])),
+               voxels_per_instance=dict(min=min(r["n_voxels"] for r in res), mean=float(np.mean([r["n_voxels"] for r in res])), max=max(r["n_voxels"] for r in res)),
+               model_points=nm, hyps_per_instance=args.hyps, icp_max_iterations=args.icp_iters, icp_distance_factor=args.icp_factor,
+               wall_s=dt, instances_per_s=B / dt, ms_per_instance=dt / B * 1e3,
+               ransac_hyps_per_s=B * args.hyps / dt, icp_iterations_run=icp_total, icp_iterations_per_instance=icp_total / B,
+               icp_iters_per_s=icp_total / dt, kernel_ms_per_instance=stage,
+               coarse_fitness=dict(min=float(min(r["coarse_fitness"] for r in res)), mean=float(np.mean([r["coarse_fitness"] for r in res]))),
+               icp_fitness=dict(min=float(min(r["fitness"] for r in res)), mean=float(np.mean([r["fitness"] for r in res]))),
+               angle_to_gt_rad=dict(max=float(ang.max()), mean=float(ang.mean())), translation_to_gt_m=dict(max=float(tr.max()), mean=float(tr.mean())),
+               registered=B - len(bad), failed_instances=bad[:16], workload_build_s=t_build)
+    print(json.dumps(out))
     ctx.close()
+    if bad:
+        sys.stderr.write("FAILED: %d of %d instances further than %.0e rad from ground truth\n" % (len(bad), B, args.max_angle))
+        sys.exit(1)
 
 
 if __name__ == "__main__":
