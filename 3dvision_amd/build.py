@@ -23,7 +23,7 @@ LIB = os.path.join(HERE, "lib3dvision_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
-         "-I", os.path.join(ROOT, "include"), "-I", SRC]
+         "-I", os.path.join(ROOT, "include"), "-I", SRC] + os.environ.get("TDV_HIPCC_FLAGS", "").split()   # tuning builds (-DNAME=value)
 
 
 def _sources():

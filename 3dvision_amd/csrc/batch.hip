@@ -32,6 +32,12 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
                                           prm->mask_mode, prm->fx, prm->fy, prm->cx, prm->cy, prm->zmax, d_off, all_xyz, nullptr));
     }
     (void)d_bgr;  // colours do not enter the registration chain (voxelDownsample keeps them, nothing downstream reads them)
+    // the model's descriptors are packed once; every instance, on either lane, searches the same read-only index
+    FmIndex model_index; bool have_index = false;
+    if (n_model >= 2048 && !getenv("TDV_FM_BRUTE") && !getenv("TDV_FM_KEYORDER")) {
+        TDV_TRY(fm_index_build(ctx, d_model_fpfh, n_model, &model_index));
+        have_index = true;
+    }
     // one instance: voxel -> normals + FPFH -> match -> RANSAC -> ICP on context c (its stream, its workspace)
     auto run_instance = [&](tdv_ctx* c, int b) -> int {
         tdv_instance_result& r = results[b];
@@ -52,7 +58,8 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         TDV_TRY(ws_alloc(c, (size_t)v, &corr));
         TDV_TRY(normals_fpfh_dev(c, vx, v, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor, nrm, fpfh));
         tdv_ransac_result coarse;
-        TDV_TRY(feature_match_dev(c, fpfh, v, d_model_fpfh, n_model, corr));
+        if (have_index && v >= 4096) TDV_TRY(feature_match_indexed_dev(c, fpfh, v, model_index, corr));
+        else TDV_TRY(feature_match_dev(c, fpfh, v, d_model_fpfh, n_model, corr));
         TDV_TRY(ransac_run_dev(c, vx, v, d_model_xyz, n_model, nullptr, nullptr, corr, prm->voxel_size, prm->ransac_max_iterations,
                                prm->ransac_confidence, prm->seed, &coarse, nullptr));
         r.coarse_fitness = coarse.fitness; r.coarse_inliers = coarse.inliers;

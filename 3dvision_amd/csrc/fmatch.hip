@@ -1,0 +1,933 @@
+// Descriptor correspondences of RANSAC on gfx950 (f32 VALU work; nothing here is HBM- or MFMA-bound).
+//
+// Replaces the matching loop of Registration::ransacRegistration (/root/reference/src/registration.cpp:216-232):
+// for every source descriptor the target with the smallest 33-D squared distance, accumulated in d order without FMA,
+// strict <, lowest target index on ties.  Three implementations with identical results:
+//   * k_feature_match_scan      the reference's scan (small problems, TDV_FM_BRUTE=1): source descriptors in VGPRs,
+//                               targets broadcast through the scalar data path, 98 VALU ops per pair;
+//   * k_fm_query (default)      exact search over a packed index of the targets (below): STR packing along the
+//                               targets' principal directions, 33-D boxes of 64-row leaves and 4096-row groups;
+//   * k_feature_match_pruned    round 1's pruned scan over a scalar key order (TDV_FM_KEYORDER=1, kept for A/B).
+// Every distance that is evaluated is the reference's expression; every target that is not evaluated is excluded by a
+// box lower bound computed with the same expression on the per-dimension gaps (float sub/mul/add are monotone, so
+// lb <= fl(dist) for every row of the box, no margin), or by the tie rule (equal bound, only higher indices inside).
+// The order of rows, the principal directions and the host eigen-solver only decide WHICH rows are looked at first.
+#include "tdv_internal.hpp"
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+namespace tdv {
+
+constexpr int FM_SPL = 2;
+#ifndef FM_BLOCK_VALUE
+#define FM_BLOCK_VALUE 256
+#endif
+constexpr int FM_BLOCK = FM_BLOCK_VALUE;
+constexpr int FM_SRC_PER_BLOCK = FM_SPL * FM_BLOCK;
+constexpr int FD = 33;
+constexpr int FM_SEED = 256;   // targets of the seeding launch
+
+// EARLY: partial-distance early exit.  dist accumulates non-negative terms in d order, and fl(a + b) >= a for b >= 0,
+// so once the partial sum is >= the lane's best the final distance cannot pass the strict "<": a target is dropped
+// as soon as that holds for every lane of the wave (checked after 11 and 22 of the 33 dimensions).  `seed` (the exact
+// best over the first targets, computed by a first launch) lets every split start with a tight bound.
+template <bool EARLY>
+__global__ __launch_bounds__(FM_BLOCK)
+void k_feature_match_scan(const float* __restrict__ fs, int ns, int ns_pad,
+                          const float* __restrict__ ft, int j_begin, int j_end, int per_split,
+                          const float* __restrict__ seed, const uint4* __restrict__ order,
+                          float* __restrict__ pd, int* __restrict__ pj) {
+    const int split = blockIdx.y;
+    const int j0 = j_begin + split * per_split;
+    const int j1 = min(j_end, j0 + per_split);
+    const int base = blockIdx.x * FM_SRC_PER_BLOCK + threadIdx.x;
+    float f[FM_SPL][FD];
+    float best[FM_SPL]; int bj[FM_SPL]; int src[FM_SPL];
+#pragma unroll
+    for (int s = 0; s < FM_SPL; ++s) {
+        // with `order` (records sorted by seed distance, .w = source index) a wave holds sources whose bounds are
+        // alike, so it leaves a target as early as its typical lane does; results go back to the source's own row
+        const int t = base + s * FM_BLOCK;
+        src[s] = order ? (int)order[min(t, ns - 1)].w : t;
+        const int i = min(src[s], ns - 1);
+#pragma unroll
+        for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
+        best[s] = seed ? seed[i] : FLT_MAX;   // a seed comes from lower target indices: strict < keeps the tie rule
+        bj[s] = seed ? -1 : 0;
+        if (order && t >= ns) src[s] = -1;    // padding lane: duplicate work, no output
+    }
+    for (int j = j0; j < j1; ++j) {
+        const float* __restrict__ g = ft + (size_t)j * FD;  // wave-uniform -> scalar loads
+        float q[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) q[d] = g[d];
+        float dist[FM_SPL];
+#pragma unroll
+        for (int s = 0; s < FM_SPL; ++s) dist[s] = 0.f;
+#pragma unroll
+        for (int seg = 0; seg < 3; ++seg) {
+#pragma unroll
+            for (int s = 0; s < FM_SPL; ++s)
+#pragma unroll
+                for (int d = seg * 11; d < seg * 11 + 11; ++d) { float diff = f[s][d] - q[d]; dist[s] += diff * diff; }
+            if (EARLY && seg < 2) {
+                bool alive = false;
+#pragma unroll
+                for (int s = 0; s < FM_SPL; ++s) alive = alive || (dist[s] < best[s]);
+                if (!__any(alive)) goto next_target;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < FM_SPL; ++s) {
+            bool lt = dist[s] < best[s];
+            best[s] = lt ? dist[s] : best[s];
+            bj[s] = lt ? j : bj[s];
+        }
+    next_target:;
+    }
+#pragma unroll
+    for (int s = 0; s < FM_SPL; ++s) {
+        if (src[s] < 0) continue;
+        size_t o = (size_t)split * ns_pad + src[s];
+        pd[o] = best[s]; pj[o] = bj[s];
+    }
+}
+
+// partial results are combined in launch/split order with strict <: the lowest target index wins ties
+__global__ void k_feature_match_combine(int ns, int ns_pad, int nparts, const float* __restrict__ pd,
+                                        const int* __restrict__ pj, int* __restrict__ corr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    float best = FLT_MAX; int bj = 0;
+    for (int s = 0; s < nparts; ++s) {
+        float d = pd[(size_t)s * ns_pad + i];
+        if (d < best) { best = d; bj = pj[(size_t)s * ns_pad + i]; }
+    }
+    corr[i] = bj;
+}
+
+// ---- exact pruned descriptor match (large problems) -------------------------------------------------------------
+// FPFH descriptors of a real part are strongly clustered (most of their variance lies along one direction), so both
+// sides are ordered by a cheap scalar key (the three centre bins) with a counting sort, 33-D bounding boxes are built
+// over runs of 64 ordered targets, and a wave of neighbouring sources skips every box whose lower bound exceeds all
+// its lanes' current best.  The bound is the distance expression itself applied to the per-dimension gaps, summed in
+// the same order: every term is <= the corresponding term of any target inside the box and float addition /
+// multiplication are monotone, so lb <= fl(dist) holds exactly and no margin is needed.  Targets are visited
+// inside-out from the wave's own key position; ties keep the lowest ORIGINAL target index, as the CPU scan does.
+// The order only affects speed: any key (and the arbitrary order inside a bucket) gives the same correspondences.
+constexpr int FMP_KEY_BITS = 7;                       // bits per key of the 2-D Morton bucket
+constexpr int FMP_BUCKETS = 1 << (2 * FMP_KEY_BITS);   // 16384 (64 KB of LDS counters in the ordering kernels)
+constexpr int FMP_BOX = 64;
+constexpr int FMP_TWO_KEYS_MAX_TARGETS = 32768;
+
+__device__ __forceinline__ int fm_bucket(const float* __restrict__ f, int two_keys) {
+    // key 1: the three centre bins (descriptors sum to 1, so it lies in [0, 1]); key 2: the first moment of the phi
+    // sub-histogram (in [0, 10]).  two_keys: FMP_KEY_BITS bits each, interleaved (a 128 x 128 Morton grid) — measured
+    // better against a small model (C4: 128k x 9.4k, 0.71 -> 0.60 ms); else key 1 alone at full resolution — better
+    // when the target side is large (100k x 100k: 8.3 vs 9.6 ms).  An offline study on real descriptors
+    // (tools/studies/feature_match_box_pruning.py) put this pair ahead of every other cheap pair.
+    const float c1 = f[5] + (f[16] + f[27]);
+    if (!two_keys) {
+        const float k = c1 * (float)FMP_BUCKETS;
+        return (k == k) ? (int)fminf(fmaxf(k, 0.f), (float)(FMP_BUCKETS - 1)) : 0;
+    }
+    constexpr float LEVELS = (float)(1 << FMP_KEY_BITS);
+    const float k1 = c1 * LEVELS;
+    float k2 = 0.f;
+#pragma unroll
+    for (int b = 1; b < 11; ++b) k2 += (float)b * f[11 + b];
+    k2 *= LEVELS * 0.1f;
+    const unsigned a = (k1 == k1) ? (unsigned)fminf(fmaxf(k1, 0.f), LEVELS - 1.f) : 0u;
+    const unsigned c = (k2 == k2) ? (unsigned)fminf(fmaxf(k2, 0.f), LEVELS - 1.f) : 0u;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < FMP_KEY_BITS; ++i) m |= (((a >> i) & 1u) << (2 * i + 1)) | (((c >> i) & 1u) << (2 * i));
+    return (int)m;
+}
+// Real descriptors crowd a few buckets, so both passes count in an LDS histogram first (one global atomic per
+// non-empty bucket and workgroup instead of one per row).
+constexpr int FMP_SORT_BLOCK = 1024;
+__global__ __launch_bounds__(FMP_SORT_BLOCK)
+void k_fm_hist(const float* __restrict__ f, int n, int two_keys, int* __restrict__ bucket_of, int* __restrict__ hist) {
+    __shared__ int h[FMP_BUCKETS];
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
+    if (i < n) {
+        const int b = fm_bucket(f + (size_t)i * FD, two_keys);
+        bucket_of[i] = b;
+        atomicAdd(&h[b], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+__global__ __launch_bounds__(FMP_SORT_BLOCK)
+void k_fm_scatter(const int* __restrict__ bucket_of, int n, const int* __restrict__ start, int* __restrict__ cursor,
+                  int* __restrict__ perm) {
+    __shared__ int h[FMP_BUCKETS];      // rows of this workgroup per bucket, then the workgroup's base inside the bucket
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
+    int b = 0, local = 0;
+    if (i < n) { b = bucket_of[i]; local = atomicAdd(&h[b], 1); }
+    __syncthreads();
+    for (int c = threadIdx.x; c < FMP_BUCKETS; c += FMP_SORT_BLOCK) if (h[c]) h[c] = atomicAdd(&cursor[c], h[c]);
+    __syncthreads();
+    if (i < n) perm[start[b] + h[b] + local] = i;   // order inside a bucket is irrelevant to the result
+}
+__global__ void k_fm_gather_targets(const float* __restrict__ ft, const int* __restrict__ perm, int nt, int nt_pad,
+                                    float* __restrict__ T, int* __restrict__ torig) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)nt_pad * FD) return;
+    const int row = (int)(e / FD), d = (int)(e % FD);
+    T[e] = row < nt ? ft[(size_t)perm[row] * FD + d] : INFINITY;   // padding rows: distance +inf, never chosen
+    if (d == 0) torig[row] = row < nt ? perm[row] : INT_MAX;
+}
+__global__ void k_fm_boxes(const float* __restrict__ T, int nt, int nbox, float* __restrict__ bmin, float* __restrict__ bmax) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nbox * FD) return;
+    const int b = e / FD, d = e % FD;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int r = b * FMP_BOX; r < min(nt, (b + 1) * FMP_BOX); ++r) { float v = T[(size_t)r * FD + d]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    bmin[e] = mn; bmax[e] = mx;
+}
+
+// box visited at position v of the inside-out order centred at box c (bijection onto [0, nbox))
+__device__ __forceinline__ int visit_inside_out(int v, int c, int nbox) {
+    const int L = c, R = nbox - 1 - c;
+    const int m = min(L, R);
+    if (v <= 2 * m) { int k = (v + 1) >> 1; return (v & 1) ? c + k : c - k; }
+    return R > L ? c + (v - m) : c - (v - m);
+}
+
+template <int SPL>
+__global__ __launch_bounds__(FM_BLOCK)
+void k_feature_match_pruned(const float* __restrict__ fs, const int* __restrict__ sperm, int ns, int ns_pad,
+                            const float* __restrict__ T, const int* __restrict__ torig, int nbox,
+                            const float* __restrict__ bmin, const float* __restrict__ bmax, const int* __restrict__ tstart,
+                            int two_keys, int nsplit, float* __restrict__ pd, int* __restrict__ pj) {
+    const int split = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wbase = (blockIdx.x * (FM_BLOCK / 64) + wave) * (64 * SPL);   // the wave's 64*SPL consecutive ordered sources
+    float f[SPL][FD];
+    float best[SPL]; int bj[SPL]; int src[SPL];
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        const int t = wbase + s * 64 + lane;
+        const int i = sperm[min(t, ns - 1)];
+        src[s] = t < ns ? i : -1;   // padding lanes duplicate the last source and write nothing
+#pragma unroll
+        for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
+        best[s] = INFINITY; bj[s] = INT_MAX;
+    }
+    // start where the targets with the wave's own key begin
+    const int c = min(nbox - 1, tstart[__builtin_amdgcn_readfirstlane(fm_bucket(f[0], two_keys))] / FMP_BOX);
+    for (int v = split; v < nbox; v += nsplit) {
+        const int b = visit_inside_out(v, c, nbox);
+        const float* __restrict__ lo = bmin + (size_t)b * FD;   // wave-uniform -> scalar loads
+        const float* __restrict__ hi = bmax + (size_t)b * FD;
+        float lb[SPL];
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) lb[s] = 0.f;
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {
+            const float l = lo[d], h = hi[d];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) { float g = fmaxf(fmaxf(l - f[s][d], f[s][d] - h), 0.f); lb[s] += g * g; }
+        }
+        bool alive = false;
+#pragma unroll
+        for (int s = 0; s < SPL; ++s) alive = alive || (lb[s] <= best[s]);   // <=: an equal distance with a lower index still wins
+        if (!__any(alive)) continue;
+#pragma unroll 1
+        for (int t = 0; t < FMP_BOX; ++t) {
+            const int j = b * FMP_BOX + t;
+            const float* __restrict__ g = T + (size_t)j * FD;
+            const int o = torig[j];
+            float q[FD];
+#pragma unroll
+            for (int d = 0; d < FD; ++d) q[d] = g[d];
+#pragma unroll
+            for (int s = 0; s < SPL; ++s) {
+                float dist = 0.f;
+#pragma unroll
+                for (int d = 0; d < FD; ++d) { float diff = f[s][d] - q[d]; dist += diff * diff; }
+                const bool take = dist < best[s] || (dist == best[s] && o < bj[s]);
+                best[s] = take ? dist : best[s];
+                bj[s] = take ? o : bj[s];
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < SPL; ++s) {
+        if (src[s] < 0) continue;
+        const size_t o = (size_t)split * ns_pad + src[s];
+        pd[o] = best[s]; pj[o] = bj[s];
+    }
+}
+
+// partials of the pruned match: lexicographic (distance, original index) minimum, order-independent
+__global__ void k_feature_match_combine_lex(int ns, int ns_pad, int nparts, const float* __restrict__ pd,
+                                            const int* __restrict__ pj, int* __restrict__ corr) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    float best = INFINITY; int bj = INT_MAX;
+    for (int s = 0; s < nparts; ++s) {
+        const float d = pd[(size_t)s * ns_pad + i]; const int j = pj[(size_t)s * ns_pad + i];
+        if (d < best || (d == best && j < bj)) { best = d; bj = j; }
+    }
+    corr[i] = bj == INT_MAX ? 0 : bj;   // nothing finite: the CPU loop keeps its initial index 0
+}
+
+namespace {
+// counting sort of n descriptors by key bucket: perm (ordered position -> row) and, optionally, the bucket starts
+int fm_order(tdv_ctx* ctx, const float* d_f, int n, int two_keys, int* perm, int* start /* FMP_BUCKETS + 1 */) {
+    hipStream_t s = ctx->stream;
+    int *hist, *cursor, *d_total, *bucket_of;
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &hist));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &cursor));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &bucket_of));
+    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
+    const int blocks = (n + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
+    k_fm_hist<<<blocks, FMP_SORT_BLOCK, 0, s>>>(d_f, n, two_keys, bucket_of, hist);
+    TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
+    k_fm_scatter<<<blocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, n, start, cursor, perm);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+constexpr int FMP_SPL = 1;   // 1 measured better than 2 (C4: 0.84 vs 0.93 ms)
+
+int feature_match_keyorder_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
+    hipStream_t s = ctx->stream;
+    const int nt_pad = (int)align_up((size_t)nt, FMP_BOX);
+    const int nbox = nt_pad / FMP_BOX;
+    constexpr int SRC_PER_BLOCK = FM_BLOCK * FMP_SPL;
+    const int ns_pad = (int)align_up((size_t)ns, SRC_PER_BLOCK);
+    const int blocks_x = ns_pad / SRC_PER_BLOCK;
+    int want = (4096 + blocks_x - 1) / blocks_x;
+    const int nsplit = std::max(1, std::min(std::min(want, std::max(1, nbox / 8)), 32));
+    int *sperm, *tperm, *tstart, *sstart, *torig; float *T, *bmin, *bmax, *pd; int* pj;
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &sperm));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &tperm));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &tstart));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &sstart));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt_pad, &torig));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt_pad * FD, &T));
+    TDV_TRY(ws_alloc(ctx, (size_t)nbox * FD, &bmin));
+    TDV_TRY(ws_alloc(ctx, (size_t)nbox * FD, &bmax));
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pd));
+    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pj));
+    ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
+    const int two_keys = nt <= FMP_TWO_KEYS_MAX_TARGETS ? 1 : 0;
+    TDV_TRY(fm_order(ctx, d_ft, nt, two_keys, tperm, tstart));
+    TDV_TRY(fm_order(ctx, d_fs, ns, two_keys, sperm, sstart));
+    k_fm_gather_targets<<<(unsigned)(((size_t)nt_pad * FD + 255) / 256), 256, 0, s>>>(d_ft, tperm, nt, nt_pad, T, torig);
+    k_fm_boxes<<<(nbox * FD + 255) / 256, 256, 0, s>>>(T, nt, nbox, bmin, bmax);
+    k_feature_match_pruned<FMP_SPL><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, sperm, ns, ns_pad, T, torig, nbox, bmin, bmax, tstart,
+                                                                               two_keys, nsplit, pd, pj);
+    k_feature_match_combine_lex<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nsplit, pd, pj, d_corr);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+}  // namespace
+
+// ---- packed target index -----------------------------------------------------------------------------------------
+// FPFH descriptors of a surface live close to a 3-D manifold of R^33 (96 % of their variance in three principal
+// directions on the relief part).  The targets are therefore packed sort-tile-recursive along those directions:
+// equal-count slabs along p0, equal-count columns along p1 inside every slab, rows sorted along p2 inside every column
+// (three sorts of 16-B records; slab / column counts proportional to the spread, chosen on the host from the
+// eigenvalues).  Columns are padded to a multiple of 64 rows (+inf rows that never win), so a leaf = 64 consecutive
+// rows never straddles two columns; group = 64 consecutive leaves.  Offline study on real descriptors
+// (tools/studies/feature_match_pca_tree.py): a wave of 64 neighbouring sources has to open 2.3 % of the leaves with
+// this packing against 17.8 % with round 1's scalar key.
+constexpr int FX_LEAF = 64;
+constexpr int FX_GROUP = 64;          // leaves per group
+constexpr int FX_MAX_S = 64;          // slabs / columns per slab at most
+constexpr int FX_NMOM = 561 + 33;     // upper triangle of sum f f^T, then sum f
+#ifndef FMQ_WAVES_PER_SIMD
+#define FMQ_WAVES_PER_SIMD 4
+#endif
+
+__device__ __forceinline__ unsigned sortable_bits(float v) {   // ascending float order as ascending unsigned order; NaN last
+    if (v != v) return 0xffffffffu;
+    unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// raw moments of the rows, per workgroup, in double; fixed order (deterministic basis -> deterministic packing)
+constexpr int FX_MOM_BLOCK = 640;
+constexpr int FX_MOM_TILE = 32;
+__global__ __launch_bounds__(FX_MOM_BLOCK)
+void k_fm_moments(const float* __restrict__ f, int n, int rows_per_block, double* __restrict__ partial) {
+    __shared__ float tile[FX_MOM_TILE][FD + 1];
+    const int t = threadIdx.x;
+    int a = 0, b = 0;   // thread t < 561: pair (a <= b); 561 <= t < 594: column sum
+    if (t < 561) { int r = t; a = 0; while (r >= FD - a) { r -= FD - a; ++a; } b = a + r; }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(n, r0 + rows_per_block);
+    double acc = 0.0;
+    for (int base = r0; base < r1; base += FX_MOM_TILE) {
+        const int m = min(FX_MOM_TILE, r1 - base);
+        for (int e = t; e < m * FD; e += FX_MOM_BLOCK) tile[e / FD][e % FD] = f[(size_t)base * FD + e];
+        __syncthreads();
+        if (t < 561) { for (int r = 0; r < m; ++r) acc += (double)tile[r][a] * (double)tile[r][b]; }
+        else if (t < FX_NMOM) { for (int r = 0; r < m; ++r) acc += (double)tile[r][t - 561]; }
+        __syncthreads();
+    }
+    if (t < FX_NMOM) partial[(size_t)blockIdx.x * FX_NMOM + t] = acc;
+}
+__global__ void k_fm_moments_fold(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= FX_NMOM) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * FX_NMOM + t];
+    out[t] = s;
+}
+
+// basis: [3][33] directions, then mean[33]
+__global__ void k_fm_project(const float* __restrict__ f, int n, const float* __restrict__ basis, float* __restrict__ p0,
+                             float* __restrict__ p1, float* __restrict__ p2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < FD; ++d) {
+        const float v = f[(size_t)i * FD + d] - basis[3 * FD + d];
+        a0 += v * basis[d]; a1 += v * basis[FD + d]; a2 += v * basis[2 * FD + d];
+    }
+    p0[i] = a0; p1[i] = a1; p2[i] = a2;
+}
+
+__global__ void k_fm_rec_p0(const float* __restrict__ p0, int n, int n_pow2, uint4* __restrict__ rec) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pow2) return;
+    rec[i] = i < n ? make_uint4(sortable_bits(p0[i]), (unsigned)i, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+}
+// number of entries of the ascending array `starts` (m + 1 entries, starts[0] = 0) that are <= r, minus 1
+__device__ __forceinline__ int segment_of(const int* __restrict__ starts, int m, int r) {
+    int lo = 0, hi = m;   // invariant: starts[lo] <= r < starts[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= r) lo = mid; else hi = mid; }
+    return lo;
+}
+// after the sort along p0: rank -> slab (equal counts); next key = (slab, p1, row); slab boundary values for locating
+__global__ void k_fm_rec_p1(uint4* __restrict__ rec, int n, const int* __restrict__ slab_start, int S0, const float* __restrict__ p0,
+                            const float* __restrict__ p1, float* __restrict__ b0) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const unsigned idx = rec[r].y;
+    const int k = segment_of(slab_start, S0, r);
+    if (r == slab_start[k]) b0[k] = p0[idx];
+    rec[r] = make_uint4((unsigned)k, sortable_bits(p1[idx]), idx, 0u);
+}
+// after the sort along (slab, p1): rank -> column; next key = (column, p2, row)
+__global__ void k_fm_rec_p2(uint4* __restrict__ rec, int n, const int* __restrict__ col_start, int ncol, const float* __restrict__ p1,
+                            const float* __restrict__ p2, float* __restrict__ b1) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const unsigned idx = rec[r].z;
+    const int c = segment_of(col_start, ncol, r);
+    if (r == col_start[c]) b1[c] = p1[idx];
+    rec[r] = make_uint4((unsigned)c, sortable_bits(p2[idx]), idx, 0u);
+}
+__global__ void k_fm_fill_rows(float* __restrict__ T, int* __restrict__ torig, size_t n_rows) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_rows * FD) T[e] = INFINITY;
+    if (e < n_rows) torig[e] = INT_MAX;
+}
+// Row r of the packed table lives in leaf r / 64 as column r % 64 of a [33][64] block: a wave reads one dimension of a
+// whole leaf with one coalesced 256-B load (lane = row) and hands rows to its lanes' arithmetic with v_readlane.
+__device__ __forceinline__ size_t row_elem(size_t row, int d) { return (row / FX_LEAF) * (size_t)(FD * FX_LEAF) + (size_t)d * FX_LEAF + row % FX_LEAF; }
+// after the sort along (column, p2, row): rows to their padded positions
+__global__ void k_fm_place_rows(const uint4* __restrict__ rec, int n, const int* __restrict__ col_start, const int* __restrict__ col_row0, int ncol,
+                                const float* __restrict__ ft, const float* __restrict__ p2, float* __restrict__ T, int* __restrict__ torig,
+                                float* __restrict__ leaf_p2) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)n * FD) return;
+    const int r = (int)(e / FD), d = (int)(e % FD);
+    const unsigned idx = rec[r].z;
+    const int c = segment_of(col_start, ncol, r);
+    const size_t row = (size_t)col_row0[c] + (size_t)(r - col_start[c]);
+    T[row_elem(row, d)] = ft[(size_t)idx * FD + d];
+    if (d == 0) {
+        torig[row] = (int)idx;
+        if (row % FX_LEAF == 0) leaf_p2[row / FX_LEAF] = p2[idx];
+    }
+}
+// Leaf boxes over the real rows of 64 padded rows; a leaf of padding only gets the
+// empty box (+inf, -inf): its bound is +inf.  Stored per group, transposed: lbox[group][min | max][33][64 leaves], so a
+// wave reads one dimension of a group's 64 boxes with one coalesced load (lane = leaf); leaves past the end are empty.
+__global__ void k_fm_leaf_boxes(const float* __restrict__ T, const int* __restrict__ torig, int nleaf, int ngroup, float* __restrict__ lbox) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ngroup * FX_GROUP * FD) return;
+    const int b = e / FD, d = e % FD;
+    float mn = INFINITY, mx = -INFINITY;
+    if (b < nleaf)
+        for (int r = b * FX_LEAF; r < (b + 1) * FX_LEAF; ++r) {
+            if (torig[r] == INT_MAX) continue;
+            const float v = T[row_elem((size_t)r, d)];
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+    float* gb = lbox + (size_t)(b / FX_GROUP) * (2 * FD * FX_GROUP);
+    gb[d * FX_GROUP + b % FX_GROUP] = mn; gb[(FD + d) * FX_GROUP + b % FX_GROUP] = mx;
+}
+// group boxes, same transposed layout one level up: gbox[chunk of 64 groups][min | max][33][64]; groups past the end are empty
+__global__ void k_fm_group_boxes(const float* __restrict__ lbox, int ngroup, int nchunk, float* __restrict__ gbox) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nchunk * 64 * FD) return;
+    const int g = e / FD, d = e % FD;
+    float mn = INFINITY, mx = -INFINITY;
+    if (g < ngroup) {
+        const float* gb = lbox + (size_t)g * (2 * FD * FX_GROUP);
+        for (int l = 0; l < FX_GROUP; ++l) { mn = fminf(mn, gb[d * FX_GROUP + l]); mx = fmaxf(mx, gb[(FD + d) * FX_GROUP + l]); }
+    }
+    float* cb = gbox + (size_t)(g / 64) * (2 * FD * 64);
+    cb[d * 64 + g % 64] = mn; cb[(FD + d) * 64 + g % 64] = mx;
+}
+
+// home leaf of every source: its cell of the target packing (slab by p0, column by p1, leaf by p2)
+__global__ void k_fm_locate(const float* __restrict__ fs, int ns, const float* __restrict__ basis, int S0, int S1,
+                            const float* __restrict__ b0, const float* __restrict__ b1, const int* __restrict__ col_leaf0,
+                            const float* __restrict__ leaf_p2, int bucket_shift, int* __restrict__ home, int* __restrict__ bucket_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int d = 0; d < FD; ++d) {
+        const float v = fs[(size_t)i * FD + d] - basis[3 * FD + d];
+        a0 += v * basis[d]; a1 += v * basis[FD + d]; a2 += v * basis[2 * FD + d];
+    }
+    int k = 0;
+    for (int s = 1; s < S0; ++s) k += (b0[s] <= a0) ? 1 : 0;           // boundaries ascend; NaN compares false -> cell 0
+    int j = 0;
+    for (int s = 1; s < S1; ++s) j += (b1[k * S1 + s] <= a1) ? 1 : 0;
+    const int c = k * S1 + j;
+    const int l0 = col_leaf0[c], l1 = col_leaf0[c + 1];
+    int l = l0;
+    for (int s = l0 + 1; s < l1; ++s) l += (leaf_p2[s] <= a2) ? 1 : 0;
+    l = min(l, max(l1 - 1, l0));
+    home[i] = l;
+    bucket_of[i] = l >> bucket_shift;
+}
+__global__ __launch_bounds__(FMP_SORT_BLOCK)
+void k_fm_bucket_hist(const int* __restrict__ bucket_of, int n, int* __restrict__ hist) {
+    __shared__ int h[FMP_BUCKETS];
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
+    if (i < n) atomicAdd(&h[bucket_of[i]], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+
+__device__ __forceinline__ float box_bound(const float (&f)[FD], const float* __restrict__ lo, const float* __restrict__ hi) {
+    float lb = 0.f;
+#pragma unroll
+    for (int d = 0; d < FD; ++d) { const float g = fmaxf(fmaxf(lo[d] - f[d], f[d] - hi[d]), 0.f); lb += g * g; }
+    return lb;
+}
+
+// ---- wave-level helpers (DPP: no LDS traffic) ----------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// minimum over the 64 lanes, returned wave-uniform (an SGPR after readlane)
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = fminf(v, dpp_f32<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
+    v = fminf(v, dpp_f32<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
+    v = fminf(v, dpp_f32<0x141, 0xF>(v));   // row_half_mirror
+    v = fminf(v, dpp_f32<0x140, 0xF>(v));   // row_mirror: every lane of a 16-lane row holds the row minimum
+    v = fminf(v, dpp_f32<0x142, 0xA>(v));   // row_bcast15 into rows 1 and 3
+    v = fminf(v, dpp_f32<0x143, 0xC>(v));   // row_bcast31 into rows 2 and 3: lane 63 holds the wave minimum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// K sources per wave, LANE = TARGET-SIDE ITEM (a row of a leaf, a leaf box of a group, a group box): every lane does
+// useful, distinct work, and the K source descriptors are wave-uniform (scalar loads of the wave's own 132-B rows, which
+// stay in the scalar cache).  The sources of a wave share a home leaf (they were ordered by it), so they need nearly the
+// same leaves: a leaf fetched once (33 coalesced 256-B loads, lane = row) serves all K of them.
+//   round-2 history of this kernel at 143k x 151k real descriptors (profiles/r2/history/feature_match_designs.md):
+//   lane = source, rows through the scalar path 7.5 ms (every wave opens its own leaves: the scalar cache misses on all
+//   of them); lane = source, rows through v_readlane 7.6 ms (175 issue slots per row, and a wave of 64 sources opens the
+//   union of their leaves: 78 against 19 for a single source); lane = row with K = 8 / 4 / 2 / 1 sources per wave:
+//   12.8 (register spills) / 5.8 / 1.6 / 2.0 ms; four waves sharing one source pair through LDS bounds: 3.1 ms (the
+//   table is then read 36 GB instead of 28 GB per call — the kernel is bound by L2 / Infinity-Cache bandwidth).
+// Per source and lane a running (distance, original index) minimum over the rows that lane has seen; its wave minimum is
+// the source's bound.  A box is opened when its bound <= the source's bound (<=: an equal distance with a lower index
+// could still win; the exact lowest-index rule is applied by the final lexicographic reduction).
+// Order: home leaf, home group, then every group whose box passes (tested once, lane = group, with the bounds the home
+// group left), inside-out from the home group; inside a group the leaves whose boxes pass (lane = leaf), inside-out.
+// Bounds only shrink, so a mask computed earlier can open a leaf too many, never skip one.
+template <int K, bool STATS>
+__global__ __launch_bounds__(FM_BLOCK, FMQ_WAVES_PER_SIMD)
+void k_fm_query(const float* __restrict__ fs, const int* __restrict__ sperm, const int* __restrict__ home_of, int ns, int blocks_per_xcd,
+                const float* __restrict__ T, const int* __restrict__ torig, int nleaf, int ngroup,
+                const float* __restrict__ lbox, const float* __restrict__ gbox,
+                int* __restrict__ corr, unsigned long long* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one).  Give every XCD a CONTIGUOUS stretch of
+    // the home-ordered sources: neighbouring waves open the same leaves, so the stretch's leaves (1/8 of the table) stay
+    // in that XCD's 4 MB L2 instead of every L2 seeing the whole table.
+    const int block = (blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
+    const int wid = block * (FM_BLOCK / 64) + (threadIdx.x >> 6);
+    const int s0 = __builtin_amdgcn_readfirstlane(wid * K);
+    if (s0 >= ns) return;
+    unsigned n_group_tests = 0, n_leaf_tests = 0, n_open = 0;   // STATS only
+    unsigned long long t_start = 0;
+    if (STATS) t_start = wall_clock64();
+    int src[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) src[k] = __builtin_amdgcn_readfirstlane(sperm[min(s0 + k, ns - 1)]);   // past the end: the last source again
+    const int home = min(nleaf - 1, max(0, __builtin_amdgcn_readfirstlane(home_of[src[K / 2]])));
+    float lbest[K]; int lbj[K]; float bound[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { lbest[k] = FLT_MAX; lbj[k] = INT_MAX; bound[k] = FLT_MAX; }   // registration.cpp:218-219
+
+    auto open_leaf = [&](int leaf) {
+        const float* __restrict__ blk = T + (size_t)leaf * (FD * FX_LEAF);
+        float row[FD];
+#pragma unroll
+        for (int d = 0; d < FD; ++d) row[d] = blk[d * FX_LEAF + lane];
+        const int ro = torig[(size_t)leaf * FX_LEAF + lane];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float* __restrict__ q = fs + (size_t)src[k] * FD;   // wave-uniform -> scalar loads
+            float dist = 0.f;
+#pragma unroll
+            for (int d = 0; d < FD; ++d) { const float diff = q[d] - row[d]; dist += diff * diff; }   // registration.cpp:222-224
+            const bool take = dist < lbest[k] || (dist == lbest[k] && ro < lbj[k] && lbest[k] < FLT_MAX);
+            lbest[k] = take ? dist : lbest[k];
+            lbj[k] = take ? ro : lbj[k];
+            bound[k] = wave_min_f32(lbest[k]);
+        }
+        if (STATS) ++n_open;
+    };
+    // lanes = the 64 boxes of one [min | max][33][64] block; bit b of the result: some source may still find a better row in box b
+    auto box_mask = [&](const float* __restrict__ blk) -> unsigned long long {
+        float lb[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) lb[k] = 0.f;
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {   // one dimension of the 64 boxes at a time: two coalesced loads, K bounds advance
+            const float lo = blk[d * 64 + lane], hi = blk[(FD + d) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float qd = fs[(size_t)src[k] * FD + d];   // wave-uniform -> scalar load
+                const float g = fmaxf(fmaxf(lo - qd, qd - hi), 0.f);
+                lb[k] += g * g;
+            }
+        }
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k) m |= __ballot(lb[k] <= bound[k]);    // an empty box (+inf, -inf) has lb = +inf: never set
+        return m;
+    };
+    const int hg = home / FX_GROUP;
+    auto visit_group = [&](int g) {
+        const int l0 = g * FX_GROUP, cnt = min(FX_GROUP, nleaf - l0);
+        unsigned long long m = box_mask(lbox + (size_t)g * (2 * FD * FX_GROUP));
+        if (STATS) n_leaf_tests += 1;
+        if (g == hg) m &= ~(1ull << (home - l0));
+        const int centre = (g == hg) ? home - l0 : (g < hg ? cnt - 1 : 0);   // enter a neighbouring group from the home side
+        for (int u = 0; u < cnt && m; ++u) {
+            const int l = visit_inside_out(u, centre, cnt);
+            if (!((m >> l) & 1ull)) continue;
+            m &= ~(1ull << l);
+            open_leaf(l0 + l);
+        }
+    };
+
+    open_leaf(home);
+    visit_group(hg);
+    const int nchunk = (ngroup + 63) / 64;
+    for (int c = 0; c < nchunk; ++c) {     // (chunks in index order; within a chunk inside-out from the home group's side)
+        unsigned long long m = box_mask(gbox + (size_t)c * (2 * FD * 64));
+        if (STATS) n_group_tests += 1;
+        const int g0 = c * 64, cnt = min(64, ngroup - g0);
+        if (hg >= g0 && hg < g0 + cnt) m &= ~(1ull << (hg - g0));
+        const int centre = hg < g0 ? 0 : (hg >= g0 + cnt ? cnt - 1 : hg - g0);
+        for (int u = 0; u < cnt && m; ++u) {
+            const int g = visit_inside_out(u, centre, cnt);
+            if (!((m >> g) & 1ull)) continue;
+            m &= ~(1ull << g);
+            visit_group(g0 + g);
+        }
+    }
+    // lowest (distance, original index) over the lanes; nothing finite -> the reference keeps index 0
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float bd = lbest[k]; int bo = lbj[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float od = __shfl_xor(bd, off, 64); const int oo = __shfl_xor(bo, off, 64);
+            const bool tk = od < bd || (od == bd && oo < bo);
+            bd = tk ? od : bd; bo = tk ? oo : bo;
+        }
+        if (lane == 0 && s0 + k < ns) corr[src[k]] = bo == INT_MAX ? 0 : bo;
+    }
+    if (STATS && lane == 0) {   // [0] waves, [1] group-chunk tests, [2] groups visited, [3] leaves opened, [4] most leaves opened by one wave
+        const unsigned long long dt = wall_clock64() - t_start;   // 100 MHz ticks
+        atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)n_group_tests); atomicAdd(&stats[2], (unsigned long long)n_leaf_tests);
+        atomicAdd(&stats[3], (unsigned long long)n_open); atomicMax(&stats[4], (unsigned long long)n_open);
+        atomicAdd(&stats[5], dt); atomicMax(&stats[6], dt);
+    }
+}
+
+namespace {
+
+// cyclic Jacobi eigen-solver for a symmetric n x n matrix (host, double): eigenvalues descending, eigenvectors in rows
+void jacobi_eigen_host(std::vector<double>& A, int n, std::vector<double>& evals, std::vector<double>& evecs) {
+    std::vector<double> V((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
+        if (!(off > 1e-30)) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A[(size_t)p * n + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+                const double tt = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(tt * tt + 1.0), s = tt * c;
+                for (int k = 0; k < n; ++k) {
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - s * akq; A[(size_t)k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - s * aqk; A[(size_t)q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) {
+                    const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+                    V[(size_t)k * n + p] = c * vkp - s * vkq; V[(size_t)k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return A[(size_t)a * n + a] > A[(size_t)b * n + b]; });
+    evals.resize(n); evecs.assign((size_t)n * n, 0.0);
+    for (int r = 0; r < n; ++r) {
+        evals[r] = A[(size_t)order[r] * n + order[r]];
+        for (int k = 0; k < n; ++k) evecs[(size_t)r * n + k] = V[(size_t)k * n + order[r]];
+    }
+}
+
+}  // namespace
+
+int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
+    if (!ctx || !d_ft || !ix || nt <= 0) return TDV_ERR_BAD_ARG;
+    hipStream_t s = ctx->stream;
+    ScopedTimer tm(ctx, TDV_TIMER_FM_INDEX);
+    // 1. principal directions of the targets: raw moments on the device, 33 x 33 eigen-problem on the host
+    const int mblocks = std::max(1, std::min(512, (nt + 255) / 256));
+    const int rows_per_block = (nt + mblocks - 1) / mblocks;
+    double *partial, *mom;
+    TDV_TRY(ws_alloc(ctx, (size_t)mblocks * FX_NMOM, &partial));
+    TDV_TRY(ws_alloc(ctx, (size_t)FX_NMOM, &mom));
+    k_fm_moments<<<mblocks, FX_MOM_BLOCK, 0, s>>>(d_ft, nt, rows_per_block, partial);
+    k_fm_moments_fold<<<(FX_NMOM + 255) / 256, 256, 0, s>>>(partial, mblocks, mom);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_TRY(pin_reserve(ctx, 64 * 1024));
+    double* h_mom = reinterpret_cast<double*>(ctx->pin);
+    TDV_HIP(ctx, hipMemcpyAsync(h_mom, mom, FX_NMOM * sizeof(double), hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    std::vector<double> C((size_t)FD * FD), mean(FD), evals, evecs;
+    bool finite = true;
+    for (int d = 0; d < FD; ++d) { mean[d] = h_mom[561 + d] / nt; finite = finite && std::isfinite(mean[d]); }
+    for (int a = 0, e = 0; a < FD; ++a)
+        for (int b = a; b < FD; ++b, ++e) {
+            const double c = h_mom[e] / nt - mean[a] * mean[b];
+            finite = finite && std::isfinite(c);
+            C[(size_t)a * FD + b] = C[(size_t)b * FD + a] = c;
+        }
+    float h_basis[4 * FD];
+    double e0 = 1, e1 = 1, e2 = 1;
+    if (finite) {
+        jacobi_eigen_host(C, FD, evals, evecs);
+        for (int r = 0; r < 3; ++r) for (int d = 0; d < FD; ++d) h_basis[r * FD + d] = (float)evecs[(size_t)r * FD + d];
+        for (int d = 0; d < FD; ++d) h_basis[3 * FD + d] = (float)mean[d];
+        e0 = std::sqrt(std::max(evals[0], 0.0)); e1 = std::sqrt(std::max(evals[1], 0.0)); e2 = std::sqrt(std::max(evals[2], 0.0));
+    } else {   // non-finite descriptors: any directions will do (the order only affects speed)
+        for (int r = 0; r < 3; ++r) for (int d = 0; d < FD; ++d) h_basis[r * FD + d] = (d % 3 == r) ? 1.f : 0.f;
+        for (int d = 0; d < FD; ++d) h_basis[3 * FD + d] = 0.f;
+    }
+    // 2. slab / column counts: S0 * S1 * S2 = number of leaves with S_d proportional to the spread along p_d
+    const double nleaf_t = std::max(1.0, (double)nt / FX_LEAF);
+    const double tiny = 1e-6 * std::max(e0, 1e-30);
+    e0 = std::max(e0, tiny); e1 = std::max(e1, tiny); e2 = std::max(e2, tiny);
+    double g = std::cbrt(nleaf_t / (e0 * e1 * e2));
+    double s0 = e0 * g, s1 = e1 * g, s2 = e2 * g;
+    if (s2 < 1.0) { const double k = std::sqrt(s2); s0 *= k; s1 *= k; s2 = 1.0; }
+    if (s1 < 1.0) { s0 *= s1; s1 = 1.0; }
+    const int S0 = std::max(1, std::min(FX_MAX_S, (int)std::lround(s0)));
+    const int S1 = std::max(1, std::min(FX_MAX_S, (int)std::lround(s1)));
+    const int ncol = S0 * S1;
+    // equal-count cuts by rank are known without looking at the data
+    std::vector<int> h_int((size_t)(S0 + 1) + 3 * ((size_t)ncol + 1));
+    int* slab_start = h_int.data(); int* col_start = slab_start + S0 + 1; int* col_row0 = col_start + ncol + 1; int* col_leaf0 = col_row0 + ncol + 1;
+    for (int k = 0; k <= S0; ++k) slab_start[k] = (int)((long long)nt * k / S0);
+    for (int k = 0; k < S0; ++k) {
+        const int c0 = slab_start[k], cnt = slab_start[k + 1] - c0;
+        for (int j = 0; j < S1; ++j) col_start[k * S1 + j] = c0 + (int)((long long)cnt * j / S1);
+    }
+    col_start[ncol] = nt;
+    size_t rows = 0;
+    for (int c = 0; c < ncol; ++c) {
+        col_row0[c] = (int)rows; col_leaf0[c] = (int)(rows / FX_LEAF);
+        rows += align_up((size_t)(col_start[c + 1] - col_start[c]), FX_LEAF);
+    }
+    col_row0[ncol] = (int)rows; col_leaf0[ncol] = (int)(rows / FX_LEAF);
+    if (rows == 0) rows = FX_LEAF;
+    const int nleaf = (int)(rows / FX_LEAF), ngroup = (nleaf + FX_GROUP - 1) / FX_GROUP;
+    // 3. device side
+    float *basis, *p0, *p1, *p2; int* d_int; uint4* rec;
+    size_t n_pow2 = sort_pow2((size_t)nt);
+    TDV_TRY(ws_alloc(ctx, (size_t)4 * FD, &basis));
+    TDV_TRY(ws_alloc(ctx, h_int.size(), &d_int));
+    TDV_TRY(ws_alloc(ctx, (size_t)S0 + 1, &ix->b0));
+    TDV_TRY(ws_alloc(ctx, (size_t)ncol + 1, &ix->b1));
+    TDV_TRY(ws_alloc(ctx, (size_t)nleaf, &ix->leaf_p2));
+    TDV_TRY(ws_alloc(ctx, rows * FD, &ix->T));
+    TDV_TRY(ws_alloc(ctx, rows, &ix->torig));
+    const int nchunk = (ngroup + 63) / 64;
+    TDV_TRY(ws_alloc(ctx, (size_t)ngroup * 2 * FD * FX_GROUP, &ix->lbox));
+    TDV_TRY(ws_alloc(ctx, (size_t)nchunk * 2 * FD * 64, &ix->gbox));
+    const WsMark scratch = ws_mark(ctx);   // everything below is build scratch
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &p0));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &p1));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &p2));
+    TDV_TRY(ws_alloc(ctx, n_pow2, &rec));
+    char* stage = ctx->pin + 8192;   // the moments occupied the first bytes
+    std::memcpy(stage, h_basis, sizeof(h_basis));
+    std::memcpy(stage + sizeof(h_basis), h_int.data(), h_int.size() * 4);
+    TDV_HIP(ctx, hipMemcpyAsync(basis, stage, sizeof(h_basis), hipMemcpyHostToDevice, s));
+    TDV_HIP(ctx, hipMemcpyAsync(d_int, stage + sizeof(h_basis), h_int.size() * 4, hipMemcpyHostToDevice, s));
+    const int* d_slab_start = d_int; const int* d_col_start = d_int + S0 + 1; const int* d_col_row0 = d_col_start + ncol + 1;
+    ix->col_leaf0 = d_col_row0 + ncol + 1;
+    ix->basis = basis; ix->nt = nt; ix->rows = (int)rows; ix->nleaf = nleaf; ix->ngroup = ngroup; ix->S0 = S0; ix->S1 = S1;
+    TDV_HIP(ctx, hipMemsetAsync(ix->leaf_p2, 0, (size_t)nleaf * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(ix->b0, 0, ((size_t)S0 + 1) * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(ix->b1, 0, ((size_t)ncol + 1) * 4, s));
+    const unsigned gn = (unsigned)((nt + 255) / 256);
+    k_fm_project<<<gn, 256, 0, s>>>(d_ft, nt, basis, p0, p1, p2);
+    k_fm_rec_p0<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(p0, nt, (int)n_pow2, rec);
+    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
+    k_fm_rec_p1<<<gn, 256, 0, s>>>(rec, nt, d_slab_start, S0, p0, p1, ix->b0);
+    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
+    k_fm_rec_p2<<<gn, 256, 0, s>>>(rec, nt, d_col_start, ncol, p1, p2, ix->b1);
+    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
+    k_fm_fill_rows<<<(unsigned)((rows * FD + 255) / 256), 256, 0, s>>>(ix->T, ix->torig, rows);
+    k_fm_place_rows<<<(unsigned)(((size_t)nt * FD + 255) / 256), 256, 0, s>>>(rec, nt, d_col_start, d_col_row0, ncol, d_ft, p2, ix->T, ix->torig, ix->leaf_p2);
+    k_fm_leaf_boxes<<<(ngroup * FX_GROUP * FD + 255) / 256, 256, 0, s>>>(ix->T, ix->torig, nleaf, ngroup, ix->lbox);
+    k_fm_group_boxes<<<(nchunk * 64 * FD + 255) / 256, 256, 0, s>>>(ix->lbox, ngroup, nchunk, ix->gbox);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_HIP(ctx, hipStreamSynchronize(s));   // the pinned staging is reused by later calls; the scratch is released here
+    ws_rewind(ctx, scratch);
+    return TDV_OK;
+}
+
+template <int K>
+static int launch_fm_query(tdv_ctx* ctx, const float* d_fs, const int* sperm, const int* home, int ns, const FmIndex& ix, int* d_corr) {
+    hipStream_t s = ctx->stream;
+    const int waves = (ns + K - 1) / K;
+    const int blocks_per_xcd = ((waves + FM_BLOCK / 64 - 1) / (FM_BLOCK / 64) + 7) / 8, blocks = blocks_per_xcd * 8;
+    if (getenv("TDV_FM_STATS")) {   // study knob: counts of box tests and leaf openings, printed to stderr
+        unsigned long long* d_stats; unsigned long long h[8];
+        TDV_TRY(ws_alloc(ctx, 8, &d_stats));
+        TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, s));
+        k_fm_query<K, true><<<blocks, FM_BLOCK, 0, s>>>(d_fs, sperm, home, ns, blocks_per_xcd, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, d_corr, d_stats);
+        TDV_HIP(ctx, hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        fprintf(stderr, "[tdv] fm query: %d sources x %d targets, %d leaves, %d groups, %d sources per wave, %llu waves: per wave %.1f group-chunk tests, "
+                "%.1f groups visited, %.1f leaves opened (max %llu); wave time mean %.1f us max %.1f us\n",
+                ns, ix.nt, ix.nleaf, ix.ngroup, K, h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], h[4],
+                (double)h[5] / h[0] * 0.01, (double)h[6] * 0.01);
+    } else {
+        k_fm_query<K, false><<<blocks, FM_BLOCK, 0, s>>>(d_fs, sperm, home, ns, blocks_per_xcd, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, d_corr, nullptr);
+    }
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmIndex& ix, int* d_corr) {
+    if (!ctx || !d_fs || !d_corr || ns < 0) return TDV_ERR_BAD_ARG;
+    if (ns == 0) return TDV_OK;
+    hipStream_t s = ctx->stream;
+    int bucket_shift = 0;
+    while ((ix.nleaf >> bucket_shift) > FMP_BUCKETS) ++bucket_shift;
+    int *home, *bucket_of, *sperm, *hist, *cursor, *start, *d_total;
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &home));
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &bucket_of));
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &sperm));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &hist));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &cursor));
+    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &start));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
+    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
+    k_fm_locate<<<(ns + 255) / 256, 256, 0, s>>>(d_fs, ns, ix.basis, ix.S0, ix.S1, ix.b0, ix.b1, ix.col_leaf0, ix.leaf_p2, bucket_shift, home, bucket_of);
+    const int sblocks = (ns + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
+    k_fm_bucket_hist<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, hist);
+    TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
+    k_fm_scatter<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, start, cursor, sperm);
+    // sources per wave: as many as still leave the chip full of waves
+    static const int force_k = getenv("TDV_FM_K") ? atoi(getenv("TDV_FM_K")) : 0;   // tuning knob
+    const int k = force_k ? force_k : 2;
+    if (k >= 4) return launch_fm_query<4>(ctx, d_fs, sperm, home, ns, ix, d_corr);
+    if (k >= 2) return launch_fm_query<2>(ctx, d_fs, sperm, home, ns, ix, d_corr);
+    return launch_fm_query<1>(ctx, d_fs, sperm, home, ns, ix, d_corr);
+}
+
+int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
+    if (!ctx || !d_fs || !d_ft || !d_corr || ns < 0 || nt < 0) return TDV_ERR_BAD_ARG;
+    if (ns == 0) return TDV_OK;
+    hipStream_t s = ctx->stream;
+    if (nt == 0) { TDV_HIP(ctx, hipMemsetAsync(d_corr, 0, (size_t)ns * 4, s)); return TDV_OK; }
+    const char* brute = getenv("TDV_FM_BRUTE");         // A/B knobs: same results every way
+    const char* keyorder = getenv("TDV_FM_KEYORDER");
+    if (!brute && ns >= 4096 && nt >= 2048) {
+        if (keyorder) return feature_match_keyorder_dev(ctx, d_fs, ns, d_ft, nt, d_corr);
+        FmIndex ix;
+        TDV_TRY(fm_index_build(ctx, d_ft, nt, &ix));
+        return feature_match_indexed_dev(ctx, d_fs, ns, ix, d_corr);
+    }
+    static const bool early = getenv("TDV_FM_NO_EARLY_EXIT") == nullptr;   // A/B knob: same results either way
+    const int ns_pad = (int)align_up((size_t)ns, FM_SRC_PER_BLOCK);
+    const int blocks_x = ns_pad / FM_SRC_PER_BLOCK;
+    // part 0: the first n_seed targets in one split (its exact best seeds the bound of every later split)
+    const int n_seed = early ? std::min(nt, FM_SEED) : 0;
+    const int rest = nt - n_seed;
+    int want = (4096 + blocks_x - 1) / blocks_x;
+    int nsplit = rest > 0 ? std::max(1, std::min(std::min(want, std::max(1, rest / 64)), 64)) : 0;
+    int per_split = nsplit ? (rest + nsplit - 1) / nsplit : 0;
+    nsplit = nsplit ? (rest + per_split - 1) / per_split : 0;
+    const int nparts = nsplit + (n_seed ? 1 : 0);
+    float* pd; int* pj;
+    TDV_TRY(ws_alloc(ctx, (size_t)nparts * ns_pad, &pd));
+    TDV_TRY(ws_alloc(ctx, (size_t)nparts * ns_pad, &pj));
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
+        if (early) {
+            k_feature_match_scan<true><<<dim3(blocks_x, 1), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, n_seed, n_seed, nullptr, nullptr, pd, pj);
+            if (nsplit)   // (ordering the sources by seed distance was measured: no gain on FPFH descriptors, so rows stay in place)
+                k_feature_match_scan<true><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, n_seed, nt, per_split, pd, nullptr,
+                                                                                      pd + ns_pad, pj + ns_pad);
+        } else {
+            k_feature_match_scan<false><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, nt, per_split, nullptr, nullptr, pd, pj);
+        }
+    }
+    k_feature_match_combine<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nparts, pd, pj, d_corr);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+}  // namespace tdv

@@ -3,12 +3,7 @@
 // Replaces Registration::ransacRegistration (/root/reference/src/registration.cpp:204-295), which
 // has no GPU entry point in the reference (src/pipeline.cpp:97-102 calls the CPU static directly).
 // Sub-steps and their kernels:
-//  (i)   feature correspondences (registration.cpp:216-232): 33-D squared distance accumulated in d
-//        order without FMA, strict <, lowest j wins; source descriptors live in VGPRs, target
-//        descriptors are broadcast through the scalar data path (wave-uniform s_load of 33 floats
-//        per target), 98 VALU ops per pair.  k_feature_match_scan is the plain scan (small problems);
-//        k_feature_match_pruned visits key-ordered targets and skips 64-target boxes by an exact
-//        33-D lower bound (same correspondences).
+//  (i)   feature correspondences (registration.cpp:216-232): csrc/fmatch.hip.
 //  (ii)  index triples (registration.cpp:235-239): host, mt19937 + Lemire (ctx.hip), one batch at
 //        a time; a batch is uploaded as int4 (i0,i1,i2,valid).
 //  (iii) k_ransac_hypotheses: one lane per hypothesis — centroids, H = S_c T_c^T, Jacobi SVD,
@@ -32,360 +27,6 @@
 #include <vector>
 
 namespace tdv {
-
-// ------------------------------------------------------------------ feature match
-constexpr int FM_SPL = 2;
-#ifndef FM_BLOCK_VALUE
-#define FM_BLOCK_VALUE 256
-#endif
-constexpr int FM_BLOCK = FM_BLOCK_VALUE;
-constexpr int FM_SRC_PER_BLOCK = FM_SPL * FM_BLOCK;
-constexpr int FD = 33;
-constexpr int FM_SEED = 256;   // targets of the seeding launch
-
-// EARLY: partial-distance early exit.  dist accumulates non-negative terms in d order, and fl(a + b) >= a for b >= 0,
-// so once the partial sum is >= the lane's best the final distance cannot pass the strict "<": a target is dropped
-// as soon as that holds for every lane of the wave (checked after 11 and 22 of the 33 dimensions).  `seed` (the exact
-// best over the first targets, computed by a first launch) lets every split start with a tight bound.
-template <bool EARLY>
-__global__ __launch_bounds__(FM_BLOCK)
-void k_feature_match_scan(const float* __restrict__ fs, int ns, int ns_pad,
-                          const float* __restrict__ ft, int j_begin, int j_end, int per_split,
-                          const float* __restrict__ seed, const uint4* __restrict__ order,
-                          float* __restrict__ pd, int* __restrict__ pj) {
-    const int split = blockIdx.y;
-    const int j0 = j_begin + split * per_split;
-    const int j1 = min(j_end, j0 + per_split);
-    const int base = blockIdx.x * FM_SRC_PER_BLOCK + threadIdx.x;
-    float f[FM_SPL][FD];
-    float best[FM_SPL]; int bj[FM_SPL]; int src[FM_SPL];
-#pragma unroll
-    for (int s = 0; s < FM_SPL; ++s) {
-        // with `order` (records sorted by seed distance, .w = source index) a wave holds sources whose bounds are
-        // alike, so it leaves a target as early as its typical lane does; results go back to the source's own row
-        const int t = base + s * FM_BLOCK;
-        src[s] = order ? (int)order[min(t, ns - 1)].w : t;
-        const int i = min(src[s], ns - 1);
-#pragma unroll
-        for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
-        best[s] = seed ? seed[i] : FLT_MAX;   // a seed comes from lower target indices: strict < keeps the tie rule
-        bj[s] = seed ? -1 : 0;
-        if (order && t >= ns) src[s] = -1;    // padding lane: duplicate work, no output
-    }
-    for (int j = j0; j < j1; ++j) {
-        const float* __restrict__ g = ft + (size_t)j * FD;  // wave-uniform -> scalar loads
-        float q[FD];
-#pragma unroll
-        for (int d = 0; d < FD; ++d) q[d] = g[d];
-        float dist[FM_SPL];
-#pragma unroll
-        for (int s = 0; s < FM_SPL; ++s) dist[s] = 0.f;
-#pragma unroll
-        for (int seg = 0; seg < 3; ++seg) {
-#pragma unroll
-            for (int s = 0; s < FM_SPL; ++s)
-#pragma unroll
-                for (int d = seg * 11; d < seg * 11 + 11; ++d) { float diff = f[s][d] - q[d]; dist[s] += diff * diff; }
-            if (EARLY && seg < 2) {
-                bool alive = false;
-#pragma unroll
-                for (int s = 0; s < FM_SPL; ++s) alive = alive || (dist[s] < best[s]);
-                if (!__any(alive)) goto next_target;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < FM_SPL; ++s) {
-            bool lt = dist[s] < best[s];
-            best[s] = lt ? dist[s] : best[s];
-            bj[s] = lt ? j : bj[s];
-        }
-    next_target:;
-    }
-#pragma unroll
-    for (int s = 0; s < FM_SPL; ++s) {
-        if (src[s] < 0) continue;
-        size_t o = (size_t)split * ns_pad + src[s];
-        pd[o] = best[s]; pj[o] = bj[s];
-    }
-}
-
-// partial results are combined in launch/split order with strict <: the lowest target index wins ties
-__global__ void k_feature_match_combine(int ns, int ns_pad, int nparts, const float* __restrict__ pd,
-                                        const int* __restrict__ pj, int* __restrict__ corr) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
-    float best = FLT_MAX; int bj = 0;
-    for (int s = 0; s < nparts; ++s) {
-        float d = pd[(size_t)s * ns_pad + i];
-        if (d < best) { best = d; bj = pj[(size_t)s * ns_pad + i]; }
-    }
-    corr[i] = bj;
-}
-
-// ---- exact pruned descriptor match (large problems) -------------------------------------------------------------
-// FPFH descriptors of a real part are strongly clustered (most of their variance lies along one direction), so both
-// sides are ordered by a cheap scalar key (the three centre bins) with a counting sort, 33-D bounding boxes are built
-// over runs of 64 ordered targets, and a wave of neighbouring sources skips every box whose lower bound exceeds all
-// its lanes' current best.  The bound is the distance expression itself applied to the per-dimension gaps, summed in
-// the same order: every term is <= the corresponding term of any target inside the box and float addition /
-// multiplication are monotone, so lb <= fl(dist) holds exactly and no margin is needed.  Targets are visited
-// inside-out from the wave's own key position; ties keep the lowest ORIGINAL target index, as the CPU scan does.
-// The order only affects speed: any key (and the arbitrary order inside a bucket) gives the same correspondences.
-constexpr int FMP_KEY_BITS = 7;                       // bits per key of the 2-D Morton bucket
-constexpr int FMP_BUCKETS = 1 << (2 * FMP_KEY_BITS);   // 16384 (64 KB of LDS counters in the ordering kernels)
-constexpr int FMP_BOX = 64;
-constexpr int FMP_TWO_KEYS_MAX_TARGETS = 32768;
-
-__device__ __forceinline__ int fm_bucket(const float* __restrict__ f, int two_keys) {
-    // key 1: the three centre bins (descriptors sum to 1, so it lies in [0, 1]); key 2: the first moment of the phi
-    // sub-histogram (in [0, 10]).  two_keys: FMP_KEY_BITS bits each, interleaved (a 128 x 128 Morton grid) — measured
-    // better against a small model (C4: 128k x 9.4k, 0.71 -> 0.60 ms); else key 1 alone at full resolution — better
-    // when the target side is large (100k x 100k: 8.3 vs 9.6 ms).  An offline study on real descriptors
-    // (tools/studies/feature_match_box_pruning.py) put this pair ahead of every other cheap pair.
-    const float c1 = f[5] + (f[16] + f[27]);
-    if (!two_keys) {
-        const float k = c1 * (float)FMP_BUCKETS;
-        return (k == k) ? (int)fminf(fmaxf(k, 0.f), (float)(FMP_BUCKETS - 1)) : 0;
-    }
-    constexpr float LEVELS = (float)(1 << FMP_KEY_BITS);
-    const float k1 = c1 * LEVELS;
-    float k2 = 0.f;
-#pragma unroll
-    for (int b = 1; b < 11; ++b) k2 += (float)b * f[11 + b];
-    k2 *= LEVELS * 0.1f;
-    const unsigned a = (k1 == k1) ? (unsigned)fminf(fmaxf(k1, 0.f), LEVELS - 1.f) : 0u;
-    const unsigned c = (k2 == k2) ? (unsigned)fminf(fmaxf(k2, 0.f), LEVELS - 1.f) : 0u;
-    unsigned m = 0;
-#pragma unroll
-    for (int i = 0; i < FMP_KEY_BITS; ++i) m |= (((a >> i) & 1u) << (2 * i + 1)) | (((c >> i) & 1u) << (2 * i));
-    return (int)m;
-}
-// Real descriptors crowd a few buckets, so both passes count in an LDS histogram first (one global atomic per
-// non-empty bucket and workgroup instead of one per row).
-constexpr int FMP_SORT_BLOCK = 1024;
-__global__ __launch_bounds__(FMP_SORT_BLOCK)
-void k_fm_hist(const float* __restrict__ f, int n, int two_keys, int* __restrict__ bucket_of, int* __restrict__ hist) {
-    __shared__ int h[FMP_BUCKETS];
-    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
-    __syncthreads();
-    const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
-    if (i < n) {
-        const int b = fm_bucket(f + (size_t)i * FD, two_keys);
-        bucket_of[i] = b;
-        atomicAdd(&h[b], 1);
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) if (h[b]) atomicAdd(&hist[b], h[b]);
-}
-__global__ __launch_bounds__(FMP_SORT_BLOCK)
-void k_fm_scatter(const int* __restrict__ bucket_of, int n, const int* __restrict__ start, int* __restrict__ cursor,
-                  int* __restrict__ perm) {
-    __shared__ int h[FMP_BUCKETS];      // rows of this workgroup per bucket, then the workgroup's base inside the bucket
-    for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) h[b] = 0;
-    __syncthreads();
-    const int i = blockIdx.x * FMP_SORT_BLOCK + threadIdx.x;
-    int b = 0, local = 0;
-    if (i < n) { b = bucket_of[i]; local = atomicAdd(&h[b], 1); }
-    __syncthreads();
-    for (int c = threadIdx.x; c < FMP_BUCKETS; c += FMP_SORT_BLOCK) if (h[c]) h[c] = atomicAdd(&cursor[c], h[c]);
-    __syncthreads();
-    if (i < n) perm[start[b] + h[b] + local] = i;   // order inside a bucket is irrelevant to the result
-}
-__global__ void k_fm_gather_targets(const float* __restrict__ ft, const int* __restrict__ perm, int nt, int nt_pad,
-                                    float* __restrict__ T, int* __restrict__ torig) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t)nt_pad * FD) return;
-    const int row = (int)(e / FD), d = (int)(e % FD);
-    T[e] = row < nt ? ft[(size_t)perm[row] * FD + d] : INFINITY;   // padding rows: distance +inf, never chosen
-    if (d == 0) torig[row] = row < nt ? perm[row] : INT_MAX;
-}
-__global__ void k_fm_boxes(const float* __restrict__ T, int nt, int nbox, float* __restrict__ bmin, float* __restrict__ bmax) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nbox * FD) return;
-    const int b = e / FD, d = e % FD;
-    float mn = INFINITY, mx = -INFINITY;
-    for (int r = b * FMP_BOX; r < min(nt, (b + 1) * FMP_BOX); ++r) { float v = T[(size_t)r * FD + d]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
-    bmin[e] = mn; bmax[e] = mx;
-}
-
-// box visited at position v of the inside-out order centred at box c (bijection onto [0, nbox))
-__device__ __forceinline__ int visit_inside_out(int v, int c, int nbox) {
-    const int L = c, R = nbox - 1 - c;
-    const int m = min(L, R);
-    if (v <= 2 * m) { int k = (v + 1) >> 1; return (v & 1) ? c + k : c - k; }
-    return R > L ? c + (v - m) : c - (v - m);
-}
-
-template <int SPL>
-__global__ __launch_bounds__(FM_BLOCK)
-void k_feature_match_pruned(const float* __restrict__ fs, const int* __restrict__ sperm, int ns, int ns_pad,
-                            const float* __restrict__ T, const int* __restrict__ torig, int nbox,
-                            const float* __restrict__ bmin, const float* __restrict__ bmax, const int* __restrict__ tstart,
-                            int two_keys, int nsplit, float* __restrict__ pd, int* __restrict__ pj) {
-    const int split = blockIdx.y;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wbase = (blockIdx.x * (FM_BLOCK / 64) + wave) * (64 * SPL);   // the wave's 64*SPL consecutive ordered sources
-    float f[SPL][FD];
-    float best[SPL]; int bj[SPL]; int src[SPL];
-#pragma unroll
-    for (int s = 0; s < SPL; ++s) {
-        const int t = wbase + s * 64 + lane;
-        const int i = sperm[min(t, ns - 1)];
-        src[s] = t < ns ? i : -1;   // padding lanes duplicate the last source and write nothing
-#pragma unroll
-        for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
-        best[s] = INFINITY; bj[s] = INT_MAX;
-    }
-    // start where the targets with the wave's own key begin
-    const int c = min(nbox - 1, tstart[__builtin_amdgcn_readfirstlane(fm_bucket(f[0], two_keys))] / FMP_BOX);
-    for (int v = split; v < nbox; v += nsplit) {
-        const int b = visit_inside_out(v, c, nbox);
-        const float* __restrict__ lo = bmin + (size_t)b * FD;   // wave-uniform -> scalar loads
-        const float* __restrict__ hi = bmax + (size_t)b * FD;
-        float lb[SPL];
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) lb[s] = 0.f;
-#pragma unroll
-        for (int d = 0; d < FD; ++d) {
-            const float l = lo[d], h = hi[d];
-#pragma unroll
-            for (int s = 0; s < SPL; ++s) { float g = fmaxf(fmaxf(l - f[s][d], f[s][d] - h), 0.f); lb[s] += g * g; }
-        }
-        bool alive = false;
-#pragma unroll
-        for (int s = 0; s < SPL; ++s) alive = alive || (lb[s] <= best[s]);   // <=: an equal distance with a lower index still wins
-        if (!__any(alive)) continue;
-#pragma unroll 1
-        for (int t = 0; t < FMP_BOX; ++t) {
-            const int j = b * FMP_BOX + t;
-            const float* __restrict__ g = T + (size_t)j * FD;
-            const int o = torig[j];
-            float q[FD];
-#pragma unroll
-            for (int d = 0; d < FD; ++d) q[d] = g[d];
-#pragma unroll
-            for (int s = 0; s < SPL; ++s) {
-                float dist = 0.f;
-#pragma unroll
-                for (int d = 0; d < FD; ++d) { float diff = f[s][d] - q[d]; dist += diff * diff; }
-                const bool take = dist < best[s] || (dist == best[s] && o < bj[s]);
-                best[s] = take ? dist : best[s];
-                bj[s] = take ? o : bj[s];
-            }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < SPL; ++s) {
-        if (src[s] < 0) continue;
-        const size_t o = (size_t)split * ns_pad + src[s];
-        pd[o] = best[s]; pj[o] = bj[s];
-    }
-}
-
-// partials of the pruned match: lexicographic (distance, original index) minimum, order-independent
-__global__ void k_feature_match_combine_lex(int ns, int ns_pad, int nparts, const float* __restrict__ pd,
-                                            const int* __restrict__ pj, int* __restrict__ corr) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
-    float best = INFINITY; int bj = INT_MAX;
-    for (int s = 0; s < nparts; ++s) {
-        const float d = pd[(size_t)s * ns_pad + i]; const int j = pj[(size_t)s * ns_pad + i];
-        if (d < best || (d == best && j < bj)) { best = d; bj = j; }
-    }
-    corr[i] = bj == INT_MAX ? 0 : bj;   // nothing finite: the CPU loop keeps its initial index 0
-}
-
-namespace {
-// counting sort of n descriptors by key bucket: perm (ordered position -> row) and, optionally, the bucket starts
-int fm_order(tdv_ctx* ctx, const float* d_f, int n, int two_keys, int* perm, int* start /* FMP_BUCKETS + 1 */) {
-    hipStream_t s = ctx->stream;
-    int *hist, *cursor, *d_total, *bucket_of;
-    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &hist));
-    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &cursor));
-    TDV_TRY(ws_alloc(ctx, 1, &d_total));
-    TDV_TRY(ws_alloc(ctx, (size_t)n, &bucket_of));
-    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
-    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
-    const int blocks = (n + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
-    k_fm_hist<<<blocks, FMP_SORT_BLOCK, 0, s>>>(d_f, n, two_keys, bucket_of, hist);
-    TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
-    k_fm_scatter<<<blocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, n, start, cursor, perm);
-    TDV_CHECK_LAUNCH(ctx);
-    return TDV_OK;
-}
-
-constexpr int FMP_SPL = 1;   // 1 measured better than 2 (C4: 0.84 vs 0.93 ms)
-
-int feature_match_pruned_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
-    hipStream_t s = ctx->stream;
-    const int nt_pad = (int)align_up((size_t)nt, FMP_BOX);
-    const int nbox = nt_pad / FMP_BOX;
-    constexpr int SRC_PER_BLOCK = FM_BLOCK * FMP_SPL;
-    const int ns_pad = (int)align_up((size_t)ns, SRC_PER_BLOCK);
-    const int blocks_x = ns_pad / SRC_PER_BLOCK;
-    int want = (4096 + blocks_x - 1) / blocks_x;
-    const int nsplit = std::max(1, std::min(std::min(want, std::max(1, nbox / 8)), 32));
-    int *sperm, *tperm, *tstart, *sstart, *torig; float *T, *bmin, *bmax, *pd; int* pj;
-    TDV_TRY(ws_alloc(ctx, (size_t)ns, &sperm));
-    TDV_TRY(ws_alloc(ctx, (size_t)nt, &tperm));
-    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &tstart));
-    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &sstart));
-    TDV_TRY(ws_alloc(ctx, (size_t)nt_pad, &torig));
-    TDV_TRY(ws_alloc(ctx, (size_t)nt_pad * FD, &T));
-    TDV_TRY(ws_alloc(ctx, (size_t)nbox * FD, &bmin));
-    TDV_TRY(ws_alloc(ctx, (size_t)nbox * FD, &bmax));
-    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pd));
-    TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pj));
-    ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
-    const int two_keys = nt <= FMP_TWO_KEYS_MAX_TARGETS ? 1 : 0;
-    TDV_TRY(fm_order(ctx, d_ft, nt, two_keys, tperm, tstart));
-    TDV_TRY(fm_order(ctx, d_fs, ns, two_keys, sperm, sstart));
-    k_fm_gather_targets<<<(unsigned)(((size_t)nt_pad * FD + 255) / 256), 256, 0, s>>>(d_ft, tperm, nt, nt_pad, T, torig);
-    k_fm_boxes<<<(nbox * FD + 255) / 256, 256, 0, s>>>(T, nt, nbox, bmin, bmax);
-    k_feature_match_pruned<FMP_SPL><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, sperm, ns, ns_pad, T, torig, nbox, bmin, bmax, tstart,
-                                                                               two_keys, nsplit, pd, pj);
-    k_feature_match_combine_lex<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nsplit, pd, pj, d_corr);
-    TDV_CHECK_LAUNCH(ctx);
-    return TDV_OK;
-}
-}  // namespace
-
-int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
-    if (!ctx || !d_fs || !d_ft || !d_corr || ns < 0 || nt < 0) return TDV_ERR_BAD_ARG;
-    if (ns == 0) return TDV_OK;
-    hipStream_t s = ctx->stream;
-    if (nt == 0) { TDV_HIP(ctx, hipMemsetAsync(d_corr, 0, (size_t)ns * 4, s)); return TDV_OK; }
-    static const bool pruned_ok = getenv("TDV_FM_BRUTE") == nullptr;         // A/B knob: same results either way
-    if (pruned_ok && ns >= 4096 && nt >= 2048) return feature_match_pruned_dev(ctx, d_fs, ns, d_ft, nt, d_corr);
-    static const bool early = getenv("TDV_FM_NO_EARLY_EXIT") == nullptr;   // A/B knob: same results either way
-    const int ns_pad = (int)align_up((size_t)ns, FM_SRC_PER_BLOCK);
-    const int blocks_x = ns_pad / FM_SRC_PER_BLOCK;
-    // part 0: the first n_seed targets in one split (its exact best seeds the bound of every later split)
-    const int n_seed = early ? std::min(nt, FM_SEED) : 0;
-    const int rest = nt - n_seed;
-    int want = (4096 + blocks_x - 1) / blocks_x;
-    int nsplit = rest > 0 ? std::max(1, std::min(std::min(want, std::max(1, rest / 64)), 64)) : 0;
-    int per_split = nsplit ? (rest + nsplit - 1) / nsplit : 0;
-    nsplit = nsplit ? (rest + per_split - 1) / per_split : 0;
-    const int nparts = nsplit + (n_seed ? 1 : 0);
-    float* pd; int* pj;
-    TDV_TRY(ws_alloc(ctx, (size_t)nparts * ns_pad, &pd));
-    TDV_TRY(ws_alloc(ctx, (size_t)nparts * ns_pad, &pj));
-    {
-        ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
-        if (early) {
-            k_feature_match_scan<true><<<dim3(blocks_x, 1), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, n_seed, n_seed, nullptr, nullptr, pd, pj);
-            if (nsplit)   // (ordering the sources by seed distance was measured: no gain on FPFH descriptors, so rows stay in place)
-                k_feature_match_scan<true><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, n_seed, nt, per_split, pd, nullptr,
-                                                                                      pd + ns_pad, pj + ns_pad);
-        } else {
-            k_feature_match_scan<false><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, nt, per_split, nullptr, nullptr, pd, pj);
-        }
-    }
-    k_feature_match_combine<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nparts, pd, pj, d_corr);
-    TDV_CHECK_LAUNCH(ctx);
-    return TDV_OK;
-}
 
 // ------------------------------------------------------------------ hypotheses
 // pq layout: 8 floats per point: px py pz qx qy qz 0 0  (q = tgt[corr[i]]); padding points have

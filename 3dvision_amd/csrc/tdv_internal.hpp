@@ -100,6 +100,19 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                    float voxel, int max_iterations, float confidence, uint32_t seed,
                    tdv_ransac_result* out, int* trace_inliers);
 int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr);
+// Packed index of a target descriptor set (fmatch.hip): rows in sort-tile-recursive order along the set's principal
+// directions, padded per column, with 33-D boxes of the 64-row leaves and the 64-leaf groups.  Lives in the workspace
+// of the ctx that built it (valid until that ctx's next ws_reset / rewind below the build); read-only afterwards, so a
+// batch builds it once for the model and every instance (on either lane) queries it.
+struct FmIndex {
+    float* T = nullptr; int* torig = nullptr;                       // [leaf][33][64] (row r = column r % 64 of leaf r / 64), [rows] (INT_MAX = padding)
+    float* lbox = nullptr;                                          // leaf boxes [group][min | max][33][64 leaves]
+    float* gbox = nullptr;                                          // group boxes [chunk of 64 groups][min | max][33][64 groups]
+    float *basis = nullptr, *b0 = nullptr, *b1 = nullptr, *leaf_p2 = nullptr; const int* col_leaf0 = nullptr;   // locating a source's cell
+    int nt = 0, rows = 0, nleaf = 0, ngroup = 0, S0 = 1, S1 = 1;
+};
+int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* out);
+int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmIndex& ix, int* d_corr);
 int depth_preprocess_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, int w, int h, float scale,
                          int mask_mode, float* d_out);
 int bilateral_filter_dev(tdv_ctx* ctx, const float* d_in, float* d_out, int w, int h, float sigma_spatial, float sigma_range);

@@ -67,7 +67,7 @@ const char* tdv_version(void);
 
 /* Kernel timing (HIP events on the ctx's stream around the dominant kernels).  Slots:
  * 0 = ICP nearest-neighbour scan, 1 = RANSAC scoring, 2 = feature match, 3 = kNN scan,
- * 4 = radius scan, 5 = depth+unproject, 6 = voxel.  Enabling adds one event pair per launch. */
+ * 4 = radius scan, 5 = depth+unproject, 6 = voxel, 7 = descriptor index.  Enabling adds one event pair per launch. */
 #define TDV_TIMER_ICP_NN 0
 #define TDV_TIMER_RANSAC_SCORE 1
 #define TDV_TIMER_FEATURE_MATCH 2
@@ -75,6 +75,7 @@ const char* tdv_version(void);
 #define TDV_TIMER_RADIUS 4
 #define TDV_TIMER_DEPTH 5
 #define TDV_TIMER_VOXEL 6
+#define TDV_TIMER_FM_INDEX 7   /* packing of the target descriptors (once per model in the batched chain) */
 #define TDV_TIMER_COUNT 8
 int tdv_timing_enable(tdv_ctx* ctx, int on);
 /* Synchronizes the stream, then returns accumulated milliseconds and launch count; resets the slot. */

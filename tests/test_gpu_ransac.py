@@ -163,3 +163,39 @@ def test_feature_match_pruned_degenerate_rows(ctx, orc, synth):
     ref = orc.feature_match(fs, ft)
     assert np.array_equal(got, ref)
     assert got[3] == 0 and got[10] == 0 and not np.isin(got[np.arange(ns) != 3], [77]).any()
+
+
+def test_feature_match_three_paths_on_relief_descriptors(ctx, tdv, orc, synth):
+    """Descriptors of the relief part (the full-chain workload) at a size that takes the packed-index search: the
+    index search, round 1's key-ordered pruned scan (TDV_FM_KEYORDER) and the plain scan (TDV_FM_BRUTE) all return the
+    oracle's correspondences; so do non-finite rows, duplicated rows and a target set that is one repeated row."""
+    import os
+    import chain_scene as cs
+    sc = cs.build(synth, n_instances=1)
+    voxel = 0.0012
+    clouds = []
+    for depth, mask in ((sc["model_depth"], sc["model_mask"]), (sc["depth"][0], sc["masks"][0])):
+        xyz, _ = ctx.depth_to_cloud(depth, mask, None, cs.SCALE, cs.F, cs.F, cs.CX, cs.CY, cs.ZMAX)
+        v, _ = ctx.voxel_downsample(xyz, None, voxel)
+        clouds.append(ctx.compute_fpfh(v, ctx.estimate_normals(v, 30), voxel * 5.0))
+    ft, fs = clouds
+    assert len(fs) >= 4096 and len(ft) >= 2048, (len(fs), len(ft))
+    ft = ft.copy(); fs = fs.copy()
+    ft[5000:5040] = ft[40:80]                    # duplicated rows: the lower index wins
+    fs[:40] = ft[5000:5040]
+    fs[100, 3] = np.nan; fs[101, 7] = np.inf     # rows that match nothing -> index 0 (registration.cpp:218-219)
+    ft[200, 0] = np.nan; ft[201, 5] = np.inf     # rows that are never chosen
+    ref = orc.feature_match(fs, ft)
+    try:
+        for knob in (None, "TDV_FM_KEYORDER", "TDV_FM_BRUTE"):
+            if knob:
+                os.environ[knob] = "1"
+            got = ctx.feature_match(fs, ft)
+            assert np.array_equal(got, ref), (knob, int((got != ref).sum()))
+            if knob:
+                del os.environ[knob]
+    finally:
+        os.environ.pop("TDV_FM_KEYORDER", None); os.environ.pop("TDV_FM_BRUTE", None)
+    assert ref[100] == 0 and ref[101] == 0 and (ref[:40] < 5000).all()
+    one = np.repeat(ft[:1], 3000, 0)
+    assert (ctx.feature_match(fs[:5000], one)[:99] == 0).all()
