@@ -390,18 +390,29 @@ __global__ void k_fm_moments_fold(const double* __restrict__ partial, int nblock
     out[t] = s;
 }
 
+// Principal coordinates p_r(x) = sum_d (x_d - mean_d) * b_r[d], r = 0..2, as evaluated HERE (plain f32, d ascending):
+// the one routine both sides use.  *amax receives (integer atomic max on the bits of a non-negative float) the largest
+// |x_d - mean_d| seen, +inf for non-finite input: it scales the rounding margin of the principal-direction boxes.
 // basis: [3][33] directions, then mean[33]
-__global__ void k_fm_project(const float* __restrict__ f, int n, const float* __restrict__ basis, float* __restrict__ p0,
-                             float* __restrict__ p1, float* __restrict__ p2) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+__device__ __forceinline__ void principal_coords(const float* __restrict__ x, const float* __restrict__ basis, float& a0, float& a1, float& a2, float& am) {
+    a0 = 0.f; a1 = 0.f; a2 = 0.f; am = 0.f;
 #pragma unroll
     for (int d = 0; d < FD; ++d) {
-        const float v = f[(size_t)i * FD + d] - basis[3 * FD + d];
+        const float v = x[d] - basis[3 * FD + d];
         a0 += v * basis[d]; a1 += v * basis[FD + d]; a2 += v * basis[2 * FD + d];
+        const float av = fabsf(v);
+        am = (av <= am) ? am : av;          // NaN: the comparison is false -> am = NaN, mapped to +inf below
     }
-    p0[i] = a0; p1[i] = a1; p2[i] = a2;
+    if (!(am <= FLT_MAX)) am = INFINITY;
+}
+__global__ void k_fm_project(const float* __restrict__ f, int n, const float* __restrict__ basis, float* __restrict__ p0,
+                             float* __restrict__ p1, float* __restrict__ p2, unsigned* __restrict__ amax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, am = 0.f;
+    if (i < n) { principal_coords(f + (size_t)i * FD, basis, a0, a1, a2, am); p0[i] = a0; p1[i] = a1; p2[i] = a2; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(am));
 }
 
 __global__ void k_fm_rec_p0(const float* __restrict__ p0, int n, int n_pow2, uint4* __restrict__ rec) {
@@ -445,8 +456,8 @@ __global__ void k_fm_fill_rows(float* __restrict__ T, int* __restrict__ torig, s
 __device__ __forceinline__ size_t row_elem(size_t row, int d) { return (row / FX_LEAF) * (size_t)(FD * FX_LEAF) + (size_t)d * FX_LEAF + row % FX_LEAF; }
 // after the sort along (column, p2, row): rows to their padded positions
 __global__ void k_fm_place_rows(const uint4* __restrict__ rec, int n, const int* __restrict__ col_start, const int* __restrict__ col_row0, int ncol,
-                                const float* __restrict__ ft, const float* __restrict__ p2, float* __restrict__ T, int* __restrict__ torig,
-                                float* __restrict__ leaf_p2) {
+                                const float* __restrict__ ft, const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ p2,
+                                float* __restrict__ T, int* __restrict__ torig, float* __restrict__ leaf_p2, float* __restrict__ prow /* [3][rows] */, size_t rows) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)n * FD) return;
     const int r = (int)(e / FD), d = (int)(e % FD);
@@ -457,51 +468,73 @@ __global__ void k_fm_place_rows(const uint4* __restrict__ rec, int n, const int*
     if (d == 0) {
         torig[row] = (int)idx;
         if (row % FX_LEAF == 0) leaf_p2[row / FX_LEAF] = p2[idx];
+        prow[row] = p0[idx]; prow[rows + row] = p1[idx]; prow[2 * rows + row] = p2[idx];
     }
 }
-// Leaf boxes over the real rows of 64 padded rows; a leaf of padding only gets the
-// empty box (+inf, -inf): its bound is +inf.  Stored per group, transposed: lbox[group][min | max][33][64 leaves], so a
-// wave reads one dimension of a group's 64 boxes with one coalesced load (lane = leaf); leaves past the end are empty.
-__global__ void k_fm_leaf_boxes(const float* __restrict__ T, const int* __restrict__ torig, int nleaf, int ngroup, float* __restrict__ lbox) {
+// Leaf boxes over the real rows of 64 padded rows; a leaf of padding only gets the empty box (+inf, -inf): its bound is
+// +inf.  Stored per group, transposed: lbox[group][min | max][33][64 leaves], so a wave reads one dimension of a group's
+// 64 boxes with one coalesced load (lane = leaf); leaves past the end are empty.  Beside the 33-D box every leaf has a
+// 3-D box of its rows' principal coordinates, pbox[group][min | max][3][64 leaves]: a leaf IS a cell of the packing in
+// those coordinates, so this box is tight where the 33-D box (axis-aligned, the data are not) is loose; together they
+// open 8 leaves per source where the 33-D box alone opens 19 (tools/studies/feature_match_tail.py).
+constexpr int PD = 3;
+__global__ void k_fm_leaf_boxes(const float* __restrict__ T, const int* __restrict__ torig, const float* __restrict__ prow, size_t rows,
+                                int nleaf, int ngroup, float* __restrict__ lbox, float* __restrict__ pbox) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ngroup * FX_GROUP * FD) return;
-    const int b = e / FD, d = e % FD;
+    if (e >= ngroup * FX_GROUP * (FD + PD)) return;
+    const int b = e / (FD + PD), d = e % (FD + PD);
     float mn = INFINITY, mx = -INFINITY;
     if (b < nleaf)
         for (int r = b * FX_LEAF; r < (b + 1) * FX_LEAF; ++r) {
             if (torig[r] == INT_MAX) continue;
-            const float v = T[row_elem((size_t)r, d)];
+            const float v = d < FD ? T[row_elem((size_t)r, d)] : prow[(size_t)(d - FD) * rows + r];
             mn = fminf(mn, v); mx = fmaxf(mx, v);
         }
-    float* gb = lbox + (size_t)(b / FX_GROUP) * (2 * FD * FX_GROUP);
-    gb[d * FX_GROUP + b % FX_GROUP] = mn; gb[(FD + d) * FX_GROUP + b % FX_GROUP] = mx;
+    if (d < FD) {
+        float* gb = lbox + (size_t)(b / FX_GROUP) * (2 * FD * FX_GROUP);
+        gb[d * FX_GROUP + b % FX_GROUP] = mn; gb[(FD + d) * FX_GROUP + b % FX_GROUP] = mx;
+    } else {
+        float* gb = pbox + (size_t)(b / FX_GROUP) * (2 * PD * FX_GROUP);
+        gb[(d - FD) * FX_GROUP + b % FX_GROUP] = mn; gb[(PD + d - FD) * FX_GROUP + b % FX_GROUP] = mx;
+    }
 }
-// group boxes, same transposed layout one level up: gbox[chunk of 64 groups][min | max][33][64]; groups past the end are empty
-__global__ void k_fm_group_boxes(const float* __restrict__ lbox, int ngroup, int nchunk, float* __restrict__ gbox) {
+// group boxes, same transposed layouts one level up: gbox[chunk of 64 groups][min | max][33][64], gpbox[chunk][min | max][3][64]
+__global__ void k_fm_group_boxes(const float* __restrict__ lbox, const float* __restrict__ pbox, int ngroup, int nchunk,
+                                 float* __restrict__ gbox, float* __restrict__ gpbox) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nchunk * 64 * FD) return;
-    const int g = e / FD, d = e % FD;
+    if (e >= nchunk * 64 * (FD + PD)) return;
+    const int g = e / (FD + PD), d = e % (FD + PD);
     float mn = INFINITY, mx = -INFINITY;
     if (g < ngroup) {
-        const float* gb = lbox + (size_t)g * (2 * FD * FX_GROUP);
-        for (int l = 0; l < FX_GROUP; ++l) { mn = fminf(mn, gb[d * FX_GROUP + l]); mx = fmaxf(mx, gb[(FD + d) * FX_GROUP + l]); }
+        const float* gb = d < FD ? lbox + (size_t)g * (2 * FD * FX_GROUP) : pbox + (size_t)g * (2 * PD * FX_GROUP);
+        const int dd = d < FD ? d : d - FD, nd = d < FD ? FD : PD;
+        for (int l = 0; l < FX_GROUP; ++l) { mn = fminf(mn, gb[dd * FX_GROUP + l]); mx = fmaxf(mx, gb[(nd + dd) * FX_GROUP + l]); }
     }
-    float* cb = gbox + (size_t)(g / 64) * (2 * FD * 64);
-    cb[d * 64 + g % 64] = mn; cb[(FD + d) * 64 + g % 64] = mx;
+    if (d < FD) {
+        float* cb = gbox + (size_t)(g / 64) * (2 * FD * 64);
+        cb[d * 64 + g % 64] = mn; cb[(FD + d) * 64 + g % 64] = mx;
+    } else {
+        float* cb = gpbox + (size_t)(g / 64) * (2 * PD * 64);
+        cb[(d - FD) * 64 + g % 64] = mn; cb[(PD + d - FD) * 64 + g % 64] = mx;
+    }
 }
 
 // home leaf of every source: its cell of the target packing (slab by p0, column by p1, leaf by p2)
 __global__ void k_fm_locate(const float* __restrict__ fs, int ns, const float* __restrict__ basis, int S0, int S1,
                             const float* __restrict__ b0, const float* __restrict__ b1, const int* __restrict__ col_leaf0,
-                            const float* __restrict__ leaf_p2, int bucket_shift, int* __restrict__ home, int* __restrict__ bucket_of) {
+                            const float* __restrict__ leaf_p2, int bucket_shift, int* __restrict__ home, int* __restrict__ bucket_of,
+                            float* __restrict__ sp /* [ns][4]: p0 p1 p2 - */, unsigned* __restrict__ amax) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns) return;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, am = 0.f;
+    if (i < ns) principal_coords(fs + (size_t)i * FD, basis, a0, a1, a2, am);
+    {
+        float wm = am;
 #pragma unroll
-    for (int d = 0; d < FD; ++d) {
-        const float v = fs[(size_t)i * FD + d] - basis[3 * FD + d];
-        a0 += v * basis[d]; a1 += v * basis[FD + d]; a2 += v * basis[2 * FD + d];
+        for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(wm));
     }
+    if (i >= ns) return;
+    *reinterpret_cast<float4*>(sp + (size_t)i * 4) = make_float4(a0, a1, a2, 0.f);
     int k = 0;
     for (int s = 1; s < S0; ++s) k += (b0[s] <= a0) ? 1 : 0;           // boundaries ascend; NaN compares false -> cell 0
     int j = 0;
@@ -564,118 +597,290 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 // Order: home leaf, home group, then every group whose box passes (tested once, lane = group, with the bounds the home
 // group left), inside-out from the home group; inside a group the leaves whose boxes pass (lane = leaf), inside-out.
 // Bounds only shrink, so a mask computed earlier can open a leaf too many, never skip one.
-template <int K, bool STATS>
-__global__ __launch_bounds__(FM_BLOCK, FMQ_WAVES_PER_SIMD)
-void k_fm_query(const float* __restrict__ fs, const int* __restrict__ sperm, const int* __restrict__ home_of, int ns, int blocks_per_xcd,
-                const float* __restrict__ T, const int* __restrict__ torig, int nleaf, int ngroup,
-                const float* __restrict__ lbox, const float* __restrict__ gbox,
-                int* __restrict__ corr, unsigned long long* __restrict__ stats) {
-    const int lane = threadIdx.x & 63;
-    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one).  Give every XCD a CONTIGUOUS stretch of
-    // the home-ordered sources: neighbouring waves open the same leaves, so the stretch's leaves (1/8 of the table) stay
-    // in that XCD's 4 MB L2 instead of every L2 seeing the whole table.
-    const int block = (blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
-    const int wid = block * (FM_BLOCK / 64) + (threadIdx.x >> 6);
-    const int s0 = __builtin_amdgcn_readfirstlane(wid * K);
-    if (s0 >= ns) return;
-    unsigned n_group_tests = 0, n_leaf_tests = 0, n_open = 0;   // STATS only
-    unsigned long long t_start = 0;
-    if (STATS) t_start = wall_clock64();
-    int src[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) src[k] = __builtin_amdgcn_readfirstlane(sperm[min(s0 + k, ns - 1)]);   // past the end: the last source again
-    const int home = min(nleaf - 1, max(0, __builtin_amdgcn_readfirstlane(home_of[src[K / 2]])));
-    float lbest[K]; int lbj[K]; float bound[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) { lbest[k] = FLT_MAX; lbj[k] = INT_MAX; bound[k] = FLT_MAX; }   // registration.cpp:218-219
+struct FmTables {   // device pointers of a packed index + the per-call source-side arrays (plain struct: passed by value)
+    const float* fs; const int* sperm; const int* home_of; int ns;
+    const float* T; const int* torig; int nleaf, ngroup;
+    const float *lbox, *gbox, *pbox, *gpbox;
+    const float* sp; const unsigned *amax_t, *amax_s; float pscale;
+};
 
-    auto open_leaf = [&](int leaf) {
-        const float* __restrict__ blk = T + (size_t)leaf * (FD * FX_LEAF);
-        float row[FD];
-#pragma unroll
-        for (int d = 0; d < FD; ++d) row[d] = blk[d * FX_LEAF + lane];
-        const int ro = torig[(size_t)leaf * FX_LEAF + lane];
+// The search state of one wave: K sources, lane = target-side item.  SHARED: the bounds are also kept in LDS words
+// (integer atomic min on the bits of a non-negative float) so that several waves working on the same sources tighten
+// each other's bounds.
+template <int K, bool SHARED>
+struct FmWave {
+    const FmTables& t;
+    const int lane;
+    int src[K];
+    float lbest[K]; int lbj[K]; float bound[K];
+    float pmargin;
+    int home, hg;
+    int* s_bound;                 // SHARED only
+    unsigned n_open = 0, n_leaf_tests = 0, n_group_tests = 0;
+
+    __device__ __forceinline__ FmWave(const FmTables& tt, int s0, int* sb) : t(tt), lane(threadIdx.x & 63), s_bound(sb) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const float* __restrict__ q = fs + (size_t)src[k] * FD;   // wave-uniform -> scalar loads
+            src[k] = __builtin_amdgcn_readfirstlane(t.sperm[min(s0 + k, t.ns - 1)]);   // past the end: the last source again
+            lbest[k] = FLT_MAX; lbj[k] = INT_MAX; bound[k] = FLT_MAX;                  // registration.cpp:218-219
+        }
+        home = min(t.nleaf - 1, max(0, __builtin_amdgcn_readfirstlane(t.home_of[src[K / 2]])));
+        hg = home / FX_GROUP;
+        // rounding margin of a principal-coordinate gap (principal_bound_note): 3e-5 * largest |x_d - mean_d| on either side
+        pmargin = 3e-5f * fmaxf(__uint_as_float(__builtin_amdgcn_readfirstlane(*t.amax_t)), __uint_as_float(__builtin_amdgcn_readfirstlane(*t.amax_s)));
+    }
+    __device__ __forceinline__ void refresh() {
+        if (SHARED) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) bound[k] = fminf(bound[k], __int_as_float(__builtin_amdgcn_readfirstlane(s_bound[k])));
+        }
+    }
+    __device__ __forceinline__ void load_leaf(int leaf, float (&row)[FD], int& ro) const {
+        const float* __restrict__ blk = t.T + (size_t)leaf * (FD * FX_LEAF);
+#pragma unroll
+        for (int d = 0; d < FD; ++d) row[d] = blk[d * FX_LEAF + lane];
+        ro = t.torig[(size_t)leaf * FX_LEAF + lane];
+    }
+    __device__ __forceinline__ void eval_leaf(const float (&row)[FD], int ro) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float* __restrict__ q = t.fs + (size_t)src[k] * FD;   // wave-uniform -> scalar loads
             float dist = 0.f;
 #pragma unroll
             for (int d = 0; d < FD; ++d) { const float diff = q[d] - row[d]; dist += diff * diff; }   // registration.cpp:222-224
             const bool take = dist < lbest[k] || (dist == lbest[k] && ro < lbj[k] && lbest[k] < FLT_MAX);
             lbest[k] = take ? dist : lbest[k];
             lbj[k] = take ? ro : lbj[k];
-            bound[k] = wave_min_f32(lbest[k]);
+            const float m = wave_min_f32(lbest[k]);
+            if (m < bound[k]) {
+                bound[k] = m;
+                if (SHARED && lane == 0) atomicMin(&s_bound[k], __float_as_int(m));
+            }
         }
-        if (STATS) ++n_open;
-    };
-    // lanes = the 64 boxes of one [min | max][33][64] block; bit b of the result: some source may still find a better row in box b
-    auto box_mask = [&](const float* __restrict__ blk) -> unsigned long long {
+        ++n_open;
+    }
+    __device__ __forceinline__ void open_leaf(int leaf) {
+        float row[FD]; int ro;
+        load_leaf(leaf, row, ro);
+        eval_leaf(row, ro);
+    }
+    // lanes = the 64 boxes of one block; bit b of the result: some source may still find a better row in box b.
+    // principal_bound_note — the 3-D box is tested first (6 loads), the 33-D box (66 loads) only if it leaves anything.
+    // Why the 3-D bound is safe although a projection is not monotone in float arithmetic: for orthonormal directions
+    // sum_r (p_r(q) - p_r(t))^2 <= |q - t|^2 in real numbers.  (i) The f32 directions are orthonormal to 1.2e-7 (checked on
+    // the host, else pscale = 0 disables the test).  (ii) A computed coordinate (33 sequential mul/add, no FMA) is within
+    // 34 u * sqrt(33) * M = 1.2e-5 M of its real value, M = largest |x_d - mean_d|: a computed gap to the box exceeds the
+    // real gap to any row by at most 2.5e-5 M; pmargin = 3e-5 M is subtracted.  (iii) fl(dist) >= |q - t|^2 (1 - 36 u).
+    // pscale = 1 - 1e-4 covers (i), (iii) and the rounding of the three squares with a factor 30 to spare.  Non-finite
+    // input makes M = +inf: gaps clamp to 0 and only the 33-D test decides.
+    __device__ __forceinline__ unsigned long long box_mask(const float* __restrict__ blk, const float* __restrict__ pblk) {
+        float lbp[K]; bool pa[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) lbp[k] = 0.f;
+#pragma unroll
+        for (int r = 0; r < PD; ++r) {
+            const float lo = pblk[r * 64 + lane], hi = pblk[(PD + r) * 64 + lane];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float pq = t.sp[(size_t)src[k] * 4 + r];   // wave-uniform -> scalar load
+                const float g = fmaxf(fmaxf(lo - pq, pq - hi) - pmargin, 0.f);
+                lbp[k] += g * g;
+            }
+        }
+        unsigned long long any = 0ull;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { pa[k] = !(lbp[k] * t.pscale > bound[k]); any |= __ballot(pa[k]); }
+        if (!any) return 0ull;
         float lb[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) lb[k] = 0.f;
-#pragma unroll
+#pragma unroll 11   // 22 loads in flight; full unrolling hoists all 66 and spills
         for (int d = 0; d < FD; ++d) {   // one dimension of the 64 boxes at a time: two coalesced loads, K bounds advance
             const float lo = blk[d * 64 + lane], hi = blk[(FD + d) * 64 + lane];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const float qd = fs[(size_t)src[k] * FD + d];   // wave-uniform -> scalar load
+                const float qd = t.fs[(size_t)src[k] * FD + d];   // wave-uniform -> scalar load
                 const float g = fmaxf(fmaxf(lo - qd, qd - hi), 0.f);
                 lb[k] += g * g;
             }
         }
         unsigned long long m = 0ull;
 #pragma unroll
-        for (int k = 0; k < K; ++k) m |= __ballot(lb[k] <= bound[k]);    // an empty box (+inf, -inf) has lb = +inf: never set
+        for (int k = 0; k < K; ++k) m |= __ballot(pa[k] && lb[k] <= bound[k]);    // an empty box (+inf, -inf) has lb = +inf: never set
         return m;
-    };
-    const int hg = home / FX_GROUP;
-    auto visit_group = [&](int g) {
-        const int l0 = g * FX_GROUP, cnt = min(FX_GROUP, nleaf - l0);
-        unsigned long long m = box_mask(lbox + (size_t)g * (2 * FD * FX_GROUP));
-        if (STATS) n_leaf_tests += 1;
-        if (g == hg) m &= ~(1ull << (home - l0));
+    }
+    __device__ __forceinline__ unsigned long long leaf_mask(int g) {
+        ++n_leaf_tests;
+        unsigned long long m = box_mask(t.lbox + (size_t)g * (2 * FD * FX_GROUP), t.pbox + (size_t)g * (2 * PD * FX_GROUP));
+        if (g == hg) m &= ~(1ull << (home - g * FX_GROUP));
+        return m;
+    }
+    __device__ __forceinline__ unsigned long long group_mask(int c) {
+        ++n_group_tests;
+        unsigned long long m = box_mask(t.gbox + (size_t)c * (2 * FD * 64), t.gpbox + (size_t)c * (2 * PD * 64));
+        if (hg >= 0 && hg / 64 == c) m &= ~(1ull << (hg % 64));
+        return m;
+    }
+    // The leaves of group g whose boxes pass, inside-out from the home side.  The mask is known before the first leaf is
+    // opened, so the next leaf's 34 loads are issued before the current leaf is evaluated (two register buffers): a wave
+    // that opens many leaves no longer pays a full memory round trip for each.
+    __device__ __forceinline__ void visit_group(int g) {
+        const int l0 = g * FX_GROUP, cnt = min(FX_GROUP, t.nleaf - l0);
+        unsigned long long m = leaf_mask(g);
         const int centre = (g == hg) ? home - l0 : (g < hg ? cnt - 1 : 0);   // enter a neighbouring group from the home side
-        for (int u = 0; u < cnt && m; ++u) {
-            const int l = visit_inside_out(u, centre, cnt);
-            if (!((m >> l) & 1ull)) continue;
-            m &= ~(1ull << l);
-            open_leaf(l0 + l);
-        }
-    };
-
-    open_leaf(home);
-    visit_group(hg);
-    const int nchunk = (ngroup + 63) / 64;
-    for (int c = 0; c < nchunk; ++c) {     // (chunks in index order; within a chunk inside-out from the home group's side)
-        unsigned long long m = box_mask(gbox + (size_t)c * (2 * FD * 64));
-        if (STATS) n_group_tests += 1;
-        const int g0 = c * 64, cnt = min(64, ngroup - g0);
-        if (hg >= g0 && hg < g0 + cnt) m &= ~(1ull << (hg - g0));
-        const int centre = hg < g0 ? 0 : (hg >= g0 + cnt ? cnt - 1 : hg - g0);
-        for (int u = 0; u < cnt && m; ++u) {
-            const int g = visit_inside_out(u, centre, cnt);
-            if (!((m >> g) & 1ull)) continue;
-            m &= ~(1ull << g);
-            visit_group(g0 + g);
+        int u = 0;
+        auto next = [&]() -> int {
+            while (m && u < cnt) {
+                const int l = visit_inside_out(u++, centre, cnt);
+                if ((m >> l) & 1ull) { m &= ~(1ull << l); return l0 + l; }
+            }
+            return -1;
+        };
+        int cur = next();
+        if (cur < 0) return;
+        float a[FD], b[FD]; int roa, rob = 0;
+        load_leaf(cur, a, roa);
+        for (;;) {
+            const int n1 = next();
+            if (n1 >= 0) load_leaf(n1, b, rob);
+            eval_leaf(a, roa);
+            if (n1 < 0) break;
+            const int n2 = next();
+            if (n2 >= 0) load_leaf(n2, a, roa);
+            eval_leaf(b, rob);
+            if (n2 < 0) break;
         }
     }
-    // lowest (distance, original index) over the lanes; nothing finite -> the reference keeps index 0
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        float bd = lbest[k]; int bo = lbj[k];
+    // lowest (distance, original index) of source k over the lanes
+    __device__ __forceinline__ void result(int k, float& bd, int& bo) const {
+        bd = lbest[k]; bo = lbj[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const float od = __shfl_xor(bd, off, 64); const int oo = __shfl_xor(bo, off, 64);
             const bool tk = od < bd || (od == bd && oo < bo);
             bd = tk ? od : bd; bo = tk ? oo : bo;
         }
-        if (lane == 0 && s0 + k < ns) corr[src[k]] = bo == INT_MAX ? 0 : bo;
     }
-    if (STATS && lane == 0) {   // [0] waves, [1] group-chunk tests, [2] groups visited, [3] leaves opened, [4] most leaves opened by one wave
+};
+
+// Pass A: one wave per K sources.  Home leaf, home group, then every group whose box passes (tested once per chunk of 64
+// groups, lane = group, with the bounds the home group left), inside-out from the home group.  A wave whose sources
+// turn out to be outliers (far from every target: most boxes pass) stops after `leaf_limit` leaves, stores what it has
+// (part_d / part_j) and puts its sources on the overflow list: pass B spreads them over 8 waves each.  Without that the
+// call waits for a few waves that open hundreds of leaves one after the other (measured: 580 leaves, 1.3 of 1.5 ms).
+template <int K, bool STATS>
+__global__ __launch_bounds__(FM_BLOCK, FMQ_WAVES_PER_SIMD)
+void k_fm_query(FmTables t, int blocks_per_xcd, int leaf_limit, int* __restrict__ overflow_count, int* __restrict__ overflow_list,
+                float* __restrict__ part_d, int* __restrict__ part_j, int* __restrict__ corr, unsigned long long* __restrict__ stats) {
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one).  Give every XCD a CONTIGUOUS stretch of
+    // the home-ordered sources: neighbouring waves open the same leaves, so the stretch's leaves (1/8 of the table) stay
+    // in that XCD's 4 MB L2 instead of every L2 seeing the whole table.
+    const int block = (blockIdx.x & 7) * blocks_per_xcd + (blockIdx.x >> 3);
+    const int wid = block * (FM_BLOCK / 64) + (threadIdx.x >> 6);
+    const int s0 = __builtin_amdgcn_readfirstlane(wid * K);
+    if (s0 >= t.ns) return;
+    unsigned long long t_start = 0;
+    if (STATS) t_start = wall_clock64();
+    FmWave<K, false> w(t, s0, nullptr);
+    w.open_leaf(w.home);
+    w.visit_group(w.hg);
+    bool overflow = false;
+    const int nchunk = (t.ngroup + 63) / 64;
+    for (int c = 0; c < nchunk && !overflow; ++c) {     // (chunks in index order; within a chunk inside-out from the home group's side)
+        unsigned long long m = w.group_mask(c);
+        const int g0 = c * 64, cnt = min(64, t.ngroup - g0);
+        const int centre = w.hg < g0 ? 0 : (w.hg >= g0 + cnt ? cnt - 1 : w.hg - g0);
+        for (int u = 0; u < cnt && m; ++u) {
+            const int g = visit_inside_out(u, centre, cnt);
+            if (!((m >> g) & 1ull)) continue;
+            m &= ~(1ull << g);
+            if ((int)w.n_open >= leaf_limit) { overflow = true; break; }
+            w.visit_group(g0 + g);
+        }
+    }
+    int slot = 0;
+    if (overflow && w.lane == 0) slot = atomicAdd(overflow_count, 1);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float bd; int bo;
+        w.result(k, bd, bo);
+        if (w.lane == 0 && s0 + k < t.ns) {
+            if (overflow) { part_d[w.src[k]] = bd; part_j[w.src[k]] = bo; }
+            else corr[w.src[k]] = bo == INT_MAX ? 0 : bo;   // nothing finite -> the reference keeps index 0
+        }
+    }
+    if (overflow && w.lane == 0) overflow_list[slot] = s0;
+    if (STATS && w.lane == 0) {   // [0] waves, [1] group-chunk tests, [2] groups visited, [3] leaves opened, [4] most leaves opened by one wave
         const unsigned long long dt = wall_clock64() - t_start;   // 100 MHz ticks
-        atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)n_group_tests); atomicAdd(&stats[2], (unsigned long long)n_leaf_tests);
-        atomicAdd(&stats[3], (unsigned long long)n_open); atomicMax(&stats[4], (unsigned long long)n_open);
+        atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)w.n_group_tests); atomicAdd(&stats[2], (unsigned long long)w.n_leaf_tests);
+        atomicAdd(&stats[3], (unsigned long long)w.n_open); atomicMax(&stats[4], (unsigned long long)w.n_open);
         atomicAdd(&stats[5], dt); atomicMax(&stats[6], dt);
+    }
+}
+
+// Pass B: the sources pass A gave up on, one workgroup of 8 waves per K of them.  Every wave tests the group boxes
+// with the same bounds (pass A's best, which already saw the home neighbourhood) and takes every 8th passing group;
+// bounds found by one wave reach the others through LDS.  The result is the lexicographic minimum of pass A's partial
+// answer and the 8 waves' answers, so it does not matter that pass A's groups are visited again.
+constexpr int FMB_WAVES = 8;
+template <int K, bool STATS>
+__global__ __launch_bounds__(FMB_WAVES * 64)
+void k_fm_query_overflow(FmTables t, const int* __restrict__ overflow_count, const int* __restrict__ overflow_list,
+                         const float* __restrict__ part_d, const int* __restrict__ part_j, int* __restrict__ corr,
+                         unsigned long long* __restrict__ stats) {
+    __shared__ int s_bound[K];
+    __shared__ float s_fd[FMB_WAVES][K];
+    __shared__ int s_fj[FMB_WAVES][K];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int count = *overflow_count;
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int s0 = overflow_list[e];
+        FmWave<K, true> w(t, s0, s_bound);
+        if (threadIdx.x < K) s_bound[threadIdx.x] = __float_as_int(fminf(part_d[t.sperm[min(s0 + (int)threadIdx.x, t.ns - 1)]], FLT_MAX));
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; ++k) w.bound[k] = __int_as_float(s_bound[k]);
+        w.hg = -1;                                   // no group is special here: pass A's partial answer covers what it saw
+        w.home = -1;
+        const int nchunk = (t.ngroup + 63) / 64;
+        int turn = 0;
+        for (int c = 0; c < nchunk; ++c) {
+            float keep[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) keep[k] = w.bound[k];
+#pragma unroll
+            for (int k = 0; k < K; ++k) w.bound[k] = __int_as_float(__float_as_int(part_d[w.src[k]]));   // the bound every wave shares
+            unsigned long long m = w.group_mask(c);
+#pragma unroll
+            for (int k = 0; k < K; ++k) w.bound[k] = keep[k];
+            const int g0 = c * 64;
+            while (m) {
+                const int g = __builtin_ctzll(m);
+                m &= m - 1;
+                if (turn++ % FMB_WAVES != wave) continue;
+                w.refresh();
+                w.visit_group(g0 + g);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float bd; int bo;
+            w.result(k, bd, bo);
+            if (w.lane == 0) { s_fd[wave][k] = bd; s_fj[wave][k] = bo; }
+        }
+        __syncthreads();
+        if (threadIdx.x < K && s0 + (int)threadIdx.x < t.ns) {
+            const int k = threadIdx.x;
+            const int i = t.sperm[s0 + k];
+            float bd = part_d[i]; int bo = part_j[i];
+            for (int v = 0; v < FMB_WAVES; ++v) {
+                const float od = s_fd[v][k]; const int oo = s_fj[v][k];
+                if (od < bd || (od == bd && oo < bo)) { bd = od; bo = oo; }
+            }
+            corr[i] = bo == INT_MAX ? 0 : bo;
+        }
+        if (STATS && w.lane == 0) { atomicAdd(&stats[8], 1ull); atomicAdd(&stats[9], (unsigned long long)w.n_open); atomicMax(&stats[10], (unsigned long long)w.n_open); }
+        __syncthreads();   // the LDS words are reused by the next entry
     }
 }
 
@@ -759,6 +964,17 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
         for (int r = 0; r < 3; ++r) for (int d = 0; d < FD; ++d) h_basis[r * FD + d] = (d % 3 == r) ? 1.f : 0.f;
         for (int d = 0; d < FD; ++d) h_basis[3 * FD + d] = 0.f;
     }
+    // how far the f32 directions are from orthonormal decides whether their boxes may be used (k_fm_query, principal_bound_note)
+    {
+        double dev = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double g = 0.0;
+                for (int d = 0; d < FD; ++d) g += (double)h_basis[a * FD + d] * (double)h_basis[b * FD + d];
+                dev += (g - (a == b ? 1.0 : 0.0)) * (g - (a == b ? 1.0 : 0.0));
+            }
+        ix->pscale = (std::sqrt(dev) <= 1e-6) ? (1.0f - 1e-4f) : 0.0f;
+    }
     // 2. slab / column counts: S0 * S1 * S2 = number of leaves with S_d proportional to the spread along p_d
     const double nleaf_t = std::max(1.0, (double)nt / FX_LEAF);
     const double tiny = 1e-6 * std::max(e0, 1e-30);
@@ -800,11 +1016,16 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     const int nchunk = (ngroup + 63) / 64;
     TDV_TRY(ws_alloc(ctx, (size_t)ngroup * 2 * FD * FX_GROUP, &ix->lbox));
     TDV_TRY(ws_alloc(ctx, (size_t)nchunk * 2 * FD * 64, &ix->gbox));
+    TDV_TRY(ws_alloc(ctx, (size_t)ngroup * 2 * PD * FX_GROUP, &ix->pbox));
+    TDV_TRY(ws_alloc(ctx, (size_t)nchunk * 2 * PD * 64, &ix->gpbox));
+    TDV_TRY(ws_alloc(ctx, 1, &ix->amax));
     const WsMark scratch = ws_mark(ctx);   // everything below is build scratch
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &p0));
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &p1));
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &p2));
     TDV_TRY(ws_alloc(ctx, n_pow2, &rec));
+    float* prow;
+    TDV_TRY(ws_alloc(ctx, rows * PD, &prow));
     char* stage = ctx->pin + 8192;   // the moments occupied the first bytes
     std::memcpy(stage, h_basis, sizeof(h_basis));
     std::memcpy(stage + sizeof(h_basis), h_int.data(), h_int.size() * 4);
@@ -817,7 +1038,8 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     TDV_HIP(ctx, hipMemsetAsync(ix->b0, 0, ((size_t)S0 + 1) * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(ix->b1, 0, ((size_t)ncol + 1) * 4, s));
     const unsigned gn = (unsigned)((nt + 255) / 256);
-    k_fm_project<<<gn, 256, 0, s>>>(d_ft, nt, basis, p0, p1, p2);
+    TDV_HIP(ctx, hipMemsetAsync(ix->amax, 0, 4, s));
+    k_fm_project<<<gn, 256, 0, s>>>(d_ft, nt, basis, p0, p1, p2, ix->amax);
     k_fm_rec_p0<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(p0, nt, (int)n_pow2, rec);
     TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
     k_fm_rec_p1<<<gn, 256, 0, s>>>(rec, nt, d_slab_start, S0, p0, p1, ix->b0);
@@ -825,9 +1047,9 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     k_fm_rec_p2<<<gn, 256, 0, s>>>(rec, nt, d_col_start, ncol, p1, p2, ix->b1);
     TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
     k_fm_fill_rows<<<(unsigned)((rows * FD + 255) / 256), 256, 0, s>>>(ix->T, ix->torig, rows);
-    k_fm_place_rows<<<(unsigned)(((size_t)nt * FD + 255) / 256), 256, 0, s>>>(rec, nt, d_col_start, d_col_row0, ncol, d_ft, p2, ix->T, ix->torig, ix->leaf_p2);
-    k_fm_leaf_boxes<<<(ngroup * FX_GROUP * FD + 255) / 256, 256, 0, s>>>(ix->T, ix->torig, nleaf, ngroup, ix->lbox);
-    k_fm_group_boxes<<<(nchunk * 64 * FD + 255) / 256, 256, 0, s>>>(ix->lbox, ngroup, nchunk, ix->gbox);
+    k_fm_place_rows<<<(unsigned)(((size_t)nt * FD + 255) / 256), 256, 0, s>>>(rec, nt, d_col_start, d_col_row0, ncol, d_ft, p0, p1, p2, ix->T, ix->torig, ix->leaf_p2, prow, rows);
+    k_fm_leaf_boxes<<<(ngroup * FX_GROUP * (FD + PD) + 255) / 256, 256, 0, s>>>(ix->T, ix->torig, prow, rows, nleaf, ngroup, ix->lbox, ix->pbox);
+    k_fm_group_boxes<<<(nchunk * 64 * (FD + PD) + 255) / 256, 256, 0, s>>>(ix->lbox, ix->pbox, ngroup, nchunk, ix->gbox, ix->gpbox);
     TDV_CHECK_LAUNCH(ctx);
     TDV_HIP(ctx, hipStreamSynchronize(s));   // the pinned staging is reused by later calls; the scratch is released here
     ws_rewind(ctx, scratch);
@@ -835,23 +1057,29 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
 }
 
 template <int K>
-static int launch_fm_query(tdv_ctx* ctx, const float* d_fs, const int* sperm, const int* home, int ns, const FmIndex& ix, int* d_corr) {
+static int launch_fm_query(tdv_ctx* ctx, const FmTables& t, int* overflow_count, int* overflow_list, float* part_d, int* part_j, int* d_corr) {
     hipStream_t s = ctx->stream;
-    const int waves = (ns + K - 1) / K;
+    const int waves = (t.ns + K - 1) / K;
     const int blocks_per_xcd = ((waves + FM_BLOCK / 64 - 1) / (FM_BLOCK / 64) + 7) / 8, blocks = blocks_per_xcd * 8;
+    static const int leaf_limit = getenv("TDV_FM_LIMIT") ? atoi(getenv("TDV_FM_LIMIT")) : 48;   // tuning knob
+    const int bblocks = 1024;
     if (getenv("TDV_FM_STATS")) {   // study knob: counts of box tests and leaf openings, printed to stderr
-        unsigned long long* d_stats; unsigned long long h[8];
-        TDV_TRY(ws_alloc(ctx, 8, &d_stats));
-        TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, s));
-        k_fm_query<K, true><<<blocks, FM_BLOCK, 0, s>>>(d_fs, sperm, home, ns, blocks_per_xcd, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, d_corr, d_stats);
-        TDV_HIP(ctx, hipMemcpyAsync(h, d_stats, 64, hipMemcpyDeviceToHost, s));
+        unsigned long long* d_stats; unsigned long long h[12]; int h_over = 0;
+        TDV_TRY(ws_alloc(ctx, 12, &d_stats));
+        TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 96, s));
+        k_fm_query<K, true><<<blocks, FM_BLOCK, 0, s>>>(t, blocks_per_xcd, leaf_limit, overflow_count, overflow_list, part_d, part_j, d_corr, d_stats);
+        k_fm_query_overflow<K, true><<<bblocks, FMB_WAVES * 64, 0, s>>>(t, overflow_count, overflow_list, part_d, part_j, d_corr, d_stats);
+        TDV_HIP(ctx, hipMemcpyAsync(h, d_stats, 96, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipMemcpyAsync(&h_over, overflow_count, 4, hipMemcpyDeviceToHost, s));
         TDV_HIP(ctx, hipStreamSynchronize(s));
-        fprintf(stderr, "[tdv] fm query: %d sources x %d targets, %d leaves, %d groups, %d sources per wave, %llu waves: per wave %.1f group-chunk tests, "
-                "%.1f groups visited, %.1f leaves opened (max %llu); wave time mean %.1f us max %.1f us\n",
-                ns, ix.nt, ix.nleaf, ix.ngroup, K, h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], h[4],
-                (double)h[5] / h[0] * 0.01, (double)h[6] * 0.01);
+        fprintf(stderr, "[tdv] fm query: %d sources x %d leaves, %d groups, %d sources per wave, %llu waves: per wave %.1f group-chunk tests, "
+                "%.1f groups visited, %.1f leaves opened (max %llu); wave time mean %.1f us max %.1f us; overflow: %d waves -> %llu helper waves, "
+                "%.1f leaves each (max %llu)\n",
+                t.ns, t.nleaf, t.ngroup, K, h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], h[4],
+                (double)h[5] / h[0] * 0.01, (double)h[6] * 0.01, h_over, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10]);
     } else {
-        k_fm_query<K, false><<<blocks, FM_BLOCK, 0, s>>>(d_fs, sperm, home, ns, blocks_per_xcd, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, d_corr, nullptr);
+        k_fm_query<K, false><<<blocks, FM_BLOCK, 0, s>>>(t, blocks_per_xcd, leaf_limit, overflow_count, overflow_list, part_d, part_j, d_corr, nullptr);
+        k_fm_query_overflow<K, false><<<bblocks, FMB_WAVES * 64, 0, s>>>(t, overflow_count, overflow_list, part_d, part_j, d_corr, nullptr);
     }
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
@@ -863,7 +1091,14 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     hipStream_t s = ctx->stream;
     int bucket_shift = 0;
     while ((ix.nleaf >> bucket_shift) > FMP_BUCKETS) ++bucket_shift;
-    int *home, *bucket_of, *sperm, *hist, *cursor, *start, *d_total;
+    int *home, *bucket_of, *sperm, *hist, *cursor, *start, *d_total; float* sp; unsigned* amax_s;
+    int *overflow_count, *overflow_list, *part_j; float* part_d;
+    TDV_TRY(ws_alloc(ctx, 1, &overflow_count));
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &overflow_list));
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &part_d));
+    TDV_TRY(ws_alloc(ctx, (size_t)ns, &part_j));
+    TDV_TRY(ws_alloc(ctx, (size_t)ns * 4, &sp));
+    TDV_TRY(ws_alloc(ctx, 1, &amax_s));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &home));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &bucket_of));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &sperm));
@@ -874,17 +1109,19 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
     TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
-    k_fm_locate<<<(ns + 255) / 256, 256, 0, s>>>(d_fs, ns, ix.basis, ix.S0, ix.S1, ix.b0, ix.b1, ix.col_leaf0, ix.leaf_p2, bucket_shift, home, bucket_of);
+    TDV_HIP(ctx, hipMemsetAsync(amax_s, 0, 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(overflow_count, 0, 4, s));
+    k_fm_locate<<<(ns + 255) / 256, 256, 0, s>>>(d_fs, ns, ix.basis, ix.S0, ix.S1, ix.b0, ix.b1, ix.col_leaf0, ix.leaf_p2, bucket_shift, home, bucket_of, sp, amax_s);
     const int sblocks = (ns + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
     k_fm_bucket_hist<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, hist);
     TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
     k_fm_scatter<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, start, cursor, sperm);
-    // sources per wave: as many as still leave the chip full of waves
-    static const int force_k = getenv("TDV_FM_K") ? atoi(getenv("TDV_FM_K")) : 0;   // tuning knob
+    FmTables t{d_fs, sperm, home, ns, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, ix.pbox, ix.gpbox, sp, ix.amax, amax_s, ix.pscale};
+    static const int force_k = getenv("TDV_FM_K") ? atoi(getenv("TDV_FM_K")) : 0;   // tuning knob (sources per wave)
     const int k = force_k ? force_k : 2;
-    if (k >= 4) return launch_fm_query<4>(ctx, d_fs, sperm, home, ns, ix, d_corr);
-    if (k >= 2) return launch_fm_query<2>(ctx, d_fs, sperm, home, ns, ix, d_corr);
-    return launch_fm_query<1>(ctx, d_fs, sperm, home, ns, ix, d_corr);
+    if (k >= 4) return launch_fm_query<4>(ctx, t, overflow_count, overflow_list, part_d, part_j, d_corr);
+    if (k >= 2) return launch_fm_query<2>(ctx, t, overflow_count, overflow_list, part_d, part_j, d_corr);
+    return launch_fm_query<1>(ctx, t, overflow_count, overflow_list, part_d, part_j, d_corr);
 }
 
 int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {

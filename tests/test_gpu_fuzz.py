@@ -111,3 +111,29 @@ def test_feature_match_pruned_fuzz(ctx, orc):
         if trial == 3:
             ft[:, 5] = 0; fs[:, 16] = 0
         assert np.array_equal(ctx.feature_match(fs, ft), orc.feature_match(fs, ft)), trial
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e4])
+def test_feature_match_principal_box_margins(ctx, orc, scale):
+    """The packed-index search prunes with boxes in the targets' principal coordinates, a bound that is only safe with
+    a rounding margin (fmatch.hip, principal_bound_note).  Data that stress it: rows on a thin curved filament (almost
+    all variance in one direction, tiny but decisive off-axis differences), a large common offset (cancellation in
+    x - mean), magnitudes from 1e-4 to 3e4, queries far off the filament, and exact ties."""
+    rng = np.random.default_rng(int(scale * 1000) % 97 + 5)
+    ns, nt = 5200, 3100
+    axis = rng.normal(size=33); axis /= np.linalg.norm(axis)
+    bend = rng.normal(size=33); bend -= bend @ axis * axis; bend /= np.linalg.norm(bend)
+
+    def rows(n, jitter):
+        t = rng.random(n)
+        x = np.outer(t, axis) + np.outer(0.05 * np.sin(6 * t), bend) + rng.normal(0, jitter, (n, 33))
+        return x
+
+    off = rng.random(33) * 40.0
+    ft = ((rows(nt, 1e-5) + off) * scale).astype(np.float32)
+    fs = ((rows(ns, 1e-5) + off) * scale).astype(np.float32)
+    fs[:300] = ((rows(300, 0.3) + off) * scale).astype(np.float32)        # outliers: far from every target
+    ft[2000:2100] = ft[100:200]; fs[300:400] = ft[2000:2100]              # ties: the lower index wins
+    got = ctx.feature_match(fs, ft)
+    ref = orc.feature_match(fs, ft)
+    assert np.array_equal(got, ref), int((got != ref).sum())

@@ -48,3 +48,39 @@ print("nearest distance:        mean %.4f median %.4f p90 %.4f p99 %.4f max %.4f
 heavy = need > np.percentile(need, 95)
 print("share of all leaf openings caused by the heaviest 5 %% of the queries: %.1f %%" % (100 * need[heavy].sum() / need.sum()))
 np.save("/tmp/need_%s.npy" % tag, np.stack([sel, need]))
+
+# ---- would a second box per leaf, aligned with the principal directions, cut the openings? (lower bound = max of the two)
+for m in (3, 6, 10):
+    Q = V[:, :m]
+    Pp = ((Tp.astype(np.float64) - mu) @ Q).reshape(nbox, 64, m)
+    pmin = Pp.min(1); pmax = Pp.max(1)
+    need2 = []
+    for i0 in range(0, len(sel), 250):
+        q = fs[sel[i0:i0 + 250]].astype(np.float64)
+        d2 = np.maximum((q * q).sum(1)[:, None] + tn[None] - 2 * q @ Td.T, 0)
+        best = d2.min(1)
+        gap = np.maximum(np.maximum(bmin[None] - q[:, None, :], q[:, None, :] - bmax[None]), 0)
+        lb = (gap ** 2).sum(-1)
+        pq = (q - mu) @ Q
+        pg = np.maximum(np.maximum(pmin[None] - pq[:, None, :], pq[:, None, :] - pmax[None]) - 4e-5, 0)
+        lb2 = (pg ** 2).sum(-1) * (1 - 1e-5)
+        need2.append((np.maximum(lb, lb2) <= best[:, None] * (1 + 1e-6) + 1e-12).sum(1))
+    need2 = np.concatenate(need2)
+    print("with a PCA-%d box as well: mean %.1f  median %d  p90 %d  p99 %d  max %d" % (m, need2.mean(), np.median(need2), *np.percentile(need2, [90, 99]).astype(int), need2.max()))
+
+# ---- and the principal-direction box ALONE (no 33-D box at all)?
+for m in (3, 4, 6):
+    Q = V[:, :m]
+    Pp = ((Tp.astype(np.float64) - mu) @ Q).reshape(nbox, 64, m)
+    pmin = Pp.min(1); pmax = Pp.max(1)
+    need3 = []
+    for i0 in range(0, len(sel), 250):
+        q = fs[sel[i0:i0 + 250]].astype(np.float64)
+        d2 = np.maximum((q * q).sum(1)[:, None] + tn[None] - 2 * q @ Td.T, 0)
+        best = d2.min(1)
+        pq = (q - mu) @ Q
+        pg = np.maximum(np.maximum(pmin[None] - pq[:, None, :], pq[:, None, :] - pmax[None]) - 4e-5, 0)
+        lb2 = (pg ** 2).sum(-1) * (1 - 1e-5)
+        need3.append((lb2 <= best[:, None] * (1 + 1e-6) + 1e-12).sum(1))
+    need3 = np.concatenate(need3)
+    print("PCA-%d box alone: mean %.1f  median %d  p90 %d  p99 %d  max %d" % (m, need3.mean(), np.median(need3), *np.percentile(need3, [90, 99]).astype(int), need3.max()))
