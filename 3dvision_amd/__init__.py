@@ -48,7 +48,7 @@ ABI_SYMBOLS = [
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
     "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii", "tdv_load_mask_png", "tdv_load_masks_from_dir",
-    "tdv_depth_to_cloud_batch_dev",
+    "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results",
 ]
 
 
@@ -420,7 +420,25 @@ def _depth_to_cloud_batch_dev(self, d_raw, d_masks, d_bgr, n_instances, w, h, sc
     return off
 
 
+def _broadcast_model(self, comm, root, d_xyz, d_normals, d_fpfh, capacity, n_model):
+    """tdv_broadcast_model: comm is an ncclComm_t (int / c_void_p); returns the model's point count on every rank."""
+    n = C.c_int(int(n_model))
+    _check(self._h, lib().tdv_broadcast_model(self._h, C.c_void_p(comm), int(root), _ptr(d_xyz), _ptr(d_normals), _ptr(d_fpfh), int(capacity), C.byref(n)),
+           "tdv_broadcast_model")
+    return n.value
+
+
+def _gather_results(self, comm, local, slots_per_rank, world_size):
+    """tdv_gather_results: local = list of InstanceResultC; returns world_size * slots_per_rank InstanceResultC (status -1 = unused slot)."""
+    loc = (InstanceResultC * max(len(local), 1))(*local)
+    out = (InstanceResultC * max(world_size * slots_per_rank, 1))()
+    _check(self._h, lib().tdv_gather_results(self._h, C.c_void_p(comm), loc, len(local), int(slots_per_rank), out), "tdv_gather_results")
+    return list(out)[:world_size * slots_per_rank]
+
+
 Context.depth_to_cloud_batch_dev = _depth_to_cloud_batch_dev
+Context.broadcast_model = _broadcast_model
+Context.gather_results = _gather_results
 Context.register_batch_dev = _register_batch_dev
 Context.prepare_model_dev = _prepare_model_dev
 

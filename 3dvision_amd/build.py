@@ -63,7 +63,7 @@ def build(verbose=False, jobs=6):
         if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
             os.remove(os.path.join(OBJ, f))
     if _stale(LIB, objs):
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz"], capture_output=True, text=True)
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-ldl"], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
     return LIB

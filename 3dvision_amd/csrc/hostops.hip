@@ -61,6 +61,17 @@ int tdv_load_ply_ascii(const char* path, float* out_xyz, float* out_rgb, int cap
     if (has_color_out) *has_color_out = has_color ? 1 : 0;
     int n = 0;
     for (int i = 0; i < vertex_count; ++i) {
+        if (!file) {
+            // Once a read has failed every later `file >> x` is a no-op: the reference keeps pushing vertex_count points
+            // whose values are whatever its uninitialised locals hold.  Here they are zeros, written without looping over a
+            // (possibly hostile, up to 2^31) header count.
+            for (long long j = n; j < (long long)std::min(vertex_count, capacity); ++j) {
+                if (out_xyz) { out_xyz[3 * j] = 0.f; out_xyz[3 * j + 1] = 0.f; out_xyz[3 * j + 2] = 0.f; }
+                if (out_rgb && has_color) { out_rgb[3 * j] = 0.f; out_rgb[3 * j + 1] = 0.f; out_rgb[3 * j + 2] = 0.f; }
+            }
+            n = vertex_count;
+            break;
+        }
         float x = 0.f, y = 0.f, z = 0.f;  // the reference leaves y, z uninitialised when the read fails
         file >> x >> y >> z;
         float r = 0.f, g = 0.f, b = 0.f;

@@ -1,9 +1,8 @@
 // Link-time substitute for the reference's src/registration.cpp: defines the Registration:: statics
 // declared in include/registration.hpp:32-60 on top of the HIP backend, so that the unchanged
 // src/pipeline.cpp (which calls them directly, :92-102, :291-294) runs the non-ICP stages on the GPU too.
-// Link EITHER src/registration.cpp OR this file.  Registration::loadReferenceModel stays with the
-// reference (it is file I/O): keep it by compiling the reference TU's loader
-// separately or use ../ply_loader once provided.
+// Link EITHER src/registration.cpp OR this file: every static of the class is defined here, including
+// Registration::loadReferenceModel (registration.hpp:59, called at src/pipeline.cpp:284) on tdv_load_ply_ascii.
 // NOT COMPILED IN THIS REPOSITORY'S CI (no Eigen in the image); mirrors ../tdv_registration.cpp.
 #include "registration.hpp"
 #include "tdv_hip.h"
@@ -97,6 +96,21 @@ RegistrationResult Registration::icpRefine(const PointCloud& source, const Point
     out.fitness = r.fitness; out.rmse = r.rmse;
     std::cout << "ICP result: fitness=" << out.fitness << ", RMSE=" << out.rmse << "\n";
     return out;
+}
+
+PointCloud Registration::loadReferenceModel(const std::string& path) {   // src/registration.cpp:416-461
+    PointCloud cloud;
+    int n = 0, has_color = 0;
+    if (tdv_load_ply_ascii(path.c_str(), nullptr, nullptr, 0, &n, &has_color) != TDV_OK) {   // count query; fails only if the file cannot be opened
+        std::cerr << "Cannot open reference model: " << path << "\n";
+        return cloud;
+    }
+    cloud.points.resize(n > 0 ? n : 0);
+    if (has_color) cloud.colors.resize(n > 0 ? n : 0);
+    if (n > 0 && tdv_load_ply_ascii(path.c_str(), fp(cloud.points), has_color ? fp(cloud.colors) : nullptr, n, &n, &has_color) != TDV_OK)
+        throw std::runtime_error("Registration::loadReferenceModel: " + path + " changed while it was read");
+    std::cout << "Loaded reference model: " << cloud.size() << " points from " << path << "\n";
+    return cloud;
 }
 
 }  // namespace industry_picking

@@ -149,6 +149,21 @@ RegistrationResult Registration::icpRefine(const PointCloud& source, const Point
     return out;
 }
 
+PointCloud Registration::loadReferenceModel(const std::string& path) {   // src/registration.cpp:416-461
+    PointCloud cloud;
+    int n = 0, has_color = 0;
+    if (tdv_load_ply_ascii(path.c_str(), nullptr, nullptr, 0, &n, &has_color) != TDV_OK) {   // count query; fails only if the file cannot be opened
+        std::cerr << "Cannot open reference model: " << path << "\n";                       // :420-423
+        return cloud;
+    }
+    cloud.points.resize(std::max(n, 0));
+    if (has_color) cloud.colors.resize(std::max(n, 0));
+    if (n > 0 && tdv_load_ply_ascii(path.c_str(), fp(cloud.points), has_color ? fp(cloud.colors) : nullptr, n, &n, &has_color) != TDV_OK)
+        throw std::runtime_error("Registration::loadReferenceModel: " + path + " changed while it was read");
+    std::cout << "Loaded reference model: " << cloud.size() << " points from " << path << "\n";   // :459
+    return cloud;
+}
+
 std::vector<Image> Segmentation::loadMasksFromDir(const std::string& masks_dir) {  // src/segmentation.cpp:12-42
     namespace fs = std::filesystem;
     std::vector<Image> masks;

@@ -81,6 +81,8 @@ public:
                                                  float voxel_size, int max_iterations = 100000, float confidence = 0.999f);
     static RegistrationResult icpRefine(const PointCloud& source, const PointCloud& target, const Mat4f& initial_transform,
                                         float distance_threshold, int max_iterations = 200, bool point_to_plane = true);
+    // registration.hpp:59 / src/registration.cpp:416-461 (ASCII PLY, incl. the skipped first vertex); caller: src/pipeline.cpp:284
+    static PointCloud loadReferenceModel(const std::string& path);
 };
 
 class GPURegistration {  // gpu_registration.hpp:8-19

@@ -289,6 +289,23 @@ int tdv_register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw_depth, const uint
 int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_size, int voxel_order, int normals_k,
                           float fpfh_radius_factor, float* d_out_xyz, float* d_out_normals, float* d_out_fpfh, int* n_out /* host */);
 
+/* ---- multi-GPU: instances shard across one process per GPU; the reference's only parallel axis is the
+ * same one, over host threads (src/pipeline.cpp:321-327).  rccl_comm is the caller's ncclComm_t (RCCL; one rank per
+ * process, created by the host with ncclCommInitRank) — this library does not link RCCL, it resolves ncclBroadcast /
+ * ncclAllGather among the process's loaded symbols, else from librccl.so.1, at the first call.  Both calls enqueue on the
+ * ctx's stream and return after it has been synchronized; every rank must make the same calls in the same order.
+ *
+ * tdv_broadcast_model: the prepared model (what tdv_prepare_model_dev / Pipeline::run :291-294 produce) from rank `root`
+ * to every rank, in place: on root *n_model is the input count, elsewhere it receives it; buffers hold `capacity` points
+ * on every rank (TDV_ERR_BAD_ARG if the model does not fit).  d_normals may be NULL on ALL ranks (no normals: ICP falls
+ * back to point-to-point, registration.cpp:343).
+ * tdv_gather_results: every rank contributes n_local results in slots_per_rank slots (the same number on every rank,
+ * >= n_local; unused slots come back with status -1) and receives all ranks' slots, rank-major, in `all`
+ * (world_size * slots_per_rank entries).  Both are host arrays. */
+int tdv_broadcast_model(tdv_ctx* ctx, void* rccl_comm, int root, float* d_xyz, float* d_normals, float* d_fpfh, int capacity, int* n_model);
+int tdv_gather_results(tdv_ctx* ctx, void* rccl_comm, const tdv_instance_result* local, int n_local, int slots_per_rank,
+                       tdv_instance_result* all);
+
 /* ---- host-side helpers that are part of the path's semantics -------------------------------- */
 /* The RANSAC index stream: count triples from mt19937(seed) + Lemire uniform over [0, n-1]
  * (src/registration.cpp:235-239 on libstdc++ 11).  Own implementation, no <random>. */
