@@ -61,6 +61,9 @@ static hipEvent_t get_event(tdv_ctx* ctx) {
     return e;
 }
 
+hipEvent_t event_acquire(tdv_ctx* ctx) { return get_event(ctx); }
+void event_release(tdv_ctx* ctx, hipEvent_t e) { if (e) ctx->event_pool.push_back(e); }
+
 ScopedTimer::ScopedTimer(tdv_ctx* c, int s) : ctx(c), slot(s) {
     if (!ctx->timing) return;
     a = get_event(ctx); b = get_event(ctx);

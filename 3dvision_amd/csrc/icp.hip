@@ -414,7 +414,8 @@ NnPlan make_plan(int ns, int nt) {
     p.chunks_per_split = (p.n_chunks + p.nsplit - 1) / p.nsplit;
     p.nsplit = (p.n_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
     static const int ppt_env = getenv("TDV_ICP_PPT") ? atoi(getenv("TDV_ICP_PPT")) : 0;
-    p.acc_ppt = ppt_env ? ppt_env : 4;   // make_plan's default; the brute-force path (split partials, index recovery) uses 1
+    // only 1, 2, 4 and 8 points per thread are instantiated (TDV_ACC below); anything else would size the grid for a kernel that is never launched
+    p.acc_ppt = (ppt_env == 1 || ppt_env == 2 || ppt_env == 4 || ppt_env == 8) ? ppt_env : 4;   // 4: make_plan's default; the brute-force path uses 1
     p.acc_blocks = (ns + 256 * p.acc_ppt - 1) / (256 * p.acc_ppt);
     return p;
 }

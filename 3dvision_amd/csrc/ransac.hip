@@ -31,13 +31,16 @@ namespace tdv {
 // ------------------------------------------------------------------ hypotheses
 // pq layout: 8 floats per point: px py pz qx qy qz 0 0  (q = tgt[corr[i]]); padding points have
 // p = 0 and q = +inf so that d2 = +inf and they are never inliers.
+// A correspondence outside [0, nt) (caller-supplied lists are not trusted) raises *bad and reads target 0 instead of
+// faulting; the host turns the flag into TDV_ERR_BAD_ARG at its first synchronisation.
 __global__ void k_gather_pq(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
-                            int ns, int ns_pad, float* __restrict__ pq) {
+                            int ns, int ns_pad, int nt, float* __restrict__ pq, int* __restrict__ bad) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns_pad) return;
     float4 a, b;
     if (i < ns) {
         int c = corr[i];
+        if ((unsigned)c >= (unsigned)nt) { *bad = 1; c = 0; }
         a = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], tgt[3 * c]);
         b = make_float4(tgt[3 * c + 1], tgt[3 * c + 2], 0.f, 0.f);
     } else {
@@ -219,7 +222,10 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     const int ns_pad = (int)align_up((size_t)ns, (size_t)RS_PCH * 64);
     float* pq = nullptr;
     TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 8, &pq));
-    k_gather_pq<<<(ns_pad + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, ns, ns_pad, pq);
+    int* d_bad = nullptr;
+    TDV_TRY(ws_alloc(ctx, 1, &d_bad));
+    TDV_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, s));
+    k_gather_pq<<<(ns_pad + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, ns, ns_pad, nt, pq, d_bad);
     float* pq2 = nullptr;
     TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 6, &pq2));
     k_pack_pq2<<<(ns_pad / 2 + 255) / 256, 256, 0, s>>>(pq, ns_pad, pq2);
@@ -250,14 +256,17 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     TDV_TRY(ws_alloc(ctx, 12, &d_best12));
     // pinned: 2 x triples (int4 * batch) | 2 x counts (int * batch) | best12 (12 floats) | out2 (2 doubles)
     const size_t sz_tri = align_up((size_t)batch * 16, 64), sz_cnt = align_up((size_t)batch * 4, 64);
-    const size_t pin_b12 = 2 * sz_tri + 2 * sz_cnt, pin_o2 = pin_b12 + 64, pin_total = pin_o2 + 64;
+    const size_t pin_b12 = 2 * sz_tri + 2 * sz_cnt, pin_o2 = pin_b12 + 64, pin_bad = pin_o2 + 64, pin_total = pin_bad + 64;
     TDV_TRY(pin_reserve(ctx, pin_total));
+    int* h_bad = reinterpret_cast<int*>(ctx->pin + pin_bad);
+    *h_bad = 0;
+    TDV_HIP(ctx, hipMemcpyAsync(h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));   // lands before the first batch's counts
     int4* h_tri[2] = {reinterpret_cast<int4*>(ctx->pin), reinterpret_cast<int4*>(ctx->pin + sz_tri)};
     int* h_cnt[2] = {reinterpret_cast<int*>(ctx->pin + 2 * sz_tri), reinterpret_cast<int*>(ctx->pin + 2 * sz_tri + sz_cnt)};
     float* h_b12 = reinterpret_cast<float*>(ctx->pin + pin_b12);
     double* h_o2 = reinterpret_cast<double*>(ctx->pin + pin_o2);
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    for (int q = 0; q < 2; ++q) TDV_HIP(ctx, hipEventCreateWithFlags(&ev[q], hipEventDisableTiming));
+    hipEvent_t ev[2] = {event_acquire(ctx), event_acquire(ctx)};   // from the ctx's pool: no create/destroy per call
+    if (!ev[0] || !ev[1]) { event_release(ctx, ev[0]); event_release(ctx, ev[1]); return TDV_ERR_OOM; }
 
     TripleStream stream_idx(seed, (uint64_t)ns);   // sequential over the whole run (registration.cpp:235-239)
     auto prepare = [&](int q, int it0) -> int {    // host: draw + pack the triples of one batch
@@ -301,6 +310,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
             if (status != TDV_OK) break;
         }
         if (hipEventSynchronize(ev[cur]) != hipSuccess) { status = TDV_ERR_LAUNCH; break; }
+        if (*h_bad) { std::snprintf(ctx->err, sizeof(ctx->err), "ransac: a correspondence index lies outside [0, %d)", nt); status = TDV_ERR_BAD_ARG; break; }
         int batch_best = -1;
         for (int k = 0; k < cnt_cur; ++k) {
             done_iters = it0 + k + 1;
@@ -318,7 +328,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         cur = nxt; it0 = it_next; cnt_cur = cnt_next;
     }
     (void)hipStreamSynchronize(s);   // a speculative batch may still be in flight after an early exit
-    for (int q = 0; q < 2; ++q) (void)hipEventDestroy(ev[q]);
+    for (int q = 0; q < 2; ++q) event_release(ctx, ev[q]);
     if (status != TDV_OK) return status;
     out->iterations_run = done_iters;
     if (best_iter >= 0) {

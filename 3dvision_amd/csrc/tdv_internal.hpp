@@ -79,6 +79,10 @@ struct WsMark { size_t block, off, used; };
 inline WsMark ws_mark(tdv_ctx* ctx) { return WsMark{ctx->cur_block, ctx->cur_off, ctx->used_total}; }
 inline void ws_rewind(tdv_ctx* ctx, const WsMark& m) { ctx->cur_block = m.block; ctx->cur_off = m.off; ctx->used_total = m.used; }
 
+// Events for stream synchronisation points come from (and go back to) the ctx's pool: no hipEventCreate in steady state.
+hipEvent_t event_acquire(tdv_ctx* ctx);
+void event_release(tdv_ctx* ctx, hipEvent_t e);
+
 // Timing helpers: bracket a launch with events when ctx->timing is on.
 struct ScopedTimer {
     tdv_ctx* ctx; int slot; hipEvent_t a = nullptr, b = nullptr;

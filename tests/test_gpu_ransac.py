@@ -199,3 +199,13 @@ def test_feature_match_three_paths_on_relief_descriptors(ctx, tdv, orc, synth):
     assert ref[100] == 0 and ref[101] == 0 and (ref[:40] < 5000).all()
     one = np.repeat(ft[:1], 3000, 0)
     assert (ctx.feature_match(fs[:5000], one)[:99] == 0).all()
+
+
+def test_ransac_rejects_correspondences_outside_the_target(ctx, tdv, synth):
+    """Caller-supplied correspondence lists are validated on the device (a flag, no fault): TDV_ERR_BAD_ARG."""
+    src, tgt, corr, _ = _case(synth, 3000, 2000)
+    for bad in (2000, -1, 1 << 30):
+        c = corr.copy(); c[1234] = bad
+        with pytest.raises(tdv.TdvError):
+            ctx.ransac(src, tgt, corr=c, voxel=0.004, max_iterations=300)
+    assert ctx.ransac(src, tgt, corr=corr, voxel=0.004, max_iterations=300).iterations_run == 300   # the ctx is still usable

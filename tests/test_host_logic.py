@@ -109,6 +109,25 @@ def test_ply_loader_keeps_the_reference_quirk(tdv, orc, tmp_path):
     assert tdv.load_reference_model(str(tmp_path / "missing.ply")).empty()
 
 
+def test_ply_loader_hostile_vertex_count_returns_at_once(tdv, tmp_path):
+    """A header that promises 2^30 vertices over a 3-line body: the reference would push 2^30 garbage points; the loader
+    reports that count without looping over it and fills what fits with zeros after the last real vertex."""
+    import ctypes as C
+    import time
+    p = tmp_path / "liar.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 1073741824\nproperty float x\nproperty float y\nproperty float z\nend_header\n"
+                 "1 2 3\n4 5 6\n7 8 9\n")
+    n = C.c_int(); hc = C.c_int()
+    t0 = time.time()
+    assert tdv.lib().tdv_load_ply_ascii(str(p).encode(), None, None, 0, C.byref(n), C.byref(hc)) == 0
+    assert n.value == 1 << 30 and hc.value == 0
+    xyz = np.full((8, 3), -1, np.float32)
+    st = tdv.lib().tdv_load_ply_ascii(str(p).encode(), xyz.ctypes.data_as(C.c_void_p), None, 8, C.byref(n), C.byref(hc))
+    assert st != 0 and n.value == 1 << 30                      # does not fit: TDV_ERR_BAD_ARG, needed count reported
+    assert np.array_equal(xyz[:2], [[4, 5, 6], [7, 8, 9]]) and np.array_equal(xyz[2:], np.zeros((6, 3)))
+    assert time.time() - t0 < 2.0
+
+
 # ---- mask-directory loader (Segmentation::loadMasksFromDir, src/segmentation.cpp:12-42) -----------------------------
 
 def _png_bytes(pix, depth=8, alpha=False, filters=None):
