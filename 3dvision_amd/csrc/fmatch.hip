@@ -35,30 +35,37 @@ constexpr int FM_SEED = 256;   // targets of the seeding launch
 // so once the partial sum is >= the lane's best the final distance cannot pass the strict "<": a target is dropped
 // as soon as that holds for every lane of the wave (checked after 11 and 22 of the 33 dimensions).  `seed` (the exact
 // best over the first targets, computed by a first launch) lets every split start with a tight bound.
-template <bool EARLY>
+// `list` / `n_list`: scan only these sources (the sources the packed-index search gave up on), results at the source's own
+// row.  `seed`: a per-source starting bound.  SEED_FROM_LOWER: the seed is the exact best over LOWER target indices
+// (part 0 seeding the later splits), so strict < keeps the lowest-index rule.  Otherwise the seed is a distance found
+// somewhere in the table: the scan starts one ulp above it and walks every target in ascending order with strict <, so
+// it finds that distance again and keeps the lowest index that reaches the minimum.
+template <bool EARLY, bool SEED_FROM_LOWER>
 __global__ __launch_bounds__(FM_BLOCK)
 void k_feature_match_scan(const float* __restrict__ fs, int ns, int ns_pad,
                           const float* __restrict__ ft, int j_begin, int j_end, int per_split,
-                          const float* __restrict__ seed, const uint4* __restrict__ order,
+                          const float* __restrict__ seed, const int* __restrict__ list, int n_list,
                           float* __restrict__ pd, int* __restrict__ pj) {
     const int split = blockIdx.y;
     const int j0 = j_begin + split * per_split;
     const int j1 = min(j_end, j0 + per_split);
     const int base = blockIdx.x * FM_SRC_PER_BLOCK + threadIdx.x;
+    const int n_here = list ? n_list : ns;
     float f[FM_SPL][FD];
     float best[FM_SPL]; int bj[FM_SPL]; int src[FM_SPL];
 #pragma unroll
     for (int s = 0; s < FM_SPL; ++s) {
-        // with `order` (records sorted by seed distance, .w = source index) a wave holds sources whose bounds are
-        // alike, so it leaves a target as early as its typical lane does; results go back to the source's own row
         const int t = base + s * FM_BLOCK;
-        src[s] = order ? (int)order[min(t, ns - 1)].w : t;
-        const int i = min(src[s], ns - 1);
+        src[s] = list ? list[min(t, n_here - 1)] : t;
+        const int i = min(max(src[s], 0), ns - 1);
 #pragma unroll
         for (int d = 0; d < FD; ++d) f[s][d] = fs[(size_t)i * FD + d];
-        best[s] = seed ? seed[i] : FLT_MAX;   // a seed comes from lower target indices: strict < keeps the tie rule
-        bj[s] = seed ? -1 : 0;
-        if (order && t >= ns) src[s] = -1;    // padding lane: duplicate work, no output
+        if (seed) {
+            const float sd = seed[i];
+            best[s] = SEED_FROM_LOWER ? sd : ((sd < FLT_MAX && sd >= 0.f) ? __int_as_float(__float_as_int(sd) + 1) : FLT_MAX);
+            bj[s] = -1;
+        } else { best[s] = FLT_MAX; bj[s] = 0; }
+        if (t >= n_here || src[s] < 0) src[s] = -1;    // padding lane: duplicate work, no output
     }
     for (int j = j0; j < j1; ++j) {
         const float* __restrict__ g = ft + (size_t)j * FD;  // wave-uniform -> scalar loads
@@ -91,10 +98,30 @@ void k_feature_match_scan(const float* __restrict__ fs, int ns, int ns_pad,
     }
 #pragma unroll
     for (int s = 0; s < FM_SPL; ++s) {
-        if (src[s] < 0) continue;
+        if (src[s] < 0 || src[s] >= ns) continue;
         size_t o = (size_t)split * ns_pad + src[s];
         pd[o] = best[s]; pj[o] = bj[s];
     }
+}
+// the listed sources' partial results, combined in split order with strict < (lowest target index wins ties)
+__global__ void k_feature_match_combine_list(const int* __restrict__ list, int n_list, int ns, int ns_pad, int nparts, const float* __restrict__ pd,
+                                             const int* __restrict__ pj, int* __restrict__ corr) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_list) return;
+    const int i = list[t];
+    if (i < 0 || i >= ns) return;
+    float best = FLT_MAX; int bj = 0;
+    for (int p0 = 0; p0 < nparts; p0 += 8) {   // 16 loads in flight
+        float d[8]; int j[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = min(p0 + u, nparts - 1);
+            d[u] = pd[(size_t)p * ns_pad + i]; j[u] = pj[(size_t)p * ns_pad + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (p0 + u < nparts && j[u] >= 0 && d[u] < best) { best = d[u]; bj = j[u]; }
+    }
+    corr[i] = bj;
 }
 
 // partial results are combined in launch/split order with strict <: the lowest target index wins ties
@@ -724,7 +751,8 @@ struct FmWave {
     // The leaves of group g whose boxes pass, inside-out from the home side.  The mask is known before the first leaf is
     // opened, so the next leaf's 34 loads are issued before the current leaf is evaluated (two register buffers): a wave
     // that opens many leaves no longer pays a full memory round trip for each.
-    __device__ __forceinline__ void visit_group(int g) {
+    // Returns false when the leaf budget ran out before the group was finished (pass A: the caller gives the sources up).
+    __device__ __forceinline__ bool visit_group(int g, unsigned budget = 0xffffffffu) {
         const int l0 = g * FX_GROUP, cnt = min(FX_GROUP, t.nleaf - l0);
         unsigned long long m = leaf_mask(g);
         const int centre = (g == hg) ? home - l0 : (g < hg ? cnt - 1 : 0);   // enter a neighbouring group from the home side
@@ -737,19 +765,22 @@ struct FmWave {
             return -1;
         };
         int cur = next();
-        if (cur < 0) return;
+        if (cur < 0) return true;
         float a[FD], b[FD]; int roa, rob = 0;
         load_leaf(cur, a, roa);
         for (;;) {
+            if (n_open >= budget) return false;
             const int n1 = next();
             if (n1 >= 0) load_leaf(n1, b, rob);
             eval_leaf(a, roa);
             if (n1 < 0) break;
+            if (n_open >= budget) return false;
             const int n2 = next();
             if (n2 >= 0) load_leaf(n2, a, roa);
             eval_leaf(b, rob);
             if (n2 < 0) break;
         }
+        return true;
     }
     // lowest (distance, original index) of source k over the lanes
     __device__ __forceinline__ void result(int k, float& bd, int& bo) const {
@@ -770,8 +801,8 @@ struct FmWave {
 // call waits for a few waves that open hundreds of leaves one after the other (measured: 580 leaves, 1.3 of 1.5 ms).
 template <int K, bool STATS>
 __global__ __launch_bounds__(FM_BLOCK, FMQ_WAVES_PER_SIMD)
-void k_fm_query(FmTables t, int blocks_per_xcd, int leaf_limit, int* __restrict__ overflow_count, int* __restrict__ overflow_list,
-                float* __restrict__ part_d, int* __restrict__ part_j, int* __restrict__ corr, unsigned long long* __restrict__ stats) {
+void k_fm_query(FmTables t, int blocks_per_xcd, int leaf_limit, int heavy_groups, int* __restrict__ overflow_count /* [2]: pass B, scan */, int* __restrict__ overflow_list,
+                int* __restrict__ overflow_src, float* __restrict__ part_d, int* __restrict__ part_j, int* __restrict__ corr, unsigned long long* __restrict__ stats) {
     // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one).  Give every XCD a CONTIGUOUS stretch of
     // the home-ordered sources: neighbouring waves open the same leaves, so the stretch's leaves (1/8 of the table) stay
     // in that XCD's 4 MB L2 instead of every L2 seeing the whole table.
@@ -783,9 +814,9 @@ void k_fm_query(FmTables t, int blocks_per_xcd, int leaf_limit, int* __restrict_
     if (STATS) t_start = wall_clock64();
     FmWave<K, false> w(t, s0, nullptr);
     w.open_leaf(w.home);
-    w.visit_group(w.hg);
-    bool overflow = false;
+    bool overflow = !w.visit_group(w.hg, (unsigned)leaf_limit);
     const int nchunk = (t.ngroup + 63) / 64;
+    int groups_left = overflow ? t.ngroup : 0;       // estimate of what is left when the wave gives up
     for (int c = 0; c < nchunk && !overflow; ++c) {     // (chunks in index order; within a chunk inside-out from the home group's side)
         unsigned long long m = w.group_mask(c);
         const int g0 = c * 64, cnt = min(64, t.ngroup - g0);
@@ -793,13 +824,19 @@ void k_fm_query(FmTables t, int blocks_per_xcd, int leaf_limit, int* __restrict_
         for (int u = 0; u < cnt && m; ++u) {
             const int g = visit_inside_out(u, centre, cnt);
             if (!((m >> g) & 1ull)) continue;
+            if ((int)w.n_open >= leaf_limit || !w.visit_group(g0 + g, (unsigned)leaf_limit)) {
+                overflow = true;
+                groups_left = __popcll(m) + 64 * (nchunk - 1 - c);
+                break;
+            }
             m &= ~(1ull << g);
-            if ((int)w.n_open >= leaf_limit) { overflow = true; break; }
-            w.visit_group(g0 + g);
         }
     }
+    // Sources given up with few groups left go to pass B (8 waves each on the index); with many groups left nearly every
+    // box passes (an outlier, or a plateau of near-identical rows) and the plain scan is the efficient way to finish them.
+    const bool to_scan = overflow && groups_left >= heavy_groups;
     int slot = 0;
-    if (overflow && w.lane == 0) slot = atomicAdd(overflow_count, 1);
+    if (overflow && w.lane == 0) slot = atomicAdd(overflow_count + (to_scan ? 1 : 0), 1);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float bd; int bo;
@@ -809,7 +846,14 @@ void k_fm_query(FmTables t, int blocks_per_xcd, int leaf_limit, int* __restrict_
             else corr[w.src[k]] = bo == INT_MAX ? 0 : bo;   // nothing finite -> the reference keeps index 0
         }
     }
-    if (overflow && w.lane == 0) overflow_list[slot] = s0;
+    if (overflow && w.lane == 0) {
+        if (!to_scan) overflow_list[slot] = s0;
+        else {
+            overflow_list[t.ns + 1 + slot] = s0;     // second half of the list: the scan class, as wave starts ...
+#pragma unroll
+            for (int k = 0; k < K; ++k) overflow_src[slot * K + k] = s0 + k < t.ns ? w.src[k] : -1;   // ... and as sources
+        }
+    }
     if (STATS && w.lane == 0) {   // [0] waves, [1] group-chunk tests, [2] groups visited, [3] leaves opened, [4] most leaves opened by one wave
         const unsigned long long dt = wall_clock64() - t_start;   // 100 MHz ticks
         atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], (unsigned long long)w.n_group_tests); atomicAdd(&stats[2], (unsigned long long)w.n_leaf_tests);
@@ -1033,7 +1077,7 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     TDV_HIP(ctx, hipMemcpyAsync(d_int, stage + sizeof(h_basis), h_int.size() * 4, hipMemcpyHostToDevice, s));
     const int* d_slab_start = d_int; const int* d_col_start = d_int + S0 + 1; const int* d_col_row0 = d_col_start + ncol + 1;
     ix->col_leaf0 = d_col_row0 + ncol + 1;
-    ix->basis = basis; ix->nt = nt; ix->rows = (int)rows; ix->nleaf = nleaf; ix->ngroup = ngroup; ix->S0 = S0; ix->S1 = S1;
+    ix->ft = d_ft; ix->basis = basis; ix->nt = nt; ix->rows = (int)rows; ix->nleaf = nleaf; ix->ngroup = ngroup; ix->S0 = S0; ix->S1 = S1;
     TDV_HIP(ctx, hipMemsetAsync(ix->leaf_p2, 0, (size_t)nleaf * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(ix->b0, 0, ((size_t)S0 + 1) * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(ix->b1, 0, ((size_t)ncol + 1) * 4, s));
@@ -1056,32 +1100,67 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     return TDV_OK;
 }
 
+// Pass A over every source, then the sources it gave up on: few of them -> pass B (8 waves each on the packed index);
+// many of them (descriptors without structure, or a plateau of near-identical rows: no box can exclude anything) -> the
+// plain scan over just those sources, seeded with pass A's distances, which is the efficient way to do brute force.
 template <int K>
-static int launch_fm_query(tdv_ctx* ctx, const FmTables& t, int* overflow_count, int* overflow_list, float* part_d, int* part_j, int* d_corr) {
+static int launch_fm_query(tdv_ctx* ctx, const FmTables& t, const FmIndex& ix, int* overflow_count, int* overflow_list, int* overflow_src,
+                           float* part_d, int* part_j, int* d_corr) {
     hipStream_t s = ctx->stream;
     const int waves = (t.ns + K - 1) / K;
     const int blocks_per_xcd = ((waves + FM_BLOCK / 64 - 1) / (FM_BLOCK / 64) + 7) / 8, blocks = blocks_per_xcd * 8;
-    static const int leaf_limit = getenv("TDV_FM_LIMIT") ? atoi(getenv("TDV_FM_LIMIT")) : 48;   // tuning knob
-    const int bblocks = 1024;
-    if (getenv("TDV_FM_STATS")) {   // study knob: counts of box tests and leaf openings, printed to stderr
-        unsigned long long* d_stats; unsigned long long h[12]; int h_over = 0;
+    static const int leaf_limit = getenv("TDV_FM_LIMIT") ? atoi(getenv("TDV_FM_LIMIT")) : 32;     // tuning knobs
+    static const int heavy_groups = getenv("TDV_FM_HEAVY") ? atoi(getenv("TDV_FM_HEAVY")) : 12;
+    const bool stats = getenv("TDV_FM_STATS") != nullptr;   // study knob: counts of box tests and leaf openings, printed to stderr
+    unsigned long long* d_stats = nullptr;
+    if (stats) {
         TDV_TRY(ws_alloc(ctx, 12, &d_stats));
         TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 96, s));
-        k_fm_query<K, true><<<blocks, FM_BLOCK, 0, s>>>(t, blocks_per_xcd, leaf_limit, overflow_count, overflow_list, part_d, part_j, d_corr, d_stats);
-        k_fm_query_overflow<K, true><<<bblocks, FMB_WAVES * 64, 0, s>>>(t, overflow_count, overflow_list, part_d, part_j, d_corr, d_stats);
-        TDV_HIP(ctx, hipMemcpyAsync(h, d_stats, 96, hipMemcpyDeviceToHost, s));
-        TDV_HIP(ctx, hipMemcpyAsync(&h_over, overflow_count, 4, hipMemcpyDeviceToHost, s));
-        TDV_HIP(ctx, hipStreamSynchronize(s));
-        fprintf(stderr, "[tdv] fm query: %d sources x %d leaves, %d groups, %d sources per wave, %llu waves: per wave %.1f group-chunk tests, "
-                "%.1f groups visited, %.1f leaves opened (max %llu); wave time mean %.1f us max %.1f us; overflow: %d waves -> %llu helper waves, "
-                "%.1f leaves each (max %llu)\n",
-                t.ns, t.nleaf, t.ngroup, K, h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], h[4],
-                (double)h[5] / h[0] * 0.01, (double)h[6] * 0.01, h_over, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10]);
+        k_fm_query<K, true><<<blocks, FM_BLOCK, 0, s>>>(t, blocks_per_xcd, leaf_limit, heavy_groups, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr, d_stats);
     } else {
-        k_fm_query<K, false><<<blocks, FM_BLOCK, 0, s>>>(t, blocks_per_xcd, leaf_limit, overflow_count, overflow_list, part_d, part_j, d_corr, nullptr);
-        k_fm_query_overflow<K, false><<<bblocks, FMB_WAVES * 64, 0, s>>>(t, overflow_count, overflow_list, part_d, part_j, d_corr, nullptr);
+        k_fm_query<K, false><<<blocks, FM_BLOCK, 0, s>>>(t, blocks_per_xcd, leaf_limit, heavy_groups, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr, nullptr);
     }
     TDV_CHECK_LAUNCH(ctx);
+    TDV_TRY(pin_reserve(ctx, 256));
+    int* h_over = reinterpret_cast<int*>(ctx->pin);
+    TDV_HIP(ctx, hipMemcpyAsync(h_over, overflow_count, 8, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    const int n_b = h_over[0], n_scan = h_over[1];
+    // the scan only pays when it has enough sources to fill the chip; a handful of outliers is cheaper on pass B
+    const bool scan_them = (long long)n_scan * K >= 2048;
+    for (int cls = 0; cls < 2; ++cls) {
+        const int n = cls == 0 ? n_b : (scan_them ? 0 : n_scan);
+        if (n <= 0) continue;
+        const int* list = overflow_list + (cls ? t.ns + 1 : 0);
+        const int bblocks = std::min(n, 1024);
+        if (stats) k_fm_query_overflow<K, true><<<bblocks, FMB_WAVES * 64, 0, s>>>(t, overflow_count + cls, list, part_d, part_j, d_corr, d_stats);
+        else k_fm_query_overflow<K, false><<<bblocks, FMB_WAVES * 64, 0, s>>>(t, overflow_count + cls, list, part_d, part_j, d_corr, nullptr);
+    }
+    if (n_scan > 0 && scan_them) {
+        const int n_list = n_scan * K;
+        const int ns_pad = (int)align_up((size_t)t.ns, FM_SRC_PER_BLOCK);
+        const int blocks_x = (n_list + FM_SRC_PER_BLOCK - 1) / FM_SRC_PER_BLOCK;
+        const int want = (4096 + blocks_x - 1) / blocks_x;
+        int nsplit = std::max(1, std::min(std::min(want, std::max(1, ix.nt / 256)), 64));
+        const int per_split = (ix.nt + nsplit - 1) / nsplit;
+        nsplit = (ix.nt + per_split - 1) / per_split;
+        float* pd; int* pj;
+        TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pd));
+        TDV_TRY(ws_alloc(ctx, (size_t)nsplit * ns_pad, &pj));
+        k_feature_match_scan<true, false><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(t.fs, t.ns, ns_pad, ix.ft, 0, ix.nt, per_split, part_d, overflow_src, n_list, pd, pj);
+        k_feature_match_combine_list<<<(n_list + 255) / 256, 256, 0, s>>>(overflow_src, n_list, t.ns, ns_pad, nsplit, pd, pj, d_corr);
+    }
+    TDV_CHECK_LAUNCH(ctx);
+    if (stats) {
+        unsigned long long h[12];
+        TDV_HIP(ctx, hipMemcpyAsync(h, d_stats, 96, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        fprintf(stderr, "[tdv] fm query: %d sources x %d leaves, %d groups, %d sources per wave, %llu waves: per wave %.1f group-chunk tests, "
+                "%.1f groups visited, %.1f leaves opened (max %llu); wave time mean %.1f us max %.1f us; gave up: %d waves to pass B "
+                "(%llu helper waves, %.1f leaves each, max %llu), %d waves to the plain scan\n",
+                t.ns, t.nleaf, t.ngroup, K, h[0], (double)h[1] / h[0], (double)h[2] / h[0], (double)h[3] / h[0], h[4],
+                (double)h[5] / h[0] * 0.01, (double)h[6] * 0.01, n_b, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10], n_scan);
+    }
     return TDV_OK;
 }
 
@@ -1092,9 +1171,10 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     int bucket_shift = 0;
     while ((ix.nleaf >> bucket_shift) > FMP_BUCKETS) ++bucket_shift;
     int *home, *bucket_of, *sperm, *hist, *cursor, *start, *d_total; float* sp; unsigned* amax_s;
-    int *overflow_count, *overflow_list, *part_j; float* part_d;
-    TDV_TRY(ws_alloc(ctx, 1, &overflow_count));
-    TDV_TRY(ws_alloc(ctx, (size_t)ns, &overflow_list));
+    int *overflow_count, *overflow_list, *overflow_src, *part_j; float* part_d;
+    TDV_TRY(ws_alloc(ctx, 2, &overflow_count));
+    TDV_TRY(ws_alloc(ctx, (size_t)2 * ns + 8, &overflow_list));   // two halves: pass-B class, scan class
+    TDV_TRY(ws_alloc(ctx, (size_t)ns + 8, &overflow_src));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &part_d));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &part_j));
     TDV_TRY(ws_alloc(ctx, (size_t)ns * 4, &sp));
@@ -1110,7 +1190,7 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
     TDV_HIP(ctx, hipMemsetAsync(amax_s, 0, 4, s));
-    TDV_HIP(ctx, hipMemsetAsync(overflow_count, 0, 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(overflow_count, 0, 8, s));
     k_fm_locate<<<(ns + 255) / 256, 256, 0, s>>>(d_fs, ns, ix.basis, ix.S0, ix.S1, ix.b0, ix.b1, ix.col_leaf0, ix.leaf_p2, bucket_shift, home, bucket_of, sp, amax_s);
     const int sblocks = (ns + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
     k_fm_bucket_hist<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, hist);
@@ -1119,9 +1199,9 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     FmTables t{d_fs, sperm, home, ns, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, ix.pbox, ix.gpbox, sp, ix.amax, amax_s, ix.pscale};
     static const int force_k = getenv("TDV_FM_K") ? atoi(getenv("TDV_FM_K")) : 0;   // tuning knob (sources per wave)
     const int k = force_k ? force_k : 2;
-    if (k >= 4) return launch_fm_query<4>(ctx, t, overflow_count, overflow_list, part_d, part_j, d_corr);
-    if (k >= 2) return launch_fm_query<2>(ctx, t, overflow_count, overflow_list, part_d, part_j, d_corr);
-    return launch_fm_query<1>(ctx, t, overflow_count, overflow_list, part_d, part_j, d_corr);
+    if (k >= 4) return launch_fm_query<4>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
+    if (k >= 2) return launch_fm_query<2>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
+    return launch_fm_query<1>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
 }
 
 int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
@@ -1154,12 +1234,12 @@ int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft
     {
         ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
         if (early) {
-            k_feature_match_scan<true><<<dim3(blocks_x, 1), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, n_seed, n_seed, nullptr, nullptr, pd, pj);
+            k_feature_match_scan<true, true><<<dim3(blocks_x, 1), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, n_seed, n_seed, nullptr, nullptr, 0, pd, pj);
             if (nsplit)   // (ordering the sources by seed distance was measured: no gain on FPFH descriptors, so rows stay in place)
-                k_feature_match_scan<true><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, n_seed, nt, per_split, pd, nullptr,
+                k_feature_match_scan<true, true><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, n_seed, nt, per_split, pd, nullptr, 0,
                                                                                       pd + ns_pad, pj + ns_pad);
         } else {
-            k_feature_match_scan<false><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, nt, per_split, nullptr, nullptr, pd, pj);
+            k_feature_match_scan<false, true><<<dim3(blocks_x, nsplit), FM_BLOCK, 0, s>>>(d_fs, ns, ns_pad, d_ft, 0, nt, per_split, nullptr, nullptr, 0, pd, pj);
         }
     }
     k_feature_match_combine<<<(ns + 255) / 256, 256, 0, s>>>(ns, ns_pad, nparts, pd, pj, d_corr);

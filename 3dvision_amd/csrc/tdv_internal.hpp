@@ -109,6 +109,7 @@ int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft
 // of the ctx that built it (valid until that ctx's next ws_reset / rewind below the build); read-only afterwards, so a
 // batch builds it once for the model and every instance (on either lane) queries it.
 struct FmIndex {
+    const float* ft = nullptr;                                      // the caller's rows, [nt][33] (must outlive the index: the fallback scan reads them)
     float* T = nullptr; int* torig = nullptr;                       // [leaf][33][64] (row r = column r % 64 of leaf r / 64), [rows] (INT_MAX = padding)
     float* lbox = nullptr;                                          // leaf boxes [group][min | max][33][64 leaves]
     float* gbox = nullptr;                                          // group boxes [chunk of 64 groups][min | max][33][64 groups]

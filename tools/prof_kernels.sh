@@ -1,0 +1,13 @@
+#!/bin/bash
+# GPU box: rocprofv3 kernel trace of a python tool, top kernels printed.  usage: tools/prof_kernels.sh <tag> <script.py> [args...]
+tag=$1; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
+rm -rf $out
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/"$@" > $out.stdout 2> $out.stderr)
+f=$(find $out -name "*kernel_stats.csv" | head -1)
+python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:14]:
+    print("  %-58s calls %5s avg %10.3f us total %9.3f ms %6s%%" % (r["Name"].split("(")[0][-58:], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+PY
