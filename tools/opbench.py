@@ -1,0 +1,187 @@
+"""Per-operator measurements of the hot path on one MI355X, inputs resident in HBM (the *_dev ABI).  Shared by
+bench.py (the `operators` block after the timed region: driver-run numbers for every stage, not only the headline)
+and tools/bench_ops.py.  Every figure is the MEDIAN of >= 3 synchronized repetitions after a warm-up.
+
+Each entry: {"op", "workload", "ms", "bound", ...}.  HBM-bound scans carry algorithmic bytes and the
+fraction of the 8 TB/s roofline; the brute-force-shaped kernels carry f32 VALU lane-ops and the fraction of 78.6 Tops/s;
+the exact pruned searches carry their brute-force-equivalent rate (no roofline fraction: they skip most of the work)."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBPS = 8000.0
+VALU_PEAK_TOPS = 78.6
+
+
+def median_ms(fn, torch, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
+    return float(np.median(ts))
+
+
+def kernel_ms(ctx, slot, fn, torch, reps=3, warm=1):
+    """Median wall ms and mean HIP-event ms of the slot's kernels per call."""
+    for _ in range(warm):
+        fn()
+    ctx.timing_enable(True); ctx.timing_read(slot)
+    wall = median_ms(fn, torch, reps=reps, warm=0)
+    ms, launches = ctx.timing_read(slot)
+    ctx.timing_enable(False)
+    return wall, ms / reps, launches // max(reps, 1)
+
+
+def hbm(entry, nbytes, ms):
+    entry.update(bound="hbm", algorithmic_bytes=int(nbytes), achieved_GBps=nbytes / (ms * 1e-3) / 1e9, peak_GBps=HBM_PEAK_GBPS,
+                 frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS)
+    return entry
+
+
+def valu(entry, ops, ms):
+    entry.update(bound="valu_f32", lane_ops=float(ops), achieved_Tops=ops / (ms * 1e-3) / 1e12, peak_Tops=VALU_PEAK_TOPS,
+                 frac=ops / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS)
+    return entry
+
+
+def pruned(entry, brute_ops, ms, what):
+    entry.update(bound="exact pruned search (%s)" % what, bruteforce_equivalent_Tops=brute_ops / (ms * 1e-3) / 1e12)
+    return entry
+
+
+def cuboid_scene(synth, n, seed=42):
+    pts, nrm = synth.sample_object(n, seed)
+    T = synth.gt_transform(seed)
+    Tinv = np.linalg.inv(T.astype(np.float64))
+    cam = (pts.astype(np.float64) @ Tinv[:3, :3].T + Tinv[:3, 3]).astype(np.float32)
+    return cam, pts, nrm
+
+
+def depth_ops(ctx, tdv, torch, dev, reps=5):
+    out = []
+    h, w = 720, 1280
+    rng = np.random.default_rng(0)
+    raw = (800 + rng.integers(0, 200, (h, w))).astype(np.uint16)
+    mask = np.zeros((h, w), np.uint8); mask[136:584, 416:864] = 255
+    d_raw = torch.from_numpy(raw.view(np.int16)).to(dev); d_mask = torch.from_numpy(mask).to(dev)
+    d_xyz = torch.empty((h * w, 3), dtype=torch.float32, device=dev)
+    cnt = [0]
+
+    def f():
+        cnt[0] = ctx.depth_to_cloud_dev(d_raw.data_ptr(), d_mask.data_ptr(), None, w, h, 1000.0, 900, 900, 640, 360, 1.5, d_xyz.data_ptr(), None, h * w)
+    wall, kms, _ = kernel_ms(ctx, tdv.TIMER_DEPTH, f, torch, reps=reps, warm=2)
+    out.append(hbm(dict(op="depth_to_cloud", workload="one 1280x720 frame, 448x448 mask -> %d points" % cnt[0], ms=wall, kernels_ms=kms,
+                        note="launch-bound: 3 small launches + one 4-byte read-back"), 2 * 3 * h * w + 12 * cnt[0], kms))
+    B = 256
+    masks = np.zeros((B, h, w), np.uint8)
+    for b in range(B):
+        y0 = (b * 37) % (h - 448); x0 = (b * 101) % (w - 448)
+        masks[b, y0:y0 + 448, x0:x0 + 448] = 255
+    d_masks = torch.from_numpy(masks).to(dev)
+    cap = B * 448 * 448
+    d_all = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    off = [None]
+
+    def g():
+        off[0] = ctx.depth_to_cloud_batch_dev(d_raw.data_ptr(), d_masks.data_ptr(), None, B, w, h, 1000.0, 900, 900, 640, 360, 1.5, d_all.data_ptr(), None, cap)
+    wall, kms, _ = kernel_ms(ctx, tdv.TIMER_DEPTH, g, torch, reps=reps, warm=2)
+    npts = int(off[0][-1])
+    out.append(hbm(dict(op="depth_to_cloud_batch", workload="256 stacked 448x448 masks of one 1280x720 frame -> %d points" % npts, ms=wall, kernels_ms=kms),
+                   tdv.DEPTH_BATCH_MASK_PASSES * B * h * w + 2 * h * w + 12 * npts, kms))
+    return out
+
+
+def cloud_ops(ctx, tdv, synth, torch, dev, n, reps=3, want_match=True):
+    out = []
+    cam, mdl, _ = cuboid_scene(synth, n)
+    d_xyz = torch.from_numpy(cam).to(dev)
+    spacing = float(synth.mean_spacing(n))
+    d_out = torch.empty_like(d_xyz)
+    m = [0]
+
+    def f():
+        m[0] = ctx.voxel_downsample_dev(d_xyz.data_ptr(), None, n, spacing * 1.5, d_out.data_ptr(), None, n)
+    wall = median_ms(f, torch, reps=reps)
+    out.append(hbm(dict(op="voxel_downsample", workload="%d points -> %d voxels (first-occurrence order)" % (n, m[0]), ms=wall,
+                        note="12N in + 12V out; the grouping itself moves 16-B records twice more"), 12 * n + 12 * m[0], wall))
+    d_nrm = torch.empty_like(d_xyz)
+    wall = median_ms(lambda: ctx.estimate_normals_dev(d_xyz.data_ptr(), n, 30, d_nrm.data_ptr()), torch, reps=reps)
+    out.append(pruned(dict(op="estimate_normals_k30", workload="%d points" % n, ms=wall), 9.0 * n * n, wall, "kNN, one wave per query"))
+    d_desc = torch.empty((n, 33), dtype=torch.float32, device=dev)
+    wall = median_ms(lambda: ctx.compute_fpfh_dev(d_xyz.data_ptr(), d_nrm.data_ptr(), n, spacing * 5.0, d_desc.data_ptr(), None, None), torch, reps=reps)
+    out.append(pruned(dict(op="compute_fpfh", workload="%d points, radius 5 x spacing" % n, ms=wall), 2 * 9.0 * n * n, wall, "radius search + SPFH/FPFH gathers"))
+    if want_match:
+        d_mx = torch.from_numpy(mdl).to(dev); d_mn = torch.empty_like(d_mx); d_mdesc = torch.empty((n, 33), dtype=torch.float32, device=dev)
+        ctx.estimate_normals_dev(d_mx.data_ptr(), n, 30, d_mn.data_ptr())
+        ctx.compute_fpfh_dev(d_mx.data_ptr(), d_mn.data_ptr(), n, spacing * 5.0, d_mdesc.data_ptr(), None, None)
+        d_corr = torch.empty(n, dtype=torch.int32, device=dev)
+        wall = median_ms(lambda: ctx.feature_match_dev(d_desc.data_ptr(), n, d_mdesc.data_ptr(), n, d_corr.data_ptr()), torch, reps=reps)
+        out.append(pruned(dict(op="feature_match", workload="%d x %d FPFH descriptors of the cuboid (GPU chain), index build included" % (n, n), ms=wall),
+                          98.0 * n * n, wall, "packed index; flat faces give a plateau of near-identical rows that falls back to the scan"))
+    return out
+
+
+def relief_match(ctx, tdv, synth, torch, dev, voxel_px, reps=3):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    bf = importlib.import_module("bench_fm")
+    d_fs, ns, d_ft, nt = bf.descriptors(tdv, synth, ctx, voxel_px, dev)
+    d_corr = torch.empty(ns, dtype=torch.int32, device=dev)
+    wall = median_ms(lambda: ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_corr.data_ptr()), torch, reps=reps)
+    return [pruned(dict(op="feature_match", workload="%d x %d FPFH descriptors of the relief part (C4 instance vs model), index build included" % (ns, nt), ms=wall),
+                   98.0 * ns * nt, wall, "packed index")]
+
+
+def icp_c2(ctx, tdv, synth, torch, dev, reps=3):
+    ns, nt, iters = 50000, 10000, 50
+    tgt, nrm = synth.sample_object(nt, 42)
+    src, T_gt = synth.make_scene(ns, 42)
+    T0 = synth.perturb(T_gt, angle_deg=0.3, trans=0.0005)
+    d_s = torch.from_numpy(src).to(dev); d_t = torch.from_numpy(tgt).to(dev); d_n = torch.from_numpy(nrm).to(dev)
+    thr = 0.4 * float(synth.mean_spacing(nt))
+    out = []
+    for search in ("pruned", "brute"):
+        ctx.set_icp_search(search)
+        wall = median_ms(lambda: ctx.icp_dev(d_s.data_ptr(), ns, d_t.data_ptr(), d_n.data_ptr(), nt, T0, thr, iters, True, fixed_iterations=True), torch, reps=reps)
+        e = dict(op="icp_c2", workload="C2: 50,000 x 10,000, point-to-plane, %d fixed iterations, threshold 0.4 x spacing, %s search" % (iters, search),
+                 ms=wall, iters_per_s=iters / (wall * 1e-3))
+        out.append(valu(e, 8.0 * ns * nt * iters, wall) if search == "brute" else pruned(e, 8.0 * ns * nt * iters, wall, "box walk"))
+    ctx.set_icp_search("auto")
+    return out
+
+
+def c4_batch(ctx, tdv, synth, torch, dev, instances=16, voxel_px=1.2, hyps=10000):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    bb = importlib.import_module("bench_batch")
+    order = tdv.TDV_VOXEL_ORDER_REFERENCE
+    wl = bb.build_workload(tdv, synth, ctx, instances, voxel_px, 448, 3, order, dev)
+    d_mx, d_mn, d_mf, nm = wl["model"]
+    prm = tdv.batch_params(width=bb.W, height=bb.H, scale_to_meters=bb.SCALE, fx=bb.F, fy=bb.F, cx=bb.CX, cy=bb.CY, zmax=bb.ZMAX, voxel_size=wl["voxel"],
+                           ransac_max_iterations=hyps, icp_max_iterations=50, voxel_order=order, n_frames=instances)
+    res = [None]
+
+    def f():
+        res[0] = ctx.register_batch_dev(wl["depth"].data_ptr(), None, wl["masks"].data_ptr(), instances, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+    wall = median_ms(f, torch, reps=3)
+    ang = max(synth.pose_error(r["T"], T)[0] for r, T in zip(res[0], wl["T_gt"]))
+    return [dict(op="register_batch", workload="C4 sample: %d distinct instances (~%d px masks, %d voxels) vs a %d-point model, %d hypotheses + ICP each, reference voxel order"
+                 % (instances, int(np.mean(wl["mask_px"])), int(np.mean([r["n_voxels"] for r in res[0]])), nm, hyps),
+                 ms=wall, instances_per_s=instances / (wall * 1e-3), ms_per_instance=wall / instances, max_angle_to_ground_truth_rad=ang,
+                 icp_iterations_per_instance=float(np.mean([r["icp_iterations"] for r in res[0]])), bound="chain of the operators above")]
+
+
+def measure_all(ctx, tdv, synth, torch, dev, quick=False):
+    out = []
+    out += depth_ops(ctx, tdv, torch, dev)
+    for n in ([100000] if quick else [100000, 200000]):
+        out += cloud_ops(ctx, tdv, synth, torch, dev, n)
+    out += relief_match(ctx, tdv, synth, torch, dev, 1.2)
+    out += icp_c2(ctx, tdv, synth, torch, dev)
+    out += c4_batch(ctx, tdv, synth, torch, dev, instances=8 if quick else 16)
+    return out
