@@ -38,7 +38,7 @@ TDV_MASK_LABEL_BASE = 256
 TDV_VOXEL_ORDER_FIRST = 0
 TDV_VOXEL_ORDER_REFERENCE = 1
 TIMER_ICP_NN, TIMER_RANSAC_SCORE, TIMER_FEATURE_MATCH, TIMER_KNN, TIMER_RADIUS, TIMER_DEPTH, TIMER_VOXEL, TIMER_FM_INDEX = range(8)
-DEPTH_BATCH_MASK_PASSES = 2   # passes over the B masks made by tdv_depth_to_cloud_batch_dev (count + emit): algorithmic bytes of that op
+DEPTH_BATCH_MASK_PASSES = 1   # the B masks cross HBM once in tdv_depth_to_cloud_batch_dev (SURVEY.md 8d's minimum): algorithmic bytes of that op
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [

@@ -300,113 +300,149 @@ void k_emit_batch(const uint16_t* __restrict__ raw0, const int* __restrict__ fra
     }
 }
 
-// ---- vectorised variants (used when the frame size is a multiple of 16 pixels and the pointers are 16-B aligned):
-// 16 consecutive pixels per lane = one 16-B mask load and, only where the mask keeps something, two 16-B depth loads;
-// 4096 pixels per workgroup.  The emit pass compacts through LDS (48 KB) and writes the cloud with coalesced dword stores.
-constexpr int DV_PX = 16;
-constexpr int DV_PX_PER_BLOCK = DP_BLOCK * DV_PX;
+// ---- vectorised path (frame size a multiple of 16 pixels, 16-B aligned pointers): the masks cross HBM ONCE ----------
+// Pass 1 (k_depth_bits): a wave owns 1,024 consecutive pixels (16 per lane).  It loads their depth once per frame, then
+// walks DB_GROUP instances: one 16-B mask load per lane and instance -> 16 validity bits per lane, stored as a bitmap
+// (2 B per lane, 1/8 of the mask's size) and counted per (instance, tile).  All DB_GROUP mask loads are issued before
+// the first is used.  Pass 2 (k_depth_emit_bits) reads the bitmap instead of the masks, skips tiles without a valid
+// pixel before touching anything else, recomputes depth only there, compacts through LDS and writes the cloud with
+// coalesced stores.  HBM bytes for B stacked masks of one W x H frame with n valid pixels in total:
+//   B W H (masks, once) + 2 B W H / 8 (bitmap out and in) + 12 n (points)        [round 1: 2 B W H + 12 n]
+constexpr int DB_PX = 16;
+constexpr int DB_TILE = 64 * DB_PX;       // pixels per wave
+#ifndef DB_GROUP_VALUE
+#define DB_GROUP_VALUE 8
+#endif
+constexpr int DB_GROUP = DB_GROUP_VALUE;  // instances per wave in pass 1
 
-__device__ __forceinline__ unsigned valid_mask16(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ mask, size_t i0,
-                                                 float inv_scale, int mode, float zmax, float (&z)[DV_PX]) {
-    const uint4 mv = *reinterpret_cast<const uint4*>(mask + i0);
+__device__ __forceinline__ unsigned keep_bits16(const uint4 mv, int mode) {
     const unsigned mw[4] = {mv.x, mv.y, mv.z, mv.w};
     unsigned keep = 0;
 #pragma unroll
-    for (int k = 0; k < DV_PX; ++k) keep |= mask_keeps((uint8_t)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu), mode) ? (1u << k) : 0u;
-    unsigned valid = 0;
-    if (keep) {
-        const uint4 r0 = *reinterpret_cast<const uint4*>(raw + i0);
-        const uint4 r1 = *reinterpret_cast<const uint4*>(raw + i0 + 8);
-        const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    for (int k = 0; k < DB_PX; ++k) keep |= mask_keeps((uint8_t)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu), mode) ? (1u << k) : 0u;
+    return keep;
+}
+__device__ __forceinline__ void depth16(const uint16_t* __restrict__ raw, size_t i0, float inv_scale, float (&z)[DB_PX]) {
+    const uint4 r0 = *reinterpret_cast<const uint4*>(raw + i0);
+    const uint4 r1 = *reinterpret_cast<const uint4*>(raw + i0 + 8);
+    const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int k = 0; k < DV_PX; ++k) {
-            float v = (float)((rw[k >> 1] >> (16 * (k & 1))) & 0xffffu) * inv_scale;
-            if (!((keep >> k) & 1u)) v = 0.f;
-            z[k] = v;
-            valid |= (!(v <= 0.f || v > zmax)) ? (1u << k) : 0u;
-        }
+    for (int k = 0; k < DB_PX; ++k) z[k] = (float)((rw[k >> 1] >> (16 * (k & 1))) & 0xffffu) * inv_scale;   // pipeline.cpp:47
+}
+__device__ __forceinline__ unsigned depth_valid16(const float (&z)[DB_PX], float zmax) {
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < DB_PX; ++k) v |= (!(z[k] <= 0.f || z[k] > zmax)) ? (1u << k) : 0u;                    // pipeline.cpp:71
+    return v;
+}
+
+__global__ __launch_bounds__(DP_BLOCK)
+void k_depth_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, size_t n, int n_inst,
+                  int stacked, float inv_scale, int mask_mode, float zmax, int ntiles, uint16_t* __restrict__ bits, int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (DP_BLOCK / 64) + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const size_t i0 = (size_t)tile * DB_TILE + (size_t)lane * DB_PX;
+    const bool inside = i0 < n;                       // n is a multiple of 16: a lane is in or out as a whole
+    const int b0 = blockIdx.y * DB_GROUP, b1 = min(n_inst, b0 + DB_GROUP);
+    uint4 mv[DB_GROUP];
+#pragma unroll
+    for (int u = 0; u < DB_GROUP; ++u) {              // all mask loads of the group in flight at once
+        const int b = b0 + u;
+        mv[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (inside && b < b1 && (stacked || u == 0)) mv[u] = *reinterpret_cast<const uint4*>((stacked ? masks + (size_t)b * n : masks) + i0);
     }
-    return valid;
-}
-
-__global__ __launch_bounds__(DP_BLOCK)
-void k_valid_count_batch_v(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, size_t n, int stacked,
-                           float inv_scale, int mask_mode, float zmax, int* __restrict__ block_counts) {
-    const int b = blockIdx.y;
-    const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
-    const uint16_t* __restrict__ raw = raw0 + frame * n;
-    const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
-    const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
-    const size_t i0 = (size_t)blockIdx.x * DV_PX_PER_BLOCK + (size_t)threadIdx.x * DV_PX;
-    int c = 0;
-    if (i0 < n) { float z[DV_PX]; c = __popc(valid_mask16(raw, mask, i0, inv_scale, mode, zmax, z)); }
-    __shared__ int red[DP_BLOCK / 64];
+    int cur_frame = -1;
+    unsigned dvalid = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) block_counts[(size_t)b * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    for (int u = 0; u < DB_GROUP; ++u) {
+        const int b = b0 + u;
+        if (b >= b1) break;
+        const int frame = frame_of ? frame_of[b] : 0;
+        if (frame != cur_frame) {                      // wave-uniform
+            cur_frame = frame;
+            dvalid = 0;
+            if (inside) { float z[DB_PX]; depth16(raw0 + (size_t)frame * n, i0, inv_scale, z); dvalid = depth_valid16(z, zmax); }
+        }
+        const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
+        const unsigned v = inside ? (keep_bits16(stacked ? mv[u] : mv[0], mode) & dvalid) : 0u;
+        if (inside) bits[(size_t)b * (n / DB_PX) + i0 / DB_PX] = (uint16_t)v;
+        const int c = wave_sum_i32(__popc(v));
+        if (lane == 0) counts[(size_t)b * ntiles + tile] = c;
+    }
 }
 
-__global__ __launch_bounds__(DP_BLOCK)
-void k_emit_batch_v(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, const uint8_t* __restrict__ bgr0,
-                    int width, size_t n, int stacked, float inv_scale, int mask_mode,
-                    float fx, float fy, float cx, float cy, float zmax,
-                    const int* __restrict__ offsets, float* __restrict__ xyz, float* __restrict__ rgb) {
-    __shared__ float stage[DV_PX_PER_BLOCK * 3];   // 48 KB: the workgroup's compacted points (then colours)
-    __shared__ int wsum[DP_BLOCK / 64];
+#ifndef DE_BLOCK_VALUE
+#define DE_BLOCK_VALUE 256
+#endif
+constexpr int DE_BLOCK = DE_BLOCK_VALUE;
+__global__ __launch_bounds__(DE_BLOCK)
+void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ bgr0, const uint16_t* __restrict__ bits,
+                       int width, size_t n, float inv_scale, float fx, float fy, float cx, float cy, int ntiles,
+                       const int* __restrict__ offsets, float* __restrict__ xyz, float* __restrict__ rgb) {
+    __shared__ __attribute__((aligned(16))) float stage[DE_BLOCK / 64][DB_TILE * 3 + 4];   // 12 KB per wave: its compacted points (then colours)
     const int b = blockIdx.y;
-    const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
-    const uint16_t* __restrict__ raw = raw0 + frame * n;
-    const uint8_t* __restrict__ bgr = bgr0 ? bgr0 + frame * n * 3 : nullptr;
-    const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
-    const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
-    const size_t i0 = (size_t)blockIdx.x * DV_PX_PER_BLOCK + (size_t)threadIdx.x * DV_PX;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float z[DV_PX];
-    unsigned valid = 0;
-    if (i0 < n) valid = valid_mask16(raw, mask, i0, inv_scale, mode, zmax, z);
+    const int tile = blockIdx.x * (DE_BLOCK / 64) + wave;
+    if (tile >= ntiles) return;
+    const size_t i0 = (size_t)tile * DB_TILE + (size_t)lane * DB_PX;
+    const unsigned valid = i0 < n ? (unsigned)bits[(size_t)b * (n / DB_PX) + i0 / DB_PX] : 0u;
+    if (!__any(valid != 0u)) return;                       // most tiles of an instance: nothing else is read
+    const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
     const int c = __popc(valid);
     int incl = c;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < DP_BLOCK / 64; ++w) { wbase += (w < wave) ? wsum[w] : 0; total += wsum[w]; }
-    int pos = wbase + incl - c;   // first slot of this lane's points inside the workgroup
+    const int total = __shfl(incl, 63, 64);
+    int pos = incl - c;
+    // The stage is shifted by the output's misalignment so that 16-B chunks of the cloud line up with 16-B chunks of LDS:
+    // the bulk of a tile leaves as dwordx4 stores (4x fewer store instructions than dword stores).
+    const size_t out0 = (size_t)offsets[(size_t)b * ntiles + tile] * 3;
+    const int a = (int)(out0 & 3);
+    float* st = stage[wave] + a;
+    auto flush = [&](float* __restrict__ dst) {
+        const int cnt = total * 3;
+        const int head = min(cnt, (4 - a) & 3);                 // floats before the first 16-B boundary of the output
+        const int body = (cnt - head) / 4;
+        if (lane < head) dst[out0 + lane] = st[lane];
+        for (int q = lane; q < body; q += 64)
+            *reinterpret_cast<float4*>(dst + out0 + head + 4 * (size_t)q) = *reinterpret_cast<const float4*>(st + head + 4 * q);
+        const int done = head + 4 * body;
+        if (lane < cnt - done) dst[out0 + done + lane] = st[done + lane];
+    };
     if (valid) {
+        float z[DB_PX];
+        depth16(raw0 + frame * n, i0, inv_scale, z);
         int v = (int)(i0 / width), u = (int)(i0 - (size_t)v * width);
 #pragma unroll
-        for (int k = 0; k < DV_PX; ++k) {
+        for (int k = 0; k < DB_PX; ++k) {
             if ((valid >> k) & 1u) {
-                stage[3 * pos] = ((float)u - cx) * z[k] / fx;     // pipeline.cpp:73
-                stage[3 * pos + 1] = ((float)v - cy) * z[k] / fy; // pipeline.cpp:74
-                stage[3 * pos + 2] = z[k];
+                st[3 * pos] = ((float)u - cx) * z[k] / fx;     // pipeline.cpp:73
+                st[3 * pos + 1] = ((float)v - cy) * z[k] / fy; // pipeline.cpp:74
+                st[3 * pos + 2] = z[k];
                 ++pos;
             }
             if (++u == width) { u = 0; ++v; }
         }
     }
-    __syncthreads();
-    const size_t out0 = (size_t)offsets[(size_t)b * gridDim.x + blockIdx.x] * 3;
-    for (int e = threadIdx.x; e < total * 3; e += DP_BLOCK) xyz[out0 + e] = stage[e];
-    if (rgb && bgr) {
-        __syncthreads();
-        pos = wbase + incl - c;
+    __builtin_amdgcn_wave_barrier();   // one wave writes and reads its own stage (LDS ops of a wave complete in order): no workgroup barrier
+    flush(xyz);
+    if (rgb && bgr0) {
+        const uint8_t* __restrict__ bgr = bgr0 + frame * n * 3;
+        __builtin_amdgcn_wave_barrier();
+        pos = incl - c;
         if (valid) {
 #pragma unroll
-            for (int k = 0; k < DV_PX; ++k) {
+            for (int k = 0; k < DB_PX; ++k) {
                 if ((valid >> k) & 1u) {
                     const uint8_t* p = bgr + (i0 + k) * 3;
-                    stage[3 * pos] = (float)p[2] / 255.0f; stage[3 * pos + 1] = (float)p[1] / 255.0f; stage[3 * pos + 2] = (float)p[0] / 255.0f;
+                    st[3 * pos] = (float)p[2] / 255.0f; st[3 * pos + 1] = (float)p[1] / 255.0f; st[3 * pos + 2] = (float)p[0] / 255.0f;
                     ++pos;
                 }
             }
         }
-        __syncthreads();
-        for (int e = threadIdx.x; e < total * 3; e += DP_BLOCK) rgb[out0 + e] = stage[e];
+        __builtin_amdgcn_wave_barrier();
+        flush(rgb);
     }
 }
 
@@ -417,10 +453,9 @@ __global__ void k_gather_instance_offsets(const int* __restrict__ offsets, const
 }
 
 static bool batch_vectorisable(const uint16_t* d_raw, const uint8_t* d_masks, size_t n) {
-    return n % 16 == 0 && ((uintptr_t)d_raw % 16 == 0) && ((uintptr_t)d_masks % 16 == 0);   // stacked masks sit at multiples of n
+    return n % 16 == 0 && ((uintptr_t)d_raw % 16 == 0) && ((uintptr_t)d_masks % 16 == 0);   // stacked masks and frames sit at multiples of n
 }
 
-// pass 1 (count + scan): returns the per-instance start offsets (host, n_inst + 1 entries) and keeps the device scan
 // Device copy of the instance -> frame map (nullptr when every instance reads frame 0).
 int frame_map_dev(tdv_ctx* ctx, int n_inst, int n_frames, const int* h_frame_of, const int** d_frame_of) {
     *d_frame_of = nullptr;
@@ -438,21 +473,26 @@ int frame_map_dev(tdv_ctx* ctx, int n_inst, int n_frames, const int* h_frame_of,
     return TDV_OK;
 }
 
+// pass 1 (bitmap + counts + scan): returns the per-instance start offsets (host, n_inst + 1 entries) and keeps the device
+// scan and the bitmap (ctx workspace) for pass 2
 int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, int n_inst, int stacked, int w, int h,
                                float scale, int mask_mode, float zmax, int** d_offsets_out, int* h_offsets) {
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
     const bool vec = batch_vectorisable(d_raw, d_masks, n);
-    const int blocks = (int)((n + (vec ? DV_PX_PER_BLOCK : DP_PX_PER_BLOCK) - 1) / (vec ? DV_PX_PER_BLOCK : DP_PX_PER_BLOCK));
+    const int blocks = vec ? (int)((n + DB_TILE - 1) / DB_TILE) : (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);   // tiles resp. workgroups per instance
     int *counts, *offsets, *d_total, *d_inst;
     TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &counts));
     TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &offsets));
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
     TDV_TRY(ws_alloc(ctx, (size_t)n_inst + 1, &d_inst));
+    ctx->depth_bits = nullptr;
+    if (vec) TDV_TRY(ws_alloc(ctx, (size_t)n_inst * (n / DB_PX), &ctx->depth_bits));
     hipStream_t s = ctx->stream;
     {
         ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-        if (vec) k_valid_count_batch_v<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
+        if (vec) k_depth_bits<<<dim3((blocks + DP_BLOCK / 64 - 1) / (DP_BLOCK / 64), (n_inst + DB_GROUP - 1) / DB_GROUP), DP_BLOCK, 0, s>>>(
+                     d_raw, d_frame_of, d_masks, n, n_inst, stacked, inv_scale, mask_mode, zmax, blocks, ctx->depth_bits, counts);
         else k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
     }
     TDV_CHECK_LAUNCH(ctx);
@@ -474,12 +514,17 @@ int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
     const bool vec = batch_vectorisable(d_raw, d_masks, n);
-    const int blocks = (int)((n + (vec ? DV_PX_PER_BLOCK : DP_PX_PER_BLOCK) - 1) / (vec ? DV_PX_PER_BLOCK : DP_PX_PER_BLOCK));
     ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-    if (vec) k_emit_batch_v<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
-                                                                                fx, fy, cx, cy, zmax, d_offsets, d_xyz, d_rgb);
-    else k_emit_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
+    if (vec) {
+        if (!ctx->depth_bits) return TDV_ERR_INTERNAL;
+        const int ntiles = (int)((n + DB_TILE - 1) / DB_TILE);
+        k_depth_emit_bits<<<dim3((ntiles + DE_BLOCK / 64 - 1) / (DE_BLOCK / 64), n_inst), DE_BLOCK, 0, ctx->stream>>>(
+            d_raw, d_frame_of, d_bgr, ctx->depth_bits, w, n, inv_scale, fx, fy, cx, cy, ntiles, d_offsets, d_xyz, d_rgb);
+    } else {
+        const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
+        k_emit_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
                                                                           fx, fy, cx, cy, zmax, d_offsets, d_xyz, d_rgb);
+    }
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }

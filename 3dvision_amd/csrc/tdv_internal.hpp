@@ -33,6 +33,7 @@ struct tdv_ctx {
     char err[512] = {0};
     bool timing = false;
     int icp_search = 0;      // TDV_ICP_SEARCH_AUTO / _BRUTE / _PRUNED (tdv_ctx_set_icp_search)
+    uint16_t* depth_bits = nullptr;   // validity bitmap between the two passes of the batched depth -> cloud (workspace memory of the current call)
     tdv_ctx* helper = nullptr;   // second stream + workspace of the batched pipeline's other lane (owned; created on first use)
     tdv::TimerSlot timers[TDV_TIMER_COUNT];
     std::vector<hipEvent_t> event_pool;
@@ -62,6 +63,20 @@ inline int set_err(tdv_ctx* ctx, hipError_t e, const char* what, int line) {
 #define TDV_CHECK_LAUNCH(ctx) TDV_HIP((ctx), hipGetLastError())
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+#ifdef __HIPCC__
+// Sum over the 64 lanes of a wave with DPP row operations (no LDS crossbar traffic, unlike __shfl_down): the result is
+// valid in lane 63 and returned wave-uniform.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, false);   // row_mirror: every lane of a 16-lane row holds the row sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#endif
 
 // Workspace: reset at the start of every public entry point.
 int ws_reset(tdv_ctx* ctx);
