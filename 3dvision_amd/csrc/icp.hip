@@ -131,7 +131,15 @@ void k_icp_nn_scan(const float* __restrict__ src, int ns, int ns_pad,
 #ifndef PN_WAVES_VALUE
 #define PN_WAVES_VALUE 1
 #endif
-constexpr int PN_WAVES = PN_WAVES_VALUE;   // one wave per source point and per workgroup (measured at 200k: 1 wave 0.169 ms, 4: 0.177, 16: 0.217)
+constexpr int PN_WAVES = PN_WAVES_VALUE;   // waves per workgroup (measured at 200k: 1 wave 0.169 ms, 4: 0.177, 16: 0.217)
+#ifndef PN_PTS_VALUE
+#define PN_PTS_VALUE 1
+#endif
+// Consecutive source points per wave; their results leave as ONE store per array.  With 1 every result is its own 4-B
+// partial-line write (13 MB of WRITE_SIZE per launch for 1.6 MB of results at 200k), which costs bytes but no time: the
+// kernel is bound by its box walk, and longer waves balance worse — measured at 200k x 200k (tools/studies/icp_probe.py,
+// profiles/r2/history/icp_nn_points_per_wave.jsonl): 1: 0.131 ms, 4: 0.141, 8: 0.144, 16: 0.155, 32: 0.166 ms per launch.
+constexpr int PN_PTS = PN_PTS_VALUE;
 
 // lower bound of fl(d2) between point p and any point inside box idx (see knn.hip: box_lower_bound)
 __device__ __forceinline__ float point_box_lb(const float* __restrict__ box, int count, int idx, float px, float py, float pz) {
@@ -141,7 +149,8 @@ __device__ __forceinline__ float point_box_lb(const float* __restrict__ box, int
     return gx * gx + (gy * gy + gz * gz);
 }
 
-// One wave per source point.  The 4096-point boxes are tested one per lane and visited best-first (smallest lower
+// One wave per source point at a time, PN_PTS consecutive points per wave (lane p keeps point p's result and the wave
+// stores them together).  The 4096-point boxes are tested one per lane and visited best-first (smallest lower
 // bound first, until it exceeds the bound); inside one, its 64 leaves (64 points each) are tested one per lane, and
 // the points of a leaf that passes are evaluated one per lane (coalesced).  bound = the inclusive acceptance
 // threshold, then the best distance found so far.  Each lane keeps its own (d2, original index) minimum; the wave
@@ -155,8 +164,11 @@ void k_icp_nn_pruned(const float* __restrict__ src, int ns,
                      float* __restrict__ out_d2, int* __restrict__ out_idx) {
     if (st->done) return;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * PN_WAVES + (threadIdx.x >> 6);
-    if (i >= ns) return;   // wave-uniform
+    const int i0 = (blockIdx.x * PN_WAVES + (threadIdx.x >> 6)) * PN_PTS;
+    if (i0 >= ns) return;   // wave-uniform
+    float res_d = FLT_MAX; int res_o = 0;   // lane p: the result of point i0 + p
+    for (int p = 0; p < PN_PTS && i0 + p < ns; ++p) {
+    const int i = i0 + p;
     float px, py, pz;
     transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
     float B = tau;           // wave-uniform; a target passes iff d2 <= B
@@ -204,10 +216,9 @@ void k_icp_nn_pruned(const float* __restrict__ src, int ns,
         const bool take = od < bd || (od == bd && oo < bo);
         bd = take ? od : bd; bo = take ? oo : bo;
     }
-    if (lane == 0) {
-        out_d2[i] = bo == INT_MAX ? FLT_MAX : bd;
-        out_idx[i] = bo == INT_MAX ? 0 : bo;
+    if (lane == p) { res_d = bo == INT_MAX ? FLT_MAX : bd; res_o = bo == INT_MAX ? 0 : bo; }
     }
+    if (lane < PN_PTS && i0 + lane < ns) { out_d2[i0 + lane] = res_d; out_idx[i0 + lane] = res_o; }
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -484,7 +495,7 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
             {
                 ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
                 if (pruned)
-                    k_icp_nn_pruned<<<(ns + PN_WAVES - 1) / PN_WAVES, 64 * PN_WAVES, 0, s>>>(
+                    k_icp_nn_pruned<<<(ns + PN_WAVES * PN_PTS - 1) / (PN_WAVES * PN_PTS), 64 * PN_WAVES, 0, s>>>(
                         d_src, ns, st.sx, st.sy, st.sz, st.orig, nt, st.lbox, st.n_leaf, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
                 else
                     k_icp_nn_scan<<<grid, NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
@@ -530,7 +541,7 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
     if (pruned) {   // explicit request only: entries beyond the threshold come back as corr 0 / d2 FLT_MAX
         SortedCloud st{};
         TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
-        k_icp_nn_pruned<<<(ns + PN_WAVES - 1) / PN_WAVES, 64 * PN_WAVES, 0, s>>>(
+        k_icp_nn_pruned<<<(ns + PN_WAVES * PN_PTS - 1) / (PN_WAVES * PN_PTS), 64 * PN_WAVES, 0, s>>>(
             d_src, ns, st.sx, st.sy, st.sz, st.orig, nt, st.lbox, st.n_leaf, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
     } else {
         k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
