@@ -166,56 +166,58 @@ void k_emit(const uint16_t* __restrict__ raw, const float* __restrict__ depth, c
 }
 
 // ------------------------------------------------------------------ bilateral depth filter
-// Restates the reference's (never-called) CUDA kernel cuda/depth_processing.cu:62-122 and its launcher :124-155:
-// radius = int(2*sigma_s + 0.5) clamped to 5; weight = expf(d2 * (-0.5/sigma_s^2) + dr^2 * (-0.5/sigma_r^2));
-// zero depths are skipped and stay zero; taps outside the image read 0 (skipped); sums run row-major over the window.
-// Tile: 64 x 4 pixels per 256-thread workgroup (one wave = one image row segment: coalesced 256 B rows),
-// halo staged in LDS.
-constexpr int BF_TW = 64, BF_TH = 4, BF_MAXR = 5;
+// Semantics of the reference's (never-called) filter, cuda/depth_processing.cu:62-155: window radius
+// int(2 sigma_s + 0.5) clamped to 5; weight expf(d2 * (-0.5/sigma_s^2) + dr^2 * (-0.5/sigma_r^2)); zero depths are
+// skipped and stay zero; taps outside the image count as zero; sums run row-major over the window (so results equal the
+// CPU restatement's within expf's last bit).
+// Design for gfx950 — no LDS tile, no barriers: one wave owns 64 consecutive pixels of ONE image row and streams the
+// 2r + 1 rows of its window through registers.  A row of the window is two coalesced loads (the 64 pixels shifted by
+// -r, and the 2r pixels that follow); the tap at offset dx is then a lane rotation of that register pair
+// (ds_bpermute through the LDS crossbar, no LDS storage).  The spatial term of a tap is wave-uniform (a scalar
+// operand); only the range term and the exponential are per lane.
+constexpr int BF_MAXR = 5;
 
-__global__ __launch_bounds__(BF_TW * BF_TH)
-void k_bilateral(const float* __restrict__ in, float* __restrict__ out, int width, int height, int radius,
-                 float inv_spatial2, float inv_range2) {
-    __shared__ float tile[BF_TH + 2 * BF_MAXR][BF_TW + 2 * BF_MAXR + 2];
-    const int tx = threadIdx.x & (BF_TW - 1), ty = threadIdx.x / BF_TW;
-    const int gx0 = blockIdx.x * BF_TW - radius, gy0 = blockIdx.y * BF_TH - radius;
-    const int sw = BF_TW + 2 * radius, sh = BF_TH + 2 * radius;
-    for (int sy = ty; sy < sh; sy += BF_TH)
-        for (int sx = tx; sx < sw; sx += BF_TW) {
-            int gx = gx0 + sx, gy = gy0 + sy;
-            float v = 0.f;
-            if (gx >= 0 && gx < width && gy >= 0 && gy < height) v = in[(size_t)gy * width + gx];
-            tile[sy][sx] = v;
+__global__ __launch_bounds__(256)
+void k_bilateral_rows(const float* __restrict__ depth, float* __restrict__ filtered, int width, int height, int radius,
+                      float spatial_scale, float range_scale) {
+    const int lane = threadIdx.x & 63;
+    const int segments = (width + 63) / 64;
+    const int seg = blockIdx.x * 4 + (threadIdx.x >> 6);             // wave-uniform: (row, 64-pixel segment)
+    if (seg >= segments * height) return;
+    const int row = seg / segments, col0 = (seg - row * segments) * 64;
+    const int col = col0 + lane;
+    const float mine = col < width ? depth[(size_t)row * width + col] : 0.f;
+    float weight_sum = 0.f, value_sum = 0.f;
+    for (int oy = -radius; oy <= radius; ++oy) {
+        const int r = row + oy;
+        const bool row_inside = r >= 0 && r < height;                 // wave-uniform
+        // window of this row: pixels col0 - radius ... col0 + 63 + radius as (lo: first 64, hi: the rest)
+        const int c_lo = col0 - radius + lane, c_hi = c_lo + 64;
+        const float lo = (row_inside && c_lo >= 0 && c_lo < width) ? depth[(size_t)r * width + c_lo] : 0.f;
+        const float hi = (row_inside && lane < 2 * radius && c_hi < width) ? depth[(size_t)r * width + c_hi] : 0.f;
+        for (int ox = -radius; ox <= radius; ++ox) {
+            const int k = lane + ox + radius;                          // position of this lane's tap inside the window
+            const float a = __shfl(lo, k & 63, 64), b = __shfl(hi, k & 63, 64);
+            const float tap = k < 64 ? a : b;
+            if (tap <= 0.f) continue;                                  // missing depth (or outside the image)
+            const float dr = tap - mine;
+            const float w = expf((float)(ox * ox + oy * oy) * spatial_scale + dr * dr * range_scale);
+            weight_sum += w;
+            value_sum += w * tap;
         }
-    __syncthreads();
-    const int x = blockIdx.x * BF_TW + tx, y = blockIdx.y * BF_TH + ty;
-    if (x >= width || y >= height) return;
-    const int scx = tx + radius, scy = ty + radius;
-    const float center = tile[scy][scx];
-    if (center <= 0.f) { out[(size_t)y * width + x] = 0.f; return; }
-    float sum_w = 0.f, sum_v = 0.f;
-    for (int dy = -radius; dy <= radius; ++dy)
-        for (int dx = -radius; dx <= radius; ++dx) {
-            float nb = tile[scy + dy][scx + dx];
-            if (nb <= 0.f) continue;
-            float rd = nb - center;
-            float w = expf((float)(dx * dx + dy * dy) * inv_spatial2 + rd * rd * inv_range2);
-            sum_w += w;
-            sum_v += w * nb;
-        }
-    out[(size_t)y * width + x] = (sum_w > 0.f) ? (sum_v / sum_w) : center;
+    }
+    if (col < width) filtered[(size_t)row * width + col] = mine <= 0.f ? 0.f : (weight_sum > 0.f ? value_sum / weight_sum : mine);
 }
 
 int bilateral_filter_dev(tdv_ctx* ctx, const float* d_in, float* d_out, int w, int h, float sigma_spatial, float sigma_range) {
     if (!ctx || !d_in || !d_out || w < 0 || h < 0 || !(sigma_spatial > 0.f) || !(sigma_range > 0.f)) return TDV_ERR_BAD_ARG;
     if ((size_t)w * h == 0) return TDV_OK;
-    int radius = static_cast<int>(2.0f * sigma_spatial + 0.5f);   // depth_processing.cu:131
-    if (radius > BF_MAXR) radius = BF_MAXR;                        // :132-136 (clamped; the reference also prints a warning)
-    const float inv_spatial2 = -0.5f / (sigma_spatial * sigma_spatial);
-    const float inv_range2 = -0.5f / (sigma_range * sigma_range);
-    dim3 grid((w + BF_TW - 1) / BF_TW, (h + BF_TH - 1) / BF_TH);
+    const int radius = std::min(BF_MAXR, static_cast<int>(2.0f * sigma_spatial + 0.5f));   // depth_processing.cu:131-136
+    const float spatial_scale = -0.5f / (sigma_spatial * sigma_spatial);
+    const float range_scale = -0.5f / (sigma_range * sigma_range);
+    const long long waves = (long long)((w + 63) / 64) * h;
     ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-    k_bilateral<<<grid, BF_TW * BF_TH, 0, ctx->stream>>>(d_in, d_out, w, h, radius, inv_spatial2, inv_range2);
+    k_bilateral_rows<<<(unsigned)((waves + 3) / 4), 256, 0, ctx->stream>>>(d_in, d_out, w, h, radius, spatial_scale, range_scale);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }

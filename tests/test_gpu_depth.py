@@ -94,6 +94,12 @@ def test_bilateral_filter(ctx, orc):
         ref = orc.bilateral_filter(d, ss, sr)
         assert np.array_equal(got == 0, ref == 0) and np.array_equal(got == 0, d == 0)
         assert np.abs(got - ref).max() <= 2e-6
+    # known answers that need no oracle: a constant image is a fixed point (the weights cancel); an isolated pixel keeps its value
+    flat = np.full((70, 300), 0.75, np.float32)
+    assert np.abs(ctx.bilateral_filter(flat, 1.5, 0.02) - 0.75).max() <= 1e-6
+    lone = np.zeros((40, 130), np.float32); lone[20, 64] = 0.9; lone[0, 0] = 0.5; lone[39, 129] = 0.6
+    out = ctx.bilateral_filter(lone, 2.0, 0.01)
+    assert out[20, 64] == np.float32(0.9) and out[0, 0] == np.float32(0.5) and out[39, 129] == np.float32(0.6) and np.count_nonzero(out) == 3
 
 
 def test_label_image_masks(ctx, orc, tdv):
