@@ -1,8 +1,25 @@
+#!/bin/bash
+# One gpurun call: the bench line, the kernel trace of the same command, the PMC passes (FETCH_SIZE, WRITE_SIZE, SQ) for
+# bench.py and for tools/bench_ops.py, and the full C4 batch.  Programs are started directly after `rocprofv3 ... --`.
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
-python3 $R/bench.py > $O/bench_v7.json 2> $O/bench_v7.err
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2prof
+rm -rf $O; mkdir -p $O
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_v7 -- python3 $R/bench.py --no-cpu-baseline > $O/prof_v7_bench.json 2> $O/prof_v7.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_v7 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/pmc_fetch_v7.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_v7 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2> $O/pmc_write_v7.err
-cat $O/bench_v7.json
+B="python3 $R/bench.py --no-cpu-baseline --no-operators"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bench -- $B > $O/bench_under_rocprof.json 2> $O/kt_bench.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_bench -- $B > /dev/null 2> $O/pmc_fetch_bench.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_bench -- $B > /dev/null 2> $O/pmc_write_bench.err
+P="python3 $R/tools/bench_ops.py"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_ops -- $P > $O/bench_ops_under_rocprof.jsonl 2> $O/kt_ops.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_ops -- $P > /dev/null 2> $O/pmc_fetch_ops.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_ops -- $P > /dev/null 2> $O/pmc_write_ops.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq_ops -- $P > /dev/null 2> $O/pmc_sq_ops.err || echo "SQ pass failed" >> $O/notes.txt
+python3 $R/tools/bench_ops.py > $O/bench_ops.jsonl 2> $O/bench_ops.err
+python3 $R/tools/bench_batch.py --instances 256 > $O/bench_batch_c4_256.jsonl 2> $O/bench_batch_c4_256.err
+python3 $R/tools/bench_batch.py --instances 256 --order first >> $O/bench_batch_c4_256.jsonl 2>> $O/bench_batch_c4_256.err
+python3 $R/tools/bench_batch.py --instances 256 --voxel-px 2.0 >> $O/bench_batch_c4_256.jsonl 2>> $O/bench_batch_c4_256.err
+TDV_BATCH_LANES=1 python3 $R/tools/bench_batch.py --instances 64 >> $O/bench_batch_c4_256.jsonl 2>> $O/bench_batch_c4_256.err
+# keep the merge small: per-dispatch traces are dropped, the stats and counter tables stay
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
+du -sh $O; cat $O/bench.json | head -c 600
