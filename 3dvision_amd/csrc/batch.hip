@@ -38,6 +38,12 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         TDV_TRY(fm_index_build(ctx, d_model_fpfh, n_model, &model_index));
         have_index = true;
     }
+    // likewise the model's Morton order and boxes for the ICP correspondence search (built when ICP will take the pruned path)
+    SortedCloud model_sorted{}; bool have_sorted = false;
+    if (n_model >= 4096 && ctx->icp_search != TDV_ICP_SEARCH_BRUTE) {
+        TDV_TRY(spatial_sort_cloud(ctx, d_model_xyz, n_model, model_sorted));
+        have_sorted = true;
+    }
     // one instance: voxel -> normals + FPFH -> match -> RANSAC -> ICP on context c (its stream, its workspace)
     auto run_instance = [&](tdv_ctx* c, int b) -> int {
         tdv_instance_result& r = results[b];
@@ -65,7 +71,8 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         r.coarse_fitness = coarse.fitness; r.coarse_inliers = coarse.inliers;
         tdv_icp_result fine;
         const float thr = prm->voxel_size * prm->icp_distance_factor;  // pipeline.cpp:104
-        TDV_TRY(icp_run_dev(c, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine));
+        TDV_TRY(icp_run_dev(c, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine,
+                            have_sorted ? &model_sorted : nullptr));
         std::memcpy(r.T, fine.T, 64);
         r.fitness = fine.fitness; r.rmse = fine.rmse; r.icp_iterations = fine.iterations;
         r.status = 0;

@@ -452,7 +452,7 @@ int alloc_buffers(tdv_ctx* ctx, const NnPlan& p, IcpBuffers& b) {
 
 int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
                 const float* T0, float thr, int max_iterations, int point_to_plane, int fixed_iterations,
-                tdv_icp_result* out) {
+                tdv_icp_result* out, const SortedCloud* tgt_sorted) {
     if (!ctx || !d_src || !d_tgt || !T0 || !out || ns < 0 || nt < 0 || max_iterations < 0) return TDV_ERR_BAD_ARG;
     TDV_HIP(ctx, hipSetDevice(ctx->device));
     // result defaults: registration.cpp:309-311
@@ -479,7 +479,8 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
     SortedCloud st{};
     if (pruned) {
-        TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
+        if (tgt_sorted && tgt_sorted->n == nt) st = *tgt_sorted;   // the batch orders the shared model once
+        else TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
     } else {
         k_aos_to_soa_pad<<<(p.nt_pad + 255) / 256, 256, 0, s>>>(d_tgt, nt, p.nt_pad, INFINITY, b.tx, b.ty, b.tz);
     }

@@ -109,9 +109,11 @@ struct ScopedTimer {
 struct IcpOutputs {  // optional per-source outputs of one correspondence pass (device pointers)
     int* corr = nullptr; float* d2 = nullptr; uint8_t* accepted = nullptr;
 };
+struct SortedCloud;
+// tgt_sorted (optional): the target in Morton order with its boxes, built once by spatial_sort_cloud and reused across calls
 int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
                 const float* T0, float thr, int max_iterations, int point_to_plane, int fixed_iterations,
-                tdv_icp_result* out);
+                tdv_icp_result* out, const SortedCloud* tgt_sorted = nullptr);
 int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
                             const float* T, float thr, IcpOutputs outs, int* n_corr);
 int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
