@@ -31,7 +31,7 @@ SCALE = 50000.0          # depth.scale_to_meters: 0.02 mm units (z = 0.45 m -> 2
 ZMAX = 1.3
 
 
-def build_workload(tdv, synth, ctx, B, voxel_px, part_px, seed, order, dev):
+def build_workload(tdv, synth, ctx, B, voxel_px, part_px, seed, order, dev, first_pose=0):
     """Frames, masks, ground truths and the prepared model, all on the device."""
     import torch
     px = DIST / F                                  # pixel footprint at the working distance (0.3 mm)
@@ -45,7 +45,7 @@ def build_workload(tdv, synth, ctx, B, voxel_px, part_px, seed, order, dev):
     d_masks = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
     T_gt = []
     for b in range(B):
-        S = synth.instance_pose(b, DIST, 30.0)
+        S = synth.instance_pose(first_pose + b, DIST, 30.0)
         d_depth[b], d_masks[b] = synth.render_depth_torch(dense, S, F, F, CX, CY, W, H, SCALE)
         T_gt.append(M @ np.linalg.inv(S))
     # model: scan -> cloud -> voxel -> normals -> FPFH (Pipeline::run :291-294)
