@@ -315,7 +315,8 @@ constexpr int DB_TILE = 64 * DB_PX;       // pixels per wave
 #ifndef DB_GROUP_VALUE
 #define DB_GROUP_VALUE 8
 #endif
-constexpr int DB_GROUP = DB_GROUP_VALUE;  // instances per wave in pass 1
+constexpr int DB_GROUP = DB_GROUP_VALUE;  // instances per wave in pass 1 (8: the LDS transpose of the bitmap words assumes it)
+static_assert(DB_GROUP == 8, "k_depth_bits stores 8 instances x 64 words as 64 x 16 B");
 
 __device__ __forceinline__ unsigned keep_bits16(const uint4 mv, int mode) {
     const unsigned mw[4] = {mv.x, mv.y, mv.z, mv.w};
@@ -354,23 +355,39 @@ void k_depth_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ fra
         mv[u] = make_uint4(0u, 0u, 0u, 0u);
         if (inside && b < b1 && (stacked || u == 0)) mv[u] = *reinterpret_cast<const uint4*>((stacked ? masks + (size_t)b * n : masks) + i0);
     }
+    // The 16 validity bits of a lane are 2 bytes: stored lane by lane they would leave as 2-byte stores, the slowest shape
+    // there is (per byte an order of magnitude above 16-B stores).  The wave therefore transposes its DB_GROUP x 64 words
+    // through 1 KB of LDS and every lane stores 16 B: eight lanes cover one instance's 128-B row segment.
+    __shared__ __attribute__((aligned(16))) uint16_t xpose[DP_BLOCK / 64][DB_GROUP][64];
+    const int wave = threadIdx.x >> 6;
     int cur_frame = -1;
     unsigned dvalid = 0;
 #pragma unroll
     for (int u = 0; u < DB_GROUP; ++u) {
         const int b = b0 + u;
-        if (b >= b1) break;
-        const int frame = frame_of ? frame_of[b] : 0;
-        if (frame != cur_frame) {                      // wave-uniform
-            cur_frame = frame;
-            dvalid = 0;
-            if (inside) { float z[DB_PX]; depth16(raw0 + (size_t)frame * n, i0, inv_scale, z); dvalid = depth_valid16(z, zmax); }
+        unsigned v = 0u;
+        if (b < b1) {                                      // wave-uniform
+            const int frame = frame_of ? frame_of[b] : 0;
+            if (frame != cur_frame) {                      // wave-uniform
+                cur_frame = frame;
+                dvalid = 0;
+                if (inside) { float z[DB_PX]; depth16(raw0 + (size_t)frame * n, i0, inv_scale, z); dvalid = depth_valid16(z, zmax); }
+            }
+            const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
+            v = inside ? (keep_bits16(stacked ? mv[u] : mv[0], mode) & dvalid) : 0u;
+            const int c = wave_sum_i32(__popc(v));
+            if (lane == 0) counts[(size_t)b * ntiles + tile] = c;
         }
-        const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
-        const unsigned v = inside ? (keep_bits16(stacked ? mv[u] : mv[0], mode) & dvalid) : 0u;
-        if (inside) bits[(size_t)b * (n / DB_PX) + i0 / DB_PX] = (uint16_t)v;
-        const int c = wave_sum_i32(__popc(v));
-        if (lane == 0) counts[(size_t)b * ntiles + tile] = c;
+        xpose[wave][u][lane] = (uint16_t)v;
+    }
+    __builtin_amdgcn_wave_barrier();                       // a wave reads back only what it wrote itself
+    const size_t words = n / DB_PX;                        // bitmap words per instance
+    const int u2 = lane >> 3, seg = lane & 7;              // this lane stores words [seg*8, seg*8+8) of instance b0 + u2
+    const size_t w0 = (size_t)tile * 64 + (size_t)seg * 8;
+    if (b0 + u2 < b1 && w0 < words) {
+        uint16_t* dst = bits + (size_t)(b0 + u2) * words + w0;
+        if (w0 + 8 <= words && (words % 8) == 0) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&xpose[wave][u2][seg * 8]);
+        else for (int k = 0; k < 8 && w0 + k < words; ++k) dst[k] = xpose[wave][u2][seg * 8 + k];
     }
 }
 
@@ -378,73 +395,56 @@ void k_depth_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ fra
 #define DE_BLOCK_VALUE 256
 #endif
 constexpr int DE_BLOCK = DE_BLOCK_VALUE;
+// Pass 2.  A wave owns the same 1,024 pixels as in pass 1 but walks them in 16 rounds of 64 CONSECUTIVE pixels (lane =
+// pixel): the valid pixels of a round are consecutive points of the output, so a lane's slot is the round's base plus the
+// number of valid lanes below it (one s_bcnt / v_mbcnt on the round's 64-bit mask) — no per-lane prefix sums, no
+// compaction buffer, stores of neighbouring lanes are neighbours in memory.  (The first version let every lane own 16
+// consecutive pixels and compacted through LDS: its 48 ds_write_b32 per lane hit 4 of the 64 banks — lane stride 48 dwords
+// — and the pass ran at 3.8 TB/s.)  The round masks come from the bitmap words the lanes hold (4 v_readlane per round);
+// the tile's raw depths are staged once in 2 KB of LDS so that a round reads them lane = pixel.
 __global__ __launch_bounds__(DE_BLOCK)
 void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ bgr0, const uint16_t* __restrict__ bits,
                        int width, size_t n, float inv_scale, float fx, float fy, float cx, float cy, int ntiles,
                        const int* __restrict__ offsets, float* __restrict__ xyz, float* __restrict__ rgb) {
-    __shared__ __attribute__((aligned(16))) float stage[DE_BLOCK / 64][DB_TILE * 3 + 4];   // 12 KB per wave: its compacted points (then colours)
+    __shared__ __attribute__((aligned(16))) uint16_t zraw[DE_BLOCK / 64][DB_TILE];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tile = blockIdx.x * (DE_BLOCK / 64) + wave;
     if (tile >= ntiles) return;
-    const size_t i0 = (size_t)tile * DB_TILE + (size_t)lane * DB_PX;
-    const unsigned valid = i0 < n ? (unsigned)bits[(size_t)b * (n / DB_PX) + i0 / DB_PX] : 0u;
-    if (!__any(valid != 0u)) return;                       // most tiles of an instance: nothing else is read
+    const size_t t0 = (size_t)tile * DB_TILE;                         // first pixel of the tile
+    const size_t i0 = t0 + (size_t)lane * DB_PX;
+    const unsigned word = i0 < n ? (unsigned)bits[(size_t)b * (n / DB_PX) + i0 / DB_PX] : 0u;   // validity of pixels i0 .. i0 + 15
+    if (!__any(word != 0u)) return;                                   // most tiles of an instance: nothing else is read
     const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
-    const int c = __popc(valid);
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-    const int total = __shfl(incl, 63, 64);
-    int pos = incl - c;
-    // The stage is shifted by the output's misalignment so that 16-B chunks of the cloud line up with 16-B chunks of LDS:
-    // the bulk of a tile leaves as dwordx4 stores (4x fewer store instructions than dword stores).
-    const size_t out0 = (size_t)offsets[(size_t)b * ntiles + tile] * 3;
-    const int a = (int)(out0 & 3);
-    float* st = stage[wave] + a;
-    auto flush = [&](float* __restrict__ dst) {
-        const int cnt = total * 3;
-        const int head = min(cnt, (4 - a) & 3);                 // floats before the first 16-B boundary of the output
-        const int body = (cnt - head) / 4;
-        if (lane < head) dst[out0 + lane] = st[lane];
-        for (int q = lane; q < body; q += 64)
-            *reinterpret_cast<float4*>(dst + out0 + head + 4 * (size_t)q) = *reinterpret_cast<const float4*>(st + head + 4 * q);
-        const int done = head + 4 * body;
-        if (lane < cnt - done) dst[out0 + done + lane] = st[done + lane];
-    };
-    if (valid) {
-        float z[DB_PX];
-        depth16(raw0 + frame * n, i0, inv_scale, z);
-        int v = (int)(i0 / width), u = (int)(i0 - (size_t)v * width);
-#pragma unroll
-        for (int k = 0; k < DB_PX; ++k) {
-            if ((valid >> k) & 1u) {
-                st[3 * pos] = ((float)u - cx) * z[k] / fx;     // pipeline.cpp:73
-                st[3 * pos + 1] = ((float)v - cy) * z[k] / fy; // pipeline.cpp:74
-                st[3 * pos + 2] = z[k];
-                ++pos;
-            }
-            if (++u == width) { u = 0; ++v; }
-        }
+    const uint16_t* __restrict__ raw = raw0 + frame * n;
+    if (i0 < n) {                                                     // n is a multiple of 16: 32 B per lane, whole or not at all
+        *reinterpret_cast<uint4*>(&zraw[wave][lane * DB_PX]) = *reinterpret_cast<const uint4*>(raw + i0);
+        *reinterpret_cast<uint4*>(&zraw[wave][lane * DB_PX + 8]) = *reinterpret_cast<const uint4*>(raw + i0 + 8);
     }
-    __builtin_amdgcn_wave_barrier();   // one wave writes and reads its own stage (LDS ops of a wave complete in order): no workgroup barrier
-    flush(xyz);
-    if (rgb && bgr0) {
-        const uint8_t* __restrict__ bgr = bgr0 + frame * n * 3;
-        __builtin_amdgcn_wave_barrier();
-        pos = incl - c;
-        if (valid) {
-#pragma unroll
-            for (int k = 0; k < DB_PX; ++k) {
-                if ((valid >> k) & 1u) {
-                    const uint8_t* p = bgr + (i0 + k) * 3;
-                    st[3 * pos] = (float)p[2] / 255.0f; st[3 * pos + 1] = (float)p[1] / 255.0f; st[3 * pos + 2] = (float)p[0] / 255.0f;
-                    ++pos;
-                }
+    __builtin_amdgcn_wave_barrier();                                  // a wave reads back only what it staged itself
+    size_t slot0 = (size_t)offsets[(size_t)b * ntiles + tile];        // output slot of the tile's first valid pixel
+    const uint8_t* __restrict__ bgr = (rgb && bgr0) ? bgr0 + frame * n * 3 : nullptr;
+#pragma unroll 1
+    for (int j = 0; j < DB_PX; ++j) {                                 // round j: pixels t0 + 64 j .. + 63
+        const unsigned long long m = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j)
+                                   | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 1) << 16)
+                                   | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 2) << 32)
+                                   | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 3) << 48);
+        if (!m) continue;                                             // wave-uniform
+        if ((m >> lane) & 1ull) {
+            const size_t i = t0 + 64 * (size_t)j + lane;
+            const float z = (float)zraw[wave][64 * j + lane] * inv_scale;   // pipeline.cpp:47
+            const int v = (int)(i / width), u = (int)(i - (size_t)v * width);
+            const size_t slot = slot0 + __popcll(m & ((1ull << lane) - 1ull));
+            xyz[3 * slot] = ((float)u - cx) * z / fx;                  // pipeline.cpp:73
+            xyz[3 * slot + 1] = ((float)v - cy) * z / fy;              // pipeline.cpp:74
+            xyz[3 * slot + 2] = z;
+            if (bgr) {
+                const uint8_t* p = bgr + i * 3;
+                rgb[3 * slot] = (float)p[2] / 255.0f; rgb[3 * slot + 1] = (float)p[1] / 255.0f; rgb[3 * slot + 2] = (float)p[0] / 255.0f;
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        flush(rgb);
+        slot0 += __popcll(m);
     }
 }
 
@@ -498,8 +498,11 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d
         else k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
     }
     TDV_CHECK_LAUNCH(ctx);
-    TDV_TRY(exclusive_scan_dev(ctx, counts, blocks * n_inst, offsets, d_total));
-    k_gather_instance_offsets<<<(n_inst + 256) / 256, 256, 0, s>>>(offsets, d_total, blocks, n_inst, d_inst);
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_DEPTH);   // the scan belongs to the operator's kernel time
+        TDV_TRY(exclusive_scan_dev(ctx, counts, blocks * n_inst, offsets, d_total));
+        k_gather_instance_offsets<<<(n_inst + 256) / 256, 256, 0, s>>>(offsets, d_total, blocks, n_inst, d_inst);
+    }
     TDV_CHECK_LAUNCH(ctx);
     TDV_TRY(pin_reserve(ctx, ((size_t)n_inst + 1) * 4));
     TDV_HIP(ctx, hipMemcpyAsync(ctx->pin, d_inst, ((size_t)n_inst + 1) * 4, hipMemcpyDeviceToHost, s));

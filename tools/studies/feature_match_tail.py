@@ -84,3 +84,23 @@ for m in (3, 4, 6):
         need3.append((lb2 <= best[:, None] * (1 + 1e-6) + 1e-12).sum(1))
     need3 = np.concatenate(need3)
     print("PCA-%d box alone: mean %.1f  median %d  p90 %d  p99 %d  max %d" % (m, need3.mean(), np.median(need3), *np.percentile(need3, [90, 99]).astype(int), need3.max()))
+
+# ---- a full 33-D box in the ROTATED (principal) frame, alone and beside the axis-aligned one
+Q = V
+Pp = ((Tp.astype(np.float64) - mu) @ Q).reshape(nbox, 64, 33)
+pmin = Pp.min(1); pmax = Pp.max(1)
+needr, needb = [], []
+for i0 in range(0, len(sel), 250):
+    q = fs[sel[i0:i0 + 250]].astype(np.float64)
+    d2 = np.maximum((q * q).sum(1)[:, None] + tn[None] - 2 * q @ Td.T, 0)
+    best = d2.min(1)
+    gap = np.maximum(np.maximum(bmin[None] - q[:, None, :], q[:, None, :] - bmax[None]), 0)
+    lb = (gap ** 2).sum(-1)
+    pq = (q - mu) @ Q
+    pg = np.maximum(np.maximum(pmin[None] - pq[:, None, :], pq[:, None, :] - pmax[None]) - 4e-5, 0)
+    lb2 = (pg ** 2).sum(-1) * (1 - 1e-5)
+    needr.append((lb2 <= best[:, None] * (1 + 1e-6) + 1e-12).sum(1))
+    needb.append((np.maximum(lb, lb2) <= best[:, None] * (1 + 1e-6) + 1e-12).sum(1))
+needr = np.concatenate(needr); needb = np.concatenate(needb)
+print("rotated 33-D box alone: mean %.1f median %d p90 %d p99 %d max %d" % (needr.mean(), np.median(needr), *np.percentile(needr, [90, 99]).astype(int), needr.max()))
+print("rotated 33-D + axis-aligned: mean %.1f median %d p90 %d p99 %d max %d" % (needb.mean(), np.median(needb), *np.percentile(needb, [90, 99]).astype(int), needb.max()))
