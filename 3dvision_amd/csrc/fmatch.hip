@@ -639,7 +639,8 @@ struct FmWave {
     const FmTables& t;
     const int lane;
     int src[K];
-    float lbest[K]; int lbj[K]; float bound[K];
+    unsigned long long lkey[K];   // this lane's best (distance bits : original index): unsigned order == (distance, index) order for distances >= 0
+    float bound[K];
     float pmargin;
     int home, hg;
     int* s_bound;                 // SHARED only
@@ -649,7 +650,7 @@ struct FmWave {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             src[k] = __builtin_amdgcn_readfirstlane(t.sperm[min(s0 + k, t.ns - 1)]);   // past the end: the last source again
-            lbest[k] = FLT_MAX; lbj[k] = INT_MAX; bound[k] = FLT_MAX;                  // registration.cpp:218-219
+            lkey[k] = (unsigned long long)__float_as_uint(FLT_MAX) << 32; bound[k] = FLT_MAX;   // registration.cpp:218-219: only dist < FLT_MAX is ever taken
         }
         home = min(t.nleaf - 1, max(0, __builtin_amdgcn_readfirstlane(t.home_of[src[K / 2]])));
         hg = home / FX_GROUP;
@@ -675,16 +676,23 @@ struct FmWave {
             float dist = 0.f;
 #pragma unroll
             for (int d = 0; d < FD; ++d) { const float diff = q[d] - row[d]; dist += diff * diff; }   // registration.cpp:222-224
-            const bool take = dist < lbest[k] || (dist == lbest[k] && ro < lbj[k] && lbest[k] < FLT_MAX);
-            lbest[k] = take ? dist : lbest[k];
-            lbj[k] = take ? ro : lbj[k];
-            const float m = wave_min_f32(lbest[k]);
+            // strict < on (distance, index): the lowest index among equal distances; NaN and +inf have larger bit patterns than
+            // FLT_MAX and are never taken, like `dist < best_dist` in the reference
+            const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)ro;
+            lkey[k] = key < lkey[k] ? key : lkey[k];
+        }
+        ++n_open;
+    }
+    // the sources' bounds = wave minimum of the lanes' best distances; needed only where boxes are tested
+    __device__ __forceinline__ void update_bounds() {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float m = wave_min_f32(__uint_as_float((unsigned)(lkey[k] >> 32)));
             if (m < bound[k]) {
                 bound[k] = m;
                 if (SHARED && lane == 0) atomicMin(&s_bound[k], __float_as_int(m));
             }
         }
-        ++n_open;
     }
     __device__ __forceinline__ void open_leaf(int leaf) {
         float row[FD]; int ro;
@@ -700,7 +708,8 @@ struct FmWave {
     // real gap to any row by at most 2.5e-5 M; pmargin = 3e-5 M is subtracted.  (iii) fl(dist) >= |q - t|^2 (1 - 36 u).
     // pscale = 1 - 1e-4 covers (i), (iii) and the rounding of the three squares with a factor 30 to spare.  Non-finite
     // input makes M = +inf: gaps clamp to 0 and only the 33-D test decides.
-    __device__ __forceinline__ unsigned long long box_mask(const float* __restrict__ blk, const float* __restrict__ pblk) {
+    __device__ __forceinline__ unsigned long long box_mask(const float* __restrict__ blk, const float* __restrict__ pblk, bool own_bounds = true) {
+        if (own_bounds) update_bounds();      // (pass B tests the group boxes with bounds every wave shares: see there)
         float lbp[K]; bool pa[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) lbp[k] = 0.f;
@@ -742,9 +751,9 @@ struct FmWave {
         if (g == hg) m &= ~(1ull << (home - g * FX_GROUP));
         return m;
     }
-    __device__ __forceinline__ unsigned long long group_mask(int c) {
+    __device__ __forceinline__ unsigned long long group_mask(int c, bool own_bounds = true) {
         ++n_group_tests;
-        unsigned long long m = box_mask(t.gbox + (size_t)c * (2 * FD * 64), t.gpbox + (size_t)c * (2 * PD * 64));
+        unsigned long long m = box_mask(t.gbox + (size_t)c * (2 * FD * 64), t.gpbox + (size_t)c * (2 * PD * 64), own_bounds);
         if (hg >= 0 && hg / 64 == c) m &= ~(1ull << (hg % 64));
         return m;
     }
@@ -784,13 +793,15 @@ struct FmWave {
     }
     // lowest (distance, original index) of source k over the lanes
     __device__ __forceinline__ void result(int k, float& bd, int& bo) const {
-        bd = lbest[k]; bo = lbj[k];
+        unsigned hi = (unsigned)(lkey[k] >> 32), lo = (unsigned)lkey[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float od = __shfl_xor(bd, off, 64); const int oo = __shfl_xor(bo, off, 64);
-            const bool tk = od < bd || (od == bd && oo < bo);
-            bd = tk ? od : bd; bo = tk ? oo : bo;
+            const unsigned oh = __shfl_xor(hi, off, 64), ol = __shfl_xor(lo, off, 64);
+            const bool tk = oh < hi || (oh == hi && ol < lo);
+            hi = tk ? oh : hi; lo = tk ? ol : lo;
         }
+        bd = __uint_as_float(hi);
+        bo = hi == __float_as_uint(FLT_MAX) ? INT_MAX : (int)lo;      // nothing below FLT_MAX was seen
     }
 };
 
@@ -894,7 +905,7 @@ void k_fm_query_overflow(FmTables t, const int* __restrict__ overflow_count, con
             for (int k = 0; k < K; ++k) keep[k] = w.bound[k];
 #pragma unroll
             for (int k = 0; k < K; ++k) w.bound[k] = __int_as_float(__float_as_int(part_d[w.src[k]]));   // the bound every wave shares
-            unsigned long long m = w.group_mask(c);
+            unsigned long long m = w.group_mask(c, false);
 #pragma unroll
             for (int k = 0; k < K; ++k) w.bound[k] = keep[k];
             const int g0 = c * 64;
