@@ -3,6 +3,7 @@
 // intermediate (cloud, voxels, normals, FPFH, correspondences) stays in the ctx workspace; per instance
 // the host only reads three scalars (point count, voxel count, results).  SURVEY.md 8f N1.
 #include "tdv_internal.hpp"
+#include <algorithm>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -79,43 +80,54 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         ws_rewind(c, mark);
         return TDV_OK;
     };
-    // Two lanes (the calling thread on ctx, one helper thread on ctx->helper: its own stream and workspace) take
-    // alternate instances, so that one lane's host syncs and small kernels overlap the other's work — the shape of
-    // the reference's thread pool (src/pipeline.cpp:321-327), inside one call.  Results do not depend on the lanes.
-    static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 2;
-    const bool two = lanes_env >= 2 && n_instances >= 2;
-    if (two && !ctx->helper) {
-        if (tdv_ctx_create(ctx->device, &ctx->helper) != TDV_OK) ctx->helper = nullptr;
+    // Lanes: the calling thread on ctx plus helper threads, each on its own helper ctx (stream + workspace, owned by ctx and
+    // chained through ->helper), take the instances in turn, so that one lane's host syncs, its host replay of the voxel
+    // order and its small kernels overlap the others' work — the shape of the reference's thread pool
+    // (src/pipeline.cpp:321-327), inside one call.  Results do not depend on the lanes.  Measured on C4 (96 instances,
+    // instances/s): the reference's voxel order, whose container replay is 3 ms of host time per instance, 1 / 2 / 3 / 4 / 6
+    // lanes: 125 / 184 / 211 / 226 / 252; first-occurrence order 2 / 3 / 4 lanes: 265 / 275 / 260.  Hence 6 resp. 3 lanes by
+    // default; TDV_BATCH_LANES overrides (1 = the caller's thread only).
+    static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;
+    const int lanes_default = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 6 : 3;
+    const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 8), n_instances));
+    std::vector<tdv_ctx*> lane_ctx{ctx};
+    for (tdv_ctx* c = ctx; (int)lane_ctx.size() < want; c = c->helper) {
+        if (!c->helper && tdv_ctx_create(ctx->device, &c->helper) != TDV_OK) { c->helper = nullptr; break; }
+        lane_ctx.push_back(c->helper);
     }
-    if (!two || !ctx->helper) {
+    const int L = (int)lane_ctx.size();
+    if (L == 1) {
         for (int b = 0; b < n_instances; ++b) TDV_TRY(run_instance(ctx, b));
         return TDV_OK;
     }
-    tdv_ctx* h = ctx->helper;
-    h->timing = ctx->timing; h->icp_search = ctx->icp_search; h->err[0] = 0;
-    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the clouds are complete before the other stream reads them
-    int st_helper = TDV_OK;
-    std::thread worker([&]() {
-        try {
-            if (hipSetDevice(h->device) != hipSuccess) { st_helper = TDV_ERR_NO_DEVICE; return; }
-            st_helper = ws_reset(h);
-            for (int b = 1; b < n_instances && st_helper == TDV_OK; b += 2) st_helper = run_instance(h, b);
-            if (st_helper == TDV_OK && hipStreamSynchronize(h->stream) != hipSuccess) st_helper = TDV_ERR_LAUNCH;
-        } catch (...) {   // nothing may escape a thread
-            std::snprintf(h->err, sizeof(h->err), "exception in the helper lane");
-            st_helper = TDV_ERR_INTERNAL;
-        }
-    });
-    int st_main = TDV_OK;
-    try {
-        for (int b = 0; b < n_instances && st_main == TDV_OK; b += 2) st_main = run_instance(ctx, b);
-    } catch (...) {   // the worker must be joined whatever happens here
-        std::snprintf(ctx->err, sizeof(ctx->err), "exception in the batch lane");
-        st_main = TDV_ERR_INTERNAL;
+    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the clouds and the model's index are complete before other streams read them
+    std::vector<int> status((size_t)L, TDV_OK);
+    std::vector<std::thread> workers;
+    for (int l = 1; l < L; ++l) {
+        tdv_ctx* h = lane_ctx[l];
+        h->timing = ctx->timing; h->icp_search = ctx->icp_search; h->err[0] = 0;
+        workers.emplace_back([&, h, l]() {
+            try {
+                if (hipSetDevice(h->device) != hipSuccess) { status[l] = TDV_ERR_NO_DEVICE; return; }
+                status[l] = ws_reset(h);
+                for (int b = l; b < n_instances && status[l] == TDV_OK; b += L) status[l] = run_instance(h, b);
+                if (status[l] == TDV_OK && hipStreamSynchronize(h->stream) != hipSuccess) status[l] = TDV_ERR_LAUNCH;
+            } catch (...) {   // nothing may escape a thread
+                std::snprintf(h->err, sizeof(h->err), "exception in a helper lane");
+                status[l] = TDV_ERR_INTERNAL;
+            }
+        });
     }
-    worker.join();
-    if (st_main != TDV_OK) return st_main;
-    if (st_helper != TDV_OK) { std::snprintf(ctx->err, sizeof(ctx->err), "batch lane 2: %s", h->err); return st_helper; }
+    try {
+        for (int b = 0; b < n_instances && status[0] == TDV_OK; b += L) status[0] = run_instance(ctx, b);
+    } catch (...) {   // the workers must be joined whatever happens here
+        std::snprintf(ctx->err, sizeof(ctx->err), "exception in the batch lane");
+        status[0] = TDV_ERR_INTERNAL;
+    }
+    for (auto& w : workers) w.join();
+    if (status[0] != TDV_OK) return status[0];
+    for (int l = 1; l < L; ++l)
+        if (status[l] != TDV_OK) { std::snprintf(ctx->err, sizeof(ctx->err), "batch lane %d: %s", l + 1, lane_ctx[l]->err); return status[l]; }
     return TDV_OK;
 }
 

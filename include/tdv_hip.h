@@ -249,7 +249,9 @@ int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rg
  * on the order of the downsampled cloud; TDV_VOXEL_ORDER_FIRST skips the host replay of the reference's container
  * (16 B per voxel over PCIe + ~15 ns per voxel of host time) and yields a different, equally valid, coarse pose.
  * The RANSAC index stream is seeded per instance exactly as the reference does (mt19937(42) restarted for every
- * ransacRegistration call).  Frames: as tdv_depth_to_cloud_batch_dev (n_frames, frame_of_instance). */
+ * ransacRegistration call).  Frames: as tdv_depth_to_cloud_batch_dev (n_frames, frame_of_instance).
+ * The call spreads the instances over several lanes (the caller's thread plus helper threads, each with its own stream
+ * and workspace owned by the ctx): 6 in the reference's voxel order, 3 otherwise; TDV_BATCH_LANES=n overrides. */
 typedef struct tdv_batch_params {
     int width, height;
     float scale_to_meters;      /* depth.scale_to_meters      (include/pipeline_config.hpp:18) */
