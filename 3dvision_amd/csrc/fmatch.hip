@@ -1151,8 +1151,8 @@ static int launch_fm_query(tdv_ctx* ctx, const FmTables& t, const FmIndex& ix, i
         const int n_list = n_scan * K;
         const int ns_pad = (int)align_up((size_t)t.ns, FM_SRC_PER_BLOCK);
         const int blocks_x = (n_list + FM_SRC_PER_BLOCK - 1) / FM_SRC_PER_BLOCK;
-        const int want = (4096 + blocks_x - 1) / blocks_x;
-        int nsplit = std::max(1, std::min(std::min(want, std::max(1, ix.nt / 256)), 64));
+        const int want = (6144 + blocks_x - 1) / blocks_x;
+        int nsplit = std::max(1, std::min(std::min(want, std::max(1, ix.nt / 128)), 256));   // few sources: many target splits, or the chip stays empty
         const int per_split = (ix.nt + nsplit - 1) / nsplit;
         nsplit = (ix.nt + per_split - 1) / per_split;
         float* pd; int* pj;
