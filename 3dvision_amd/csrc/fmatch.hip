@@ -409,12 +409,15 @@ void k_fm_moments(const float* __restrict__ f, int n, int rows_per_block, double
     }
     if (t < FX_NMOM) partial[(size_t)blockIdx.x * FX_NMOM + t] = acc;
 }
-__global__ void k_fm_moments_fold(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= FX_NMOM) return;
+// one wave per moment: the workgroups' partial sums in a fixed order (lane l takes blocks l, l + 64, ...; then a fixed tree)
+__global__ __launch_bounds__(64)
+void k_fm_moments_fold(const double* __restrict__ partial, int nblocks, double* __restrict__ out) {
+    const int t = blockIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * FX_NMOM + t];
-    out[t] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[(size_t)b * FX_NMOM + t];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) out[t] = s;
 }
 
 // Principal coordinates p_r(x) = sum_d (x_d - mean_d) * b_r[d], r = 0..2, as evaluated HERE (plain f32, d ascending):
@@ -993,7 +996,7 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     TDV_TRY(ws_alloc(ctx, (size_t)mblocks * FX_NMOM, &partial));
     TDV_TRY(ws_alloc(ctx, (size_t)FX_NMOM, &mom));
     k_fm_moments<<<mblocks, FX_MOM_BLOCK, 0, s>>>(d_ft, nt, rows_per_block, partial);
-    k_fm_moments_fold<<<(FX_NMOM + 255) / 256, 256, 0, s>>>(partial, mblocks, mom);
+    k_fm_moments_fold<<<FX_NMOM, 64, 0, s>>>(partial, mblocks, mom);
     TDV_CHECK_LAUNCH(ctx);
     TDV_TRY(pin_reserve(ctx, 64 * 1024));
     double* h_mom = reinterpret_cast<double*>(ctx->pin);
