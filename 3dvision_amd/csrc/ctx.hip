@@ -188,6 +188,10 @@ int tdv_ctx_create(int device, tdv_ctx** out) {
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TDV_ERR_NO_DEVICE; }
     c->own_stream = true;
+    // one persistent device word: the "last workgroup" ticket of the scans (reset by the kernel that uses it)
+    if (hipMalloc((void**)&c->scan_ticket, 64) != hipSuccess || hipMemset(c->scan_ticket, 0, 64) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream); delete c; return TDV_ERR_OOM;
+    }
     if (const char* e = getenv("TDV_ICP_SEARCH")) {
         if (!strcmp(e, "brute")) c->icp_search = TDV_ICP_SEARCH_BRUTE;
         else if (!strcmp(e, "pruned")) c->icp_search = TDV_ICP_SEARCH_PRUNED;
@@ -223,6 +227,7 @@ void tdv_ctx_destroy(tdv_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->blocks) (void)hipFree(b.p);
+    if (ctx->scan_ticket) (void)hipFree(ctx->scan_ticket);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& t : ctx->timers) for (auto& p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);

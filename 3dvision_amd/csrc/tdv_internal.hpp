@@ -33,6 +33,7 @@ struct tdv_ctx {
     char err[512] = {0};
     bool timing = false;
     int icp_search = 0;      // TDV_ICP_SEARCH_AUTO / _BRUTE / _PRUNED (tdv_ctx_set_icp_search)
+    unsigned* scan_ticket = nullptr;  // persistent device word of exclusive_scan_dev (last-workgroup ticket)
     uint16_t* depth_bits = nullptr;   // validity bitmap between the two passes of the batched depth -> cloud (workspace memory of the current call)
     tdv_ctx* helper = nullptr;   // second stream + workspace of the batched pipeline's other lane (owned; created on first use)
     tdv::TimerSlot timers[TDV_TIMER_COUNT];

@@ -125,7 +125,7 @@ int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2) {
 // Members of a voxel only have to become one run in ascending input index; the order of the runs is irrelevant
 // (positions come from the leader scan).  So: bucket = hash(cell) into >= 2n buckets (counting sort, integer atomics),
 // then every bucket — a handful of records, possibly of several colliding cells — is insertion-sorted by
-// (cell, index) by one lane.  A bucket larger than VX_MAX_BUCKET (a very coarse grid) raises a flag and the call is
+// (cell, index) by one lane, which also emits the bucket's voxels (k_voxel_bucket_emit).  A bucket larger than VX_MAX_BUCKET (a very coarse grid) raises a flag and the call is
 // redone with the full sort.
 constexpr int VX_MAX_BUCKET = 96;
 __device__ __forceinline__ unsigned voxel_hash(unsigned x, unsigned y, unsigned z) {
@@ -152,12 +152,18 @@ __global__ void k_voxel_scatter(const uint4* __restrict__ rec_in, int n, unsigne
     const unsigned b = voxel_hash(r.x, r.y, r.z) & mask;
     rec[start[b] + atomicAdd(&cursor[b], 1)] = r;
 }
-__global__ void k_voxel_bucket_sort(uint4* __restrict__ rec, const int* __restrict__ start, const int* __restrict__ hist, int nbuckets,
-                                    int* __restrict__ too_big) {
+// The hashed path's third kernel: every lane owns one bucket.  It sorts the bucket's few records by (cell, index); the
+// members of a voxel then form a run INSIDE the bucket (a cell hashes to one bucket), so the same lane marks the run's
+// leader (its smallest input index), sums the members in ascending index order and parks the mean at the leader's index.
+// One launch instead of bucket sort + heads + means; the slot of a mean (its first-occurrence rank) comes from the scan of
+// the leader flags, after which k_voxel_compact moves it there.
+__global__ void k_voxel_bucket_emit(uint4* __restrict__ rec, const int* __restrict__ start, const int* __restrict__ hist, int nbuckets,
+                                    int* __restrict__ too_big, const float* __restrict__ xyz, const float* __restrict__ rgb,
+                                    int* __restrict__ leader, float* __restrict__ mean_xyz, float* __restrict__ mean_rgb) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
     const int m = hist[b];
-    if (m <= 1) return;
+    if (m == 0) return;
     if (m > VX_MAX_BUCKET) { *too_big = 1; return; }
     uint4* a = rec + start[b];
     for (int e = 1; e < m; ++e) {   // insertion sort by (x, y, z, index)
@@ -166,6 +172,34 @@ __global__ void k_voxel_bucket_sort(uint4* __restrict__ rec, const int* __restri
         while (f >= 0 && rec_less(key, a[f])) { a[f + 1] = a[f]; --f; }
         a[f + 1] = key;
     }
+    for (int e = 0; e < m;) {
+        const uint4 r = a[e];
+        float ax = 0.f, ay = 0.f, az = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        int cnt = 0;
+        for (; e < m; ++e) {
+            const uint4 q = a[e];
+            if (!(q.x == r.x && q.y == r.y && q.z == r.z)) break;
+            const size_t idx = q.w;
+            ax += xyz[3 * idx]; ay += xyz[3 * idx + 1]; az += xyz[3 * idx + 2];        // registration.cpp:47-50, ascending input index
+            if (rgb) { cr += rgb[3 * idx]; cg += rgb[3 * idx + 1]; cb += rgb[3 * idx + 2]; }
+            ++cnt;
+        }
+        const float fn = (float)cnt;
+        const size_t l = r.w;
+        leader[l] = 1;
+        mean_xyz[3 * l] = ax / fn; mean_xyz[3 * l + 1] = ay / fn; mean_xyz[3 * l + 2] = az / fn;   // :52-53
+        if (rgb && mean_rgb) { mean_rgb[3 * l] = cr / fn; mean_rgb[3 * l + 1] = cg / fn; mean_rgb[3 * l + 2] = cb / fn; }
+    }
+}
+// out[rank[i]] = mean parked at leader i
+__global__ void k_voxel_compact(const int* __restrict__ leader, const int* __restrict__ rank, int n, const float* __restrict__ mean_xyz,
+                                const float* __restrict__ mean_rgb, int capacity, float* __restrict__ out_xyz, float* __restrict__ out_rgb) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !leader[i]) return;
+    const int slot = rank[i];
+    if (slot >= capacity) return;
+    out_xyz[3 * (size_t)slot] = mean_xyz[3 * (size_t)i]; out_xyz[3 * (size_t)slot + 1] = mean_xyz[3 * (size_t)i + 1]; out_xyz[3 * (size_t)slot + 2] = mean_xyz[3 * (size_t)i + 2];
+    if (mean_rgb && out_rgb) { out_rgb[3 * (size_t)slot] = mean_rgb[3 * (size_t)i]; out_rgb[3 * (size_t)slot + 1] = mean_rgb[3 * (size_t)i + 1]; out_rgb[3 * (size_t)slot + 2] = mean_rgb[3 * (size_t)i + 2]; }
 }
 
 // leader[idx] = 1 for the smallest input index of each voxel
@@ -188,42 +222,51 @@ __global__ void k_voxel_leader_list(const int* __restrict__ leader, const int* _
                                      (int)floorf(xyz[3 * (size_t)i + 2] * inv), i);
 }
 
-// exclusive scan of n ints: per-block (1024) reduce, single-block scan of the sums, local scan
+// exclusive scan of n ints in TWO launches: per-block (1024) reduce whose LAST workgroup (atomic ticket) scans the block
+// sums, then the local scan.  (Round 1 used three launches; the scan sits on every grouping path — voxel x2, Morton
+// order, descriptor buckets, batched depth — and each launch costs ~5 us on a path that is launch-bound anyway.)
 __global__ __launch_bounds__(1024)
-void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums) {
+void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums, int* __restrict__ total, unsigned* __restrict__ ticket) {
     __shared__ int w[16];
+    __shared__ int carry_s;
+    __shared__ bool is_last;
     int i = blockIdx.x * 1024 + threadIdx.x;
     int v = i < n ? in[i] : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) { int s = 0; for (int k = 0; k < 16; ++k) s += w[k]; sums[blockIdx.x] = s; }
-}
-__global__ __launch_bounds__(1024)
-void k_scan_sums(int* __restrict__ sums, int nblocks, int* __restrict__ total) {
-    __shared__ int wsum[16];
-    __shared__ int carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int k = 0; k < 16; ++k) s += w[k];
+        sums[blockIdx.x] = s;
+        __threadfence();                                        // the sum is visible device-wide before the ticket moves
+        is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        carry_s = 0;
+    }
     __syncthreads();
+    if (!is_last) return;
+    __threadfence();                                            // acquire: the other workgroups' sums
+    const int nblocks = gridDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    volatile int* vs = sums;                                    // written by other workgroups of this launch
     for (int b0 = 0; b0 < nblocks; b0 += 1024) {
-        int i = b0 + threadIdx.x;
-        int v = i < nblocks ? sums[i] : 0;
-        int incl = v;
+        int k = b0 + threadIdx.x;
+        int x = k < nblocks ? vs[k] : 0;
+        int incl = x;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
-        if (lane == 63) wsum[wave] = incl;
+        if (lane == 63) w[wave] = incl;
         __syncthreads();
         int wbase = 0;
-        for (int w = 0; w < wave; ++w) wbase += wsum[w];
+        for (int q = 0; q < wave; ++q) wbase += w[q];
         int carry = carry_s;
-        if (i < nblocks) sums[i] = carry + wbase + incl - v;
+        if (k < nblocks) vs[k] = carry + wbase + incl - x;
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry_s;
+    if (threadIdx.x == 0) { *total = carry_s; *ticket = 0u; }   // ready for the next launch (stream order)
 }
 __global__ __launch_bounds__(1024)
 void k_scan_local(const int* __restrict__ in, int n, const int* __restrict__ sums, int* __restrict__ out) {
@@ -352,8 +395,7 @@ int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_
     int* sums;
     TDV_TRY(ws_alloc(ctx, (size_t)sblocks, &sums));
     hipStream_t s = ctx->stream;
-    k_scan_reduce<<<sblocks, 1024, 0, s>>>(d_in, n, sums);
-    k_scan_sums<<<1, 1024, 0, s>>>(sums, sblocks, d_total);
+    k_scan_reduce<<<sblocks, 1024, 0, s>>>(d_in, n, sums, d_total, ctx->scan_ticket);
     k_scan_local<<<sblocks, 1024, 0, s>>>(d_in, n, sums, d_out);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
@@ -381,7 +423,6 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     while (n_pow2 < (size_t)n) n_pow2 <<= 1;
     uint4* rec; int *leader, *rank, *sums, *d_total;
     TDV_TRY(ws_alloc(ctx, n_pow2, &rec));
-    TDV_TRY(ws_alloc(ctx, (size_t)n, &leader));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &rank));
     const int sblocks = (n + 1023) / 1024;
     TDV_TRY(ws_alloc(ctx, (size_t)sblocks, &sums));
@@ -391,31 +432,32 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     static const bool force_sort = getenv("TDV_VOXEL_SORT") != nullptr;   // A/B knob: the full bitonic sort
     bool hashed = !force_sort && !full_sort;
     int* d_too_big = nullptr;
+    float *mean_xyz = nullptr, *mean_rgb = nullptr;     // hashed path: means parked at their leader's input index
     if (hashed) {
+        // 9 launches (round 1: 15): one memset, cell histogram, scan (2), scatter, bucket sort + leaders + means, scan (2), compact
         size_t nb = 4096;
         while (nb < 2 * (size_t)n) nb <<= 1;
-        int *hist, *cursor, *start, *d_tot2; uint4* rec_in;
-        TDV_TRY(ws_alloc(ctx, nb, &hist));
-        TDV_TRY(ws_alloc(ctx, nb, &cursor));
+        int *zeroed, *hist, *cursor, *start, *d_tot2; uint4* rec_in;
+        TDV_TRY(ws_alloc(ctx, 2 * nb + 1 + (size_t)n, &zeroed));        // hist | cursor | too_big | leader: one memset
+        hist = zeroed; cursor = zeroed + nb; d_too_big = zeroed + 2 * nb; leader = zeroed + 2 * nb + 1;
         TDV_TRY(ws_alloc(ctx, nb, &start));
         TDV_TRY(ws_alloc(ctx, 1, &d_tot2));
-        TDV_TRY(ws_alloc(ctx, 1, &d_too_big));
         TDV_TRY(ws_alloc(ctx, (size_t)n, &rec_in));
-        TDV_HIP(ctx, hipMemsetAsync(hist, 0, nb * 4, s));
-        TDV_HIP(ctx, hipMemsetAsync(cursor, 0, nb * 4, s));
-        TDV_HIP(ctx, hipMemsetAsync(d_too_big, 0, 4, s));
+        TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &mean_xyz));
+        if (d_rgb && d_out_rgb) TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &mean_rgb));
+        TDV_HIP(ctx, hipMemsetAsync(zeroed, 0, (2 * nb + 1 + (size_t)n) * 4, s));
         k_voxel_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, inv, (unsigned)(nb - 1), rec_in, hist);
         TDV_TRY(exclusive_scan_dev(ctx, hist, (int)nb, start, d_tot2));
         k_voxel_scatter<<<(n + 255) / 256, 256, 0, s>>>(rec_in, n, (unsigned)(nb - 1), start, cursor, rec);
-        k_voxel_bucket_sort<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(rec, start, hist, (int)nb, d_too_big);
+        k_voxel_bucket_emit<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(rec, start, hist, (int)nb, d_too_big, d_xyz, mean_rgb ? d_rgb : nullptr, leader, mean_xyz, mean_rgb);
     } else {
+        TDV_TRY(ws_alloc(ctx, (size_t)n, &leader));
         k_voxel_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, inv, rec);
         TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
+        TDV_HIP(ctx, hipMemsetAsync(leader, 0, (size_t)n * 4, s));
+        k_voxel_heads<<<(n + 255) / 256, 256, 0, s>>>(rec, n, leader);
     }
-    TDV_HIP(ctx, hipMemsetAsync(leader, 0, (size_t)n * 4, s));
-    k_voxel_heads<<<(n + 255) / 256, 256, 0, s>>>(rec, n, leader);
-    k_scan_reduce<<<sblocks, 1024, 0, s>>>(leader, n, sums);
-    k_scan_sums<<<1, 1024, 0, s>>>(sums, sblocks, d_total);
+    k_scan_reduce<<<sblocks, 1024, 0, s>>>(leader, n, sums, d_total, ctx->scan_ticket);
     k_scan_local<<<sblocks, 1024, 0, s>>>(leader, n, sums, rank);
     TDV_CHECK_LAUNCH(ctx);
     int* h_total = reinterpret_cast<int*>(ctx->pin);
@@ -429,7 +471,8 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     *n_out = v;
     if (v > capacity) return TDV_ERR_BAD_ARG;
     if (order == TDV_VOXEL_ORDER_FIRST) {
-        k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, capacity, d_out_xyz, d_out_rgb);
+        if (hashed) k_voxel_compact<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, n, mean_xyz, mean_rgb, capacity, d_out_xyz, d_out_rgb);
+        else k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, capacity, d_out_xyz, d_out_rgb);
         TDV_CHECK_LAUNCH(ctx);
         return TDV_OK;
     }
@@ -438,7 +481,8 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_xyz));
     if (d_rgb && d_out_rgb) TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_rgb));
     TDV_TRY(ws_alloc(ctx, (size_t)v, &d_order));
-    k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, v, tmp_xyz, tmp_rgb);
+    if (hashed) k_voxel_compact<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, n, mean_xyz, mean_rgb, v, tmp_xyz, tmp_rgb);
+    else k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, v, tmp_xyz, tmp_rgb);
     TDV_CHECK_LAUNCH(ctx);
     // leaders (first point of every voxel: cell + input index) in input order, from the device; the host only replays those
     int4* d_leaders;
