@@ -445,10 +445,81 @@ __global__ void k_fm_project(const float* __restrict__ f, int n, const float* __
     if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(am));
 }
 
-__global__ void k_fm_rec_p0(const float* __restrict__ p0, int n, int n_pow2, uint4* __restrict__ rec) {
+// Bit-identical target rows (the descriptor of a flat patch: a quarter of the relief model's rows are two such values)
+// give bit-identical distances, and the tie rule hands the match to the lowest index among them: only that row can ever
+// win, so the packed index holds it alone.  Without this every source on such a plateau has to open every leaf holding
+// a copy.  Two levels of open addressing keyed by a hash of the row's bits, rows always compared in full (a hash
+// collision costs a probe, never a row): a workgroup first folds its own 512 rows in LDS - a popular value would
+// otherwise queue tens of thousands of atomics on one L2 address - and only the lowest row of every value it holds
+// goes to the global table.  After the kernel table[slot_of[i]] == i exactly for the lowest row of every distinct value.
+constexpr int FX_DD_ROWS = 512;
+constexpr int FX_DD_SLOTS = 1024;
+__device__ __forceinline__ unsigned row_hash(const float* x) {
+    unsigned h = 0x9e3779b9u;
+#pragma unroll
+    for (int d = 0; d < FD; ++d) { h ^= __float_as_uint(x[d]); h *= 0x85ebca6bu; h ^= h >> 13; }
+    h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__global__ __launch_bounds__(FX_DD_ROWS)
+void k_fm_dedupe_insert(const float* __restrict__ f, int n, int* table, unsigned mask, int* __restrict__ slot_of, int* __restrict__ kept) {
+    __shared__ float tile[FX_DD_ROWS * FD];          // row-major, stride 33 dwords: lanes = consecutive rows hit distinct banks
+    __shared__ int ltab[FX_DD_SLOTS], lres[FX_DD_SLOTS];
+    __shared__ int claimed;
+    const int t = threadIdx.x, base = blockIdx.x * FX_DD_ROWS, m = min(FX_DD_ROWS, n - base);
+    for (int e = t; e < m * FD; e += FX_DD_ROWS) tile[e] = f[(size_t)base * FD + e];
+    for (int e = t; e < FX_DD_SLOTS; e += FX_DD_ROWS) ltab[e] = -1;
+    if (t == 0) claimed = 0;
+    __syncthreads();
+    const float* x = tile + t * FD;
+    unsigned h = 0, ls = 0;
+    if (t < m) {
+        h = row_hash(x);
+        ls = h & (FX_DD_SLOTS - 1);
+        for (;;) {
+            int cur = atomicCAS(&ltab[ls], -1, t);
+            if (cur < 0) break;
+            const float* y = tile + cur * FD;
+            bool same = true;
+#pragma unroll
+            for (int d = 0; d < FD; ++d) same = same && (__float_as_uint(x[d]) == __float_as_uint(y[d]));
+            if (same) { if (t < cur) atomicMin(&ltab[ls], t); break; }
+            ls = (ls + 1) & (FX_DD_SLOTS - 1);       // half full at most: the probe ends
+        }
+    }
+    __syncthreads();
+    bool claim = false;
+    if (t < m && ltab[ls] == t) {                    // lowest row of its value in this workgroup
+        const int i = base + t;
+        unsigned slot = h & mask;
+        for (;;) {
+            // plain load: a stale owner is still a row with the slot's value, a stale "empty" is corrected by the CAS
+            int cur = table[slot];
+            if (cur < 0) { cur = atomicCAS(&table[slot], -1, i); if (cur < 0) { claim = true; break; } }
+            const float* y = f + (size_t)cur * FD;
+            bool same = true;
+#pragma unroll
+            for (int d = 0; d < FD; ++d) same = same && (__float_as_uint(x[d]) == __float_as_uint(y[d]));
+            if (same) { if (i < cur) atomicMin(&table[slot], i); break; }
+            slot = (slot + 1) & mask;
+        }
+        lres[ls] = (int)slot;
+    }
+    // every distinct value claims exactly one empty slot of the global table: the claims count the rows that stay
+    const unsigned long long cm = __ballot(claim);
+    if ((t & 63) == 0 && cm) atomicAdd(&claimed, __popcll(cm));
+    __syncthreads();
+    if (t < m) slot_of[base + t] = lres[ls];
+    if (t == 0 && claimed) atomicAdd(kept, claimed);
+}
+
+// first key: p0 of the rows that stay; the others sort behind every real row together with the padding
+__global__ void k_fm_rec_p0(const float* __restrict__ p0, int n, int n_pow2, const int* __restrict__ table, const int* __restrict__ slot_of,
+                            uint4* __restrict__ rec) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pow2) return;
-    rec[i] = i < n ? make_uint4(sortable_bits(p0[i]), (unsigned)i, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+    const bool keep = i < n && table[slot_of[i]] == i;
+    rec[i] = keep ? make_uint4(sortable_bits(p0[i]), (unsigned)i, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
 }
 // number of entries of the ascending array `starts` (m + 1 entries, starts[0] = 0) that are <= r, minus 1
 __device__ __forceinline__ int segment_of(const int* __restrict__ starts, int m, int r) {
@@ -997,11 +1068,23 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     TDV_TRY(ws_alloc(ctx, (size_t)FX_NMOM, &mom));
     k_fm_moments<<<mblocks, FX_MOM_BLOCK, 0, s>>>(d_ft, nt, rows_per_block, partial);
     k_fm_moments_fold<<<FX_NMOM, 64, 0, s>>>(partial, mblocks, mom);
+    // ... and, for the same round trip, which rows are copies of an earlier row (k_fm_dedupe_insert)
+    const size_t table_size = sort_pow2((size_t)nt) * 2;
+    int *table, *slot_of, *d_kept;
+    TDV_TRY(ws_alloc(ctx, table_size, &table));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &slot_of));
+    TDV_TRY(ws_alloc(ctx, 1, &d_kept));
+    TDV_HIP(ctx, hipMemsetAsync(table, 0xff, table_size * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(d_kept, 0, 4, s));
+    k_fm_dedupe_insert<<<(unsigned)((nt + FX_DD_ROWS - 1) / FX_DD_ROWS), FX_DD_ROWS, 0, s>>>(d_ft, nt, table, (unsigned)(table_size - 1), slot_of, d_kept);
     TDV_CHECK_LAUNCH(ctx);
     TDV_TRY(pin_reserve(ctx, 64 * 1024));
     double* h_mom = reinterpret_cast<double*>(ctx->pin);
     TDV_HIP(ctx, hipMemcpyAsync(h_mom, mom, FX_NMOM * sizeof(double), hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipMemcpyAsync(ctx->pin + 6144, d_kept, 4, hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
+    const int nk = *reinterpret_cast<const int*>(ctx->pin + 6144);   // distinct rows: what the index packs
+    if (nk <= 0 || nk > nt) return TDV_ERR_INTERNAL;
     std::vector<double> C((size_t)FD * FD), mean(FD), evals, evecs;
     bool finite = true;
     for (int d = 0; d < FD; ++d) { mean[d] = h_mom[561 + d] / nt; finite = finite && std::isfinite(mean[d]); }
@@ -1034,7 +1117,7 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
         ix->pscale = (std::sqrt(dev) <= 1e-6) ? (1.0f - 1e-4f) : 0.0f;
     }
     // 2. slab / column counts: S0 * S1 * S2 = number of leaves with S_d proportional to the spread along p_d
-    const double nleaf_t = std::max(1.0, (double)nt / FX_LEAF);
+    const double nleaf_t = std::max(1.0, (double)nk / FX_LEAF);
     const double tiny = 1e-6 * std::max(e0, 1e-30);
     e0 = std::max(e0, tiny); e1 = std::max(e1, tiny); e2 = std::max(e2, tiny);
     double g = std::cbrt(nleaf_t / (e0 * e1 * e2));
@@ -1047,12 +1130,12 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     // equal-count cuts by rank are known without looking at the data
     std::vector<int> h_int((size_t)(S0 + 1) + 3 * ((size_t)ncol + 1));
     int* slab_start = h_int.data(); int* col_start = slab_start + S0 + 1; int* col_row0 = col_start + ncol + 1; int* col_leaf0 = col_row0 + ncol + 1;
-    for (int k = 0; k <= S0; ++k) slab_start[k] = (int)((long long)nt * k / S0);
+    for (int k = 0; k <= S0; ++k) slab_start[k] = (int)((long long)nk * k / S0);
     for (int k = 0; k < S0; ++k) {
         const int c0 = slab_start[k], cnt = slab_start[k + 1] - c0;
         for (int j = 0; j < S1; ++j) col_start[k * S1 + j] = c0 + (int)((long long)cnt * j / S1);
     }
-    col_start[ncol] = nt;
+    col_start[ncol] = nk;
     size_t rows = 0;
     for (int c = 0; c < ncol; ++c) {
         col_row0[c] = (int)rows; col_leaf0[c] = (int)(rows / FX_LEAF);
@@ -1098,14 +1181,15 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     const unsigned gn = (unsigned)((nt + 255) / 256);
     TDV_HIP(ctx, hipMemsetAsync(ix->amax, 0, 4, s));
     k_fm_project<<<gn, 256, 0, s>>>(d_ft, nt, basis, p0, p1, p2, ix->amax);
-    k_fm_rec_p0<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(p0, nt, (int)n_pow2, rec);
+    k_fm_rec_p0<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(p0, nt, (int)n_pow2, table, slot_of, rec);
     TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
-    k_fm_rec_p1<<<gn, 256, 0, s>>>(rec, nt, d_slab_start, S0, p0, p1, ix->b0);
-    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
-    k_fm_rec_p2<<<gn, 256, 0, s>>>(rec, nt, d_col_start, ncol, p1, p2, ix->b1);
-    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
+    const size_t nk_pow2 = sort_pow2((size_t)nk);   // the distinct rows now lead; what follows them up to here is padding
+    k_fm_rec_p1<<<gn, 256, 0, s>>>(rec, nk, d_slab_start, S0, p0, p1, ix->b0);
+    TDV_TRY(sort_records_dev(ctx, rec, nk_pow2));
+    k_fm_rec_p2<<<gn, 256, 0, s>>>(rec, nk, d_col_start, ncol, p1, p2, ix->b1);
+    TDV_TRY(sort_records_dev(ctx, rec, nk_pow2));
     k_fm_fill_rows<<<(unsigned)((rows * FD + 255) / 256), 256, 0, s>>>(ix->T, ix->torig, rows);
-    k_fm_place_rows<<<(unsigned)(((size_t)nt * FD + 255) / 256), 256, 0, s>>>(rec, nt, d_col_start, d_col_row0, ncol, d_ft, p0, p1, p2, ix->T, ix->torig, ix->leaf_p2, prow, rows);
+    k_fm_place_rows<<<(unsigned)(((size_t)nk * FD + 255) / 256), 256, 0, s>>>(rec, nk, d_col_start, d_col_row0, ncol, d_ft, p0, p1, p2, ix->T, ix->torig, ix->leaf_p2, prow, rows);
     k_fm_leaf_boxes<<<(ngroup * FX_GROUP * (FD + PD) + 255) / 256, 256, 0, s>>>(ix->T, ix->torig, prow, rows, nleaf, ngroup, ix->lbox, ix->pbox);
     k_fm_group_boxes<<<(nchunk * 64 * (FD + PD) + 255) / 256, 256, 0, s>>>(ix->lbox, ix->pbox, ngroup, nchunk, ix->gbox, ix->gpbox);
     TDV_CHECK_LAUNCH(ctx);
