@@ -318,12 +318,25 @@ constexpr int DB_TILE = 64 * DB_PX;       // pixels per wave
 constexpr int DB_GROUP = DB_GROUP_VALUE;  // instances per wave in pass 1 (8: the LDS transpose of the bitmap words assumes it)
 static_assert(DB_GROUP == 8, "k_depth_bits stores 8 instances x 64 words as 64 x 16 B");
 
-__device__ __forceinline__ unsigned keep_bits16(const uint4 mv, int mode) {
-    const unsigned mw[4] = {mv.x, mv.y, mv.z, mv.w};
-    unsigned keep = 0;
-#pragma unroll
-    for (int k = 0; k < DB_PX; ++k) keep |= mask_keeps((uint8_t)((mw[k >> 2] >> (8 * (k & 3))) & 0xffu), mode) ? (1u << k) : 0u;
-    return keep;
+// The mask rule on four mask bytes at once (one dword, no per-byte extraction: the byte-by-byte form made pass 1
+// VALU-bound at twice its memory time).  y = w, or w ^ label in every byte for the label rule; low 7 bits + `add` carry
+// into bit 7 exactly when the byte exceeds the threshold (thresholds < 128; bytes >= 128 have bit 7 set themselves);
+// the label rule is the exact zero-byte test of y, i.e. the complement.  Then the four bit-7 flags move to bits 0..3.
+struct MaskRule { unsigned xor4, add4, inv, and4; };
+__device__ __forceinline__ MaskRule mask_rule(int mode) {
+    if (mode == TDV_MASK_THRESHOLD10) return {0u, (127u - 10u) * 0x01010101u, 0u, 0x80808080u};   // m > 10   (pipeline.cpp:51)
+    if (mode == TDV_MASK_NONZERO) return {0u, 127u * 0x01010101u, 0u, 0x80808080u};             // m != 0   (depth_processing.cu:22)
+    const int label = mode - TDV_MASK_LABEL_BASE;                                        // m == label
+    if (label < 0 || label > 255) return {0u, 0u, 0u, 0u};                              // no byte can equal it: keeps nothing
+    return {(unsigned)label * 0x01010101u, 127u * 0x01010101u, 0xffffffffu, 0x80808080u};
+}
+__device__ __forceinline__ unsigned keep_nibble(unsigned w, const MaskRule r) {
+    const unsigned y = w ^ r.xor4;
+    const unsigned f = (((((y & 0x7f7f7f7fu) + r.add4) | y) ^ r.inv) & r.and4) >> 7;   // flags at bits 0, 8, 16, 24
+    return (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xfu;
+}
+__device__ __forceinline__ unsigned keep_bits16(const uint4 mv, const MaskRule r) {
+    return keep_nibble(mv.x, r) | (keep_nibble(mv.y, r) << 4) | (keep_nibble(mv.z, r) << 8) | (keep_nibble(mv.w, r) << 12);
 }
 __device__ __forceinline__ void depth16(const uint16_t* __restrict__ raw, size_t i0, float inv_scale, float (&z)[DB_PX]) {
     const uint4 r0 = *reinterpret_cast<const uint4*>(raw + i0);
@@ -339,52 +352,80 @@ __device__ __forceinline__ unsigned depth_valid16(const float (&z)[DB_PX], float
     return v;
 }
 
+// `0 < z <= zmax` with z = (float)raw * inv_scale (pipeline.cpp:47,71) is a test on the raw value itself: the product is
+// monotone in raw, so the raw values that pass form one range [raw_lo, raw_hi], found on the host with the same float
+// expression (depth_valid_range).  Sixteen pixels: the sign of (raw - lo) | (hi - raw) is shifted into the result, last
+// pixel first.
+__device__ __forceinline__ unsigned range_bits16(const uint4 r0, const uint4 r1, int lo, int hi) {
+    const unsigned rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    unsigned inv = 0u;
+#pragma unroll
+    for (int k = DB_PX - 1; k >= 0; --k) {
+        const int a = (int)((rw[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+        inv = __builtin_amdgcn_alignbit(inv, (unsigned)((a - lo) | (hi - a)), 31);   // inv = inv << 1 | sign
+    }
+    return ~inv & 0xffffu;
+}
+
+// STACKED: one u8 mask per instance (else one label image, label = instance + 1).  PER_FRAME: instances read their own
+// depth frame (frame_of), else all read frame 0 and its validity bits are computed once per wave.  The control flow is
+// uniform: a ragged last group repeats its last instance and only skips the stores.
+template <bool STACKED, bool PER_FRAME>
 __global__ __launch_bounds__(DP_BLOCK)
 void k_depth_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, size_t n, int n_inst,
-                  int stacked, float inv_scale, int mask_mode, float zmax, int ntiles, uint16_t* __restrict__ bits, int* __restrict__ counts) {
+                  int raw_lo, int raw_hi, int mask_mode, int ntiles, uint16_t* __restrict__ bits, int* __restrict__ counts) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (DP_BLOCK / 64) + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
     const size_t i0 = (size_t)tile * DB_TILE + (size_t)lane * DB_PX;
     const bool inside = i0 < n;                       // n is a multiple of 16: a lane is in or out as a whole
-    const int b0 = blockIdx.y * DB_GROUP, b1 = min(n_inst, b0 + DB_GROUP);
-    uint4 mv[DB_GROUP];
+    const size_t il = inside ? i0 : 0;                // lanes past the end load pixel 0 and drop the result
+    const int b0 = blockIdx.y * DB_GROUP, nb = min(DB_GROUP, n_inst - b0);
+    uint4 mv[STACKED ? DB_GROUP : 1];
+    if (STACKED) {
 #pragma unroll
-    for (int u = 0; u < DB_GROUP; ++u) {              // all mask loads of the group in flight at once
-        const int b = b0 + u;
-        mv[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (inside && b < b1 && (stacked || u == 0)) mv[u] = *reinterpret_cast<const uint4*>((stacked ? masks + (size_t)b * n : masks) + i0);
+        for (int u = 0; u < DB_GROUP; ++u)            // all mask loads of the group in flight at once
+            mv[u] = *reinterpret_cast<const uint4*>(masks + (size_t)(b0 + min(u, nb - 1)) * n + il);
+    } else {
+        mv[0] = *reinterpret_cast<const uint4*>(masks + il);
+    }
+    unsigned dvalid = 0u;
+    if (!PER_FRAME) {
+        const uint4 r0 = *reinterpret_cast<const uint4*>(raw0 + il), r1 = *reinterpret_cast<const uint4*>(raw0 + il + 8);
+        dvalid = inside ? range_bits16(r0, r1, raw_lo, raw_hi) : 0u;
     }
     // The 16 validity bits of a lane are 2 bytes: stored lane by lane they would leave as 2-byte stores, the slowest shape
     // there is (per byte an order of magnitude above 16-B stores).  The wave therefore transposes its DB_GROUP x 64 words
     // through 1 KB of LDS and every lane stores 16 B: eight lanes cover one instance's 128-B row segment.
     __shared__ __attribute__((aligned(16))) uint16_t xpose[DP_BLOCK / 64][DB_GROUP][64];
     const int wave = threadIdx.x >> 6;
-    int cur_frame = -1;
-    unsigned dvalid = 0;
+    const MaskRule stacked_rule = mask_rule(mask_mode);
 #pragma unroll
     for (int u = 0; u < DB_GROUP; ++u) {
-        const int b = b0 + u;
-        unsigned v = 0u;
-        if (b < b1) {                                      // wave-uniform
-            const int frame = frame_of ? frame_of[b] : 0;
-            if (frame != cur_frame) {                      // wave-uniform
-                cur_frame = frame;
-                dvalid = 0;
-                if (inside) { float z[DB_PX]; depth16(raw0 + (size_t)frame * n, i0, inv_scale, z); dvalid = depth_valid16(z, zmax); }
-            }
-            const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
-            v = inside ? (keep_bits16(stacked ? mv[u] : mv[0], mode) & dvalid) : 0u;
-            const int c = wave_sum_i32(__popc(v));
-            if (lane == 0) counts[(size_t)b * ntiles + tile] = c;
+        const int b = b0 + min(u, nb - 1);
+        if (PER_FRAME) {
+            const uint16_t* __restrict__ raw = raw0 + (size_t)frame_of[b] * n + il;
+            const uint4 r0 = *reinterpret_cast<const uint4*>(raw), r1 = *reinterpret_cast<const uint4*>(raw + 8);
+            dvalid = inside ? range_bits16(r0, r1, raw_lo, raw_hi) : 0u;
         }
+        // An instance's mask is zero over most of the frame, and a zero byte passes none of the rules (labels start at 1):
+        // a wave whose 1 KB of mask is all zero - most waves - skips the bit arithmetic, which otherwise costs this
+        // pass more than its memory traffic.
+        const uint4 m = mv[STACKED ? u : 0];
+        unsigned v = 0u; int c = 0;
+        if (__any((m.x | m.y | m.z | m.w) != 0u)) {       // wave-uniform
+            const MaskRule r = STACKED ? stacked_rule : mask_rule(TDV_MASK_LABEL_BASE + b + 1);
+            v = keep_bits16(m, r) & dvalid;
+            c = wave_sum_i32(__popc(v));
+        }
+        if (lane == 0 && u < nb) counts[(size_t)b * ntiles + tile] = c;
         xpose[wave][u][lane] = (uint16_t)v;
     }
     __builtin_amdgcn_wave_barrier();                       // a wave reads back only what it wrote itself
     const size_t words = n / DB_PX;                        // bitmap words per instance
     const int u2 = lane >> 3, seg = lane & 7;              // this lane stores words [seg*8, seg*8+8) of instance b0 + u2
     const size_t w0 = (size_t)tile * 64 + (size_t)seg * 8;
-    if (b0 + u2 < b1 && w0 < words) {
+    if (u2 < nb && w0 < words) {
         uint16_t* dst = bits + (size_t)(b0 + u2) * words + w0;
         if (w0 + 8 <= words && (words % 8) == 0) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(&xpose[wave][u2][seg * 8]);
         else for (int k = 0; k < 8 && w0 + k < words; ++k) dst[k] = xpose[wave][u2][seg * 8 + k];
@@ -402,6 +443,32 @@ constexpr int DE_BLOCK = DE_BLOCK_VALUE;
 // consecutive pixels and compacted through LDS: its 48 ds_write_b32 per lane hit 4 of the 64 banks — lane stride 48 dwords
 // — and the pass ran at 3.8 TB/s.)  The round masks come from the bitmap words the lanes hold (4 v_readlane per round);
 // the tile's raw depths are staged once in 2 KB of LDS so that a round reads them lane = pixel.
+// a / d for a wave-uniform d, with the instructions the compiler emits for `a / d` (v_div_scale, v_rcp, two Newton steps on
+// the reciprocal, three on the quotient, v_div_fmas, v_div_fixup) minus what does not depend on a - the reciprocal and its
+// refinement, hoisted out of the loop - and minus the scaling, which is the identity (scale 1, VCC = 0) whenever d is
+// normal, 1/d is normal, |a| >= 2^-102, the exponents of a and d differ by less than 96 and a / d is normal
+// (V_DIV_SCALE_F32 in the CDNA ISA).  emit_fast_div_ok checks on the host that the call's camera parameters keep every
+// pixel inside those conditions; otherwise the kernel divides the plain way.  Same quotient bit for bit: 6 instructions
+// instead of 11 per division, and the pass is bound by instruction issue.
+__device__ __forceinline__ float refined_rcp(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float div_by_uniform(float a, float d, float r) {
+    const float q0 = a * r;
+    const float q1 = fmaf(fmaf(-d, q0, a), r, q0);
+    const float q2 = fmaf(fmaf(-d, q1, a), r, q1);
+    return __builtin_amdgcn_div_fixupf(q2, d, a);
+}
+#ifndef DE_TPW_VALUE
+#define DE_TPW_VALUE 4
+#endif
+constexpr int DE_TPW = DE_TPW_VALUE;   // tiles per wave
+// Four of five tiles of an instance hold no valid pixel.  With one tile per wave the pass was bound by the rate at which
+// workgroups can be launched (151k waves, most of them gone after one load; 19 % of the wave slots occupied — SQ counters
+// in profiles/r2): a wave therefore takes DE_TPW tiles, strided by the number of waves of its instance so that every wave
+// gets its share of the contiguous band of occupied tiles, and loads all their bitmap words before it looks at the first.
+template <bool FAST_DIV>
 __global__ __launch_bounds__(DE_BLOCK)
 void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ bgr0, const uint16_t* __restrict__ bits,
                        int width, size_t n, float inv_scale, float fx, float fy, float cx, float cy, int ntiles,
@@ -409,42 +476,65 @@ void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict_
     __shared__ __attribute__((aligned(16))) uint16_t zraw[DE_BLOCK / 64][DB_TILE];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * (DE_BLOCK / 64) + wave;
-    if (tile >= ntiles) return;
-    const size_t t0 = (size_t)tile * DB_TILE;                         // first pixel of the tile
-    const size_t i0 = t0 + (size_t)lane * DB_PX;
-    const unsigned word = i0 < n ? (unsigned)bits[(size_t)b * (n / DB_PX) + i0 / DB_PX] : 0u;   // validity of pixels i0 .. i0 + 15
-    if (!__any(word != 0u)) return;                                   // most tiles of an instance: nothing else is read
+    const int first = blockIdx.x * (DE_BLOCK / 64) + wave, stride = gridDim.x * (DE_BLOCK / 64);
     const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
     const uint16_t* __restrict__ raw = raw0 + frame * n;
-    if (i0 < n) {                                                     // n is a multiple of 16: 32 B per lane, whole or not at all
-        *reinterpret_cast<uint4*>(&zraw[wave][lane * DB_PX]) = *reinterpret_cast<const uint4*>(raw + i0);
-        *reinterpret_cast<uint4*>(&zraw[wave][lane * DB_PX + 8]) = *reinterpret_cast<const uint4*>(raw + i0 + 8);
-    }
-    __builtin_amdgcn_wave_barrier();                                  // a wave reads back only what it staged itself
-    size_t slot0 = (size_t)offsets[(size_t)b * ntiles + tile];        // output slot of the tile's first valid pixel
     const uint8_t* __restrict__ bgr = (rgb && bgr0) ? bgr0 + frame * n * 3 : nullptr;
-#pragma unroll 1
-    for (int j = 0; j < DB_PX; ++j) {                                 // round j: pixels t0 + 64 j .. + 63
-        const unsigned long long m = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j)
-                                   | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 1) << 16)
-                                   | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 2) << 32)
-                                   | ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 3) << 48);
-        if (!m) continue;                                             // wave-uniform
-        if ((m >> lane) & 1ull) {
-            const size_t i = t0 + 64 * (size_t)j + lane;
-            const float z = (float)zraw[wave][64 * j + lane] * inv_scale;   // pipeline.cpp:47
-            const int v = (int)(i / width), u = (int)(i - (size_t)v * width);
-            const size_t slot = slot0 + __popcll(m & ((1ull << lane) - 1ull));
-            xyz[3 * slot] = ((float)u - cx) * z / fx;                  // pipeline.cpp:73
-            xyz[3 * slot + 1] = ((float)v - cy) * z / fy;              // pipeline.cpp:74
-            xyz[3 * slot + 2] = z;
-            if (bgr) {
-                const uint8_t* p = bgr + i * 3;
-                rgb[3 * slot] = (float)p[2] / 255.0f; rgb[3 * slot + 1] = (float)p[1] / 255.0f; rgb[3 * slot + 2] = (float)p[0] / 255.0f;
-            }
+    const unsigned bit_lo = lane < 32 ? 1u << lane : 0u, bit_hi = lane < 32 ? 0u : 1u << (lane - 32);
+    const float rfx = refined_rcp(fx), rfy = refined_rcp(fy);
+    unsigned words[DE_TPW];                                           // validity of pixels i0 .. i0 + 15 of each of the wave's tiles
+#pragma unroll
+    for (int k = 0; k < DE_TPW; ++k) {
+        const int tile = first + k * stride;
+        const size_t i0 = (size_t)tile * DB_TILE + (size_t)lane * DB_PX;
+        words[k] = (tile < ntiles && i0 < n) ? (unsigned)bits[(size_t)b * (n / DB_PX) + i0 / DB_PX] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < DE_TPW; ++k) {
+        const unsigned word = words[k];
+        if (!__any(word != 0u)) continue;                             // most tiles of an instance: nothing else is read
+        const int tile = first + k * stride;
+        const size_t t0 = (size_t)tile * DB_TILE;                     // first pixel of the tile
+        const size_t i0 = t0 + (size_t)lane * DB_PX;
+        __builtin_amdgcn_wave_barrier();                              // the previous tile's rounds are done with zraw
+        if (i0 < n) {                                                 // n is a multiple of 16: 32 B per lane, whole or not at all
+            *reinterpret_cast<uint4*>(&zraw[wave][lane * DB_PX]) = *reinterpret_cast<const uint4*>(raw + i0);
+            *reinterpret_cast<uint4*>(&zraw[wave][lane * DB_PX + 8]) = *reinterpret_cast<const uint4*>(raw + i0 + 8);
         }
-        slot0 += __popcll(m);
+        __builtin_amdgcn_wave_barrier();                              // a wave reads back only what it staged itself
+        const size_t slot0 = (size_t)offsets[(size_t)b * ntiles + tile];    // output slot of the tile's first valid pixel
+        float* __restrict__ tile_xyz = xyz + 3 * slot0;
+        float* __restrict__ tile_rgb = bgr ? rgb + 3 * slot0 : nullptr;
+        unsigned run = 0u;                                            // valid pixels of the tile's earlier rounds (32-bit offsets from here on)
+        // (column, row) of this lane's pixel, advanced by 64 pixels per round: a division per pixel would be a third of
+        // the loop's instructions
+        unsigned row = (unsigned)(t0 / (size_t)width);
+        unsigned col = (unsigned)(t0 - (size_t)row * (size_t)width) + (unsigned)lane;
+        while (col >= (unsigned)width) { col -= (unsigned)width; ++row; }
+#pragma unroll 1
+        for (int j = 0; j < DB_PX; ++j) {                             // round j: pixels t0 + 64 j .. + 63
+            const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)word, 4 * j) | ((unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 1) << 16);
+            const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 2) | ((unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 3) << 16);
+            if (m_lo | m_hi) {                                        // wave-uniform
+                if ((m_lo & bit_lo) | (m_hi & bit_hi)) {
+                    const float z = (float)zraw[wave][64 * j + lane] * inv_scale;   // pipeline.cpp:47
+                    const unsigned slot = 3u * (run + __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u)));   // + valid lanes below this one
+                    float* __restrict__ o = tile_xyz + slot;
+                    const float ax = ((float)col - cx) * z, ay = ((float)row - cy) * z;
+                    o[0] = FAST_DIV ? div_by_uniform(ax, fx, rfx) : ax / fx;   // pipeline.cpp:73
+                    o[1] = FAST_DIV ? div_by_uniform(ay, fy, rfy) : ay / fy;   // pipeline.cpp:74
+                    o[2] = z;
+                    if (bgr) {
+                        const uint8_t* p = bgr + (t0 + 64 * (size_t)j + lane) * 3;
+                        float* __restrict__ c = tile_rgb + slot;
+                        c[0] = (float)p[2] / 255.0f; c[1] = (float)p[1] / 255.0f; c[2] = (float)p[0] / 255.0f;   // pipeline.cpp:78-80
+                    }
+                }
+                run += __popc(m_lo) + __popc(m_hi);
+            }
+            col += 64u;
+            while (col >= (unsigned)width) { col -= (unsigned)width; ++row; }
+        }
     }
 }
 
@@ -456,6 +546,33 @@ __global__ void k_gather_instance_offsets(const int* __restrict__ offsets, const
 
 static bool batch_vectorisable(const uint16_t* d_raw, const uint8_t* d_masks, size_t n) {
     return n % 16 == 0 && ((uintptr_t)d_raw % 16 == 0) && ((uintptr_t)d_masks % 16 == 0);   // stacked masks and frames sit at multiples of n
+}
+
+// The raw values r with `z > 0 && z <= zmax`, z = (float)r * inv_scale, evaluated exactly as the kernels do (pipeline.cpp:47,71:
+// `!(z <= 0 || z > zmax)`).  For a finite inv_scale >= 0 the product is monotone in r and never NaN, so the values form one
+// range, found by two bisections; anything else (an infinite scale factor makes 0 * inf = NaN pass the test) is left to the
+// per-pixel kernels.  An empty range comes back as [1, 0].
+static bool depth_valid_range(float inv_scale, float zmax, int* lo, int* hi) {
+    if (!(inv_scale >= 0.f) || !(inv_scale <= FLT_MAX)) return false;
+    auto z = [inv_scale](int r) { volatile float v = (float)r * inv_scale; return (float)v; };
+    int a = 0, b = 65536;                      // first r with z(r) > 0 (65536: none)
+    while (a < b) { const int m = (a + b) / 2; if (z(m) > 0.f) b = m; else a = m + 1; }
+    const int first = a;
+    a = 0; b = 65536;                          // first r with z(r) > zmax (65536: none; NaN zmax: none, as in the test itself)
+    while (a < b) { const int m = (a + b) / 2; if (z(m) > zmax) b = m; else a = m + 1; }
+    *lo = first; *hi = a - 1;
+    if (*lo > *hi) { *lo = 1; *hi = 0; }
+    return true;
+}
+
+// Camera parameters for which div_by_uniform is `/` bit for bit on every pixel (see there).  a = (col - c) * z with
+// integer col, row < 2^16: col - c is 0 or at least half an ulp of c in size, hence >= 2^-34 for |c| >= 2^-10, and at
+// most 2^21; z = raw * inv_scale in [2^-30, 2^26]; so a is 0 (both forms return a signed zero through v_div_fixup) or
+// 2^-64 <= |a| <= 2^47, and with 2^-10 <= |f| <= 2^30 the quotient stays within [2^-94, 2^57].
+static bool emit_fast_div_ok(float fx, float fy, float cx, float cy, float inv_scale, int w, int h) {
+    auto focal = [](float f) { const float a = std::fabs(f); return a >= 0x1p-10f && a <= 0x1p30f; };
+    auto centre = [](float c) { const float a = std::fabs(c); return a == 0.f || (a >= 0x1p-10f && a <= 0x1p20f); };
+    return focal(fx) && focal(fy) && centre(cx) && centre(cy) && inv_scale >= 0x1p-30f && inv_scale <= 0x1p10f && w <= 65536 && h <= 65536;
 }
 
 // Device copy of the instance -> frame map (nullptr when every instance reads frame 0).
@@ -481,7 +598,8 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d
                                float scale, int mask_mode, float zmax, int** d_offsets_out, int* h_offsets) {
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
-    const bool vec = batch_vectorisable(d_raw, d_masks, n);
+    int raw_lo = 1, raw_hi = 0;
+    const bool vec = batch_vectorisable(d_raw, d_masks, n) && depth_valid_range(inv_scale, zmax, &raw_lo, &raw_hi);
     const int blocks = vec ? (int)((n + DB_TILE - 1) / DB_TILE) : (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);   // tiles resp. workgroups per instance
     int *counts, *offsets, *d_total, *d_inst;
     TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &counts));
@@ -493,9 +611,13 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d
     hipStream_t s = ctx->stream;
     {
         ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-        if (vec) k_depth_bits<<<dim3((blocks + DP_BLOCK / 64 - 1) / (DP_BLOCK / 64), (n_inst + DB_GROUP - 1) / DB_GROUP), DP_BLOCK, 0, s>>>(
-                     d_raw, d_frame_of, d_masks, n, n_inst, stacked, inv_scale, mask_mode, zmax, blocks, ctx->depth_bits, counts);
-        else k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
+        if (vec) {
+            const dim3 grid((blocks + DP_BLOCK / 64 - 1) / (DP_BLOCK / 64), (n_inst + DB_GROUP - 1) / DB_GROUP);
+#define TDV_DEPTH_BITS(ST, PF) k_depth_bits<ST, PF><<<grid, DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, n_inst, raw_lo, raw_hi, mask_mode, blocks, ctx->depth_bits, counts)
+            if (stacked) { if (d_frame_of) TDV_DEPTH_BITS(true, true); else TDV_DEPTH_BITS(true, false); }
+            else { if (d_frame_of) TDV_DEPTH_BITS(false, true); else TDV_DEPTH_BITS(false, false); }
+#undef TDV_DEPTH_BITS
+        } else k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
     }
     TDV_CHECK_LAUNCH(ctx);
     {
@@ -518,13 +640,16 @@ int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_
                               const int* d_offsets, float* d_xyz, float* d_rgb) {
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
-    const bool vec = batch_vectorisable(d_raw, d_masks, n);
+    const bool vec = batch_vectorisable(d_raw, d_masks, n) && ctx->depth_bits;   // pass 1 left a bitmap: it took the tiled path
     ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
     if (vec) {
-        if (!ctx->depth_bits) return TDV_ERR_INTERNAL;
         const int ntiles = (int)((n + DB_TILE - 1) / DB_TILE);
-        k_depth_emit_bits<<<dim3((ntiles + DE_BLOCK / 64 - 1) / (DE_BLOCK / 64), n_inst), DE_BLOCK, 0, ctx->stream>>>(
-            d_raw, d_frame_of, d_bgr, ctx->depth_bits, w, n, inv_scale, fx, fy, cx, cy, ntiles, d_offsets, d_xyz, d_rgb);
+        const int tiles_per_block = (DE_BLOCK / 64) * DE_TPW;
+        const dim3 grid((ntiles + tiles_per_block - 1) / tiles_per_block, n_inst);
+        if (emit_fast_div_ok(fx, fy, cx, cy, inv_scale, w, h))
+            k_depth_emit_bits<true><<<grid, DE_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_bgr, ctx->depth_bits, w, n, inv_scale, fx, fy, cx, cy, ntiles, d_offsets, d_xyz, d_rgb);
+        else
+            k_depth_emit_bits<false><<<grid, DE_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_bgr, ctx->depth_bits, w, n, inv_scale, fx, fy, cx, cy, ntiles, d_offsets, d_xyz, d_rgb);
     } else {
         const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
         k_emit_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,

@@ -136,6 +136,43 @@ def test_all_instance_clouds_odd_frame_scalar_path(ctx, orc):
         assert xyz[off[b]:off[b + 1]].tobytes() == ref_xyz.tobytes() and rgb[off[b]:off[b + 1]].tobytes() == ref_rgb.tobytes()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_all_instance_clouds_camera_parameter_fuzz(ctx, orc, seed):
+    """The tiled kernels (pixel count a multiple of 16) against the oracle, bit for bit, over camera parameters: the emit
+    pass divides by the wave-uniform focal lengths with a hoisted reciprocal when the parameters allow it and with `/`
+    otherwise (seeds 4, 5: focal length resp. principal point outside the allowed ranges); the depth test is a raw-value
+    range found on the host; masks go through the four-bytes-at-once rule in all three mask modes' byte ranges."""
+    rng = np.random.default_rng(100 + seed)
+    h, w, B = 48, 176, 9                      # 8,448 pixels = 8.25 tiles: a ragged last tile and a ragged last instance group
+    raw = rng.integers(0, 3000, (h, w)).astype(np.uint16)
+    raw[rng.random((h, w)) < 0.05] = 0
+    masks = rng.integers(0, 256, (B, h, w)).astype(np.uint8)
+    masks[rng.random((B, h, w)) < 0.5] = 0
+    masks[:, :, :32][:, 10:20] = 11           # around the threshold of the CPU rule (> 10)
+    masks[:, :, 32:64][:, 10:20] = 10
+    masks[B - 1] = 0                          # an instance without pixels
+    scale = float(rng.choice([1000.0, 4000.0, 0.25, 65535.0]))
+    fx = float(np.float32(rng.uniform(0.3, 3000.0))); fy = float(np.float32(rng.uniform(0.3, 3000.0)))
+    cx = float(np.float32(rng.uniform(-50.0, w + 50.0))); cy = float(np.float32(rng.choice([0.0, 23.5, h / 2 - 0.123])))
+    if seed % 2: fx = -fx
+    if seed == 4: fx = 3.0e-5
+    if seed == 5: cx = 1.0e-6
+    zmax = float(np.float32(rng.uniform(0.2, 2.5) * 1000.0 / scale))
+    dev = torch.device("cuda", 0)
+    d_raw = torch.from_numpy(raw.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev)
+    cap = B * h * w
+    d_xyz = torch.zeros((cap + 1, 3), dtype=torch.float32, device=dev)
+    for shift in (0, 1):                      # output base 16-B aligned and not
+        out_ptr = d_xyz.data_ptr() + 4 * shift
+        off = ctx.depth_to_cloud_batch_dev(d_raw.data_ptr(), d_masks.data_ptr(), None, B, w, h, scale, fx, fy, cx, cy, zmax, out_ptr, None, cap)
+        flat = d_xyz.cpu().numpy().reshape(-1)[shift:]
+        assert off[B] - off[B - 1] == 0
+        for b in range(B):
+            ref_xyz, _ = orc.unproject(orc.depth_preprocess(raw, masks[b], scale), None, fx, fy, cx, cy, zmax)
+            assert off[b + 1] - off[b] == len(ref_xyz)
+            assert flat[3 * off[b]:3 * off[b + 1]].tobytes() == ref_xyz.tobytes(), (seed, b, shift)
+
+
 @pytest.mark.parametrize("n,voxel,k", [(3, 0.01, 30), (40, 0.002, 30), (200, 0.004, 30), (3000, 0.002, 8), (5000, 0.01, 64)])
 def test_model_prep_small_clouds(ctx, tdv, synth, n, voxel, k):
     """tdv_prepare_model_dev (one radius search shared by normals and FPFH, kNN only for the deficient points) equals
