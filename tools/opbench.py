@@ -124,7 +124,7 @@ def cloud_ops(ctx, tdv, synth, torch, dev, n, reps=3, want_match=True):
         d_corr = torch.empty(n, dtype=torch.int32, device=dev)
         wall = median_ms(lambda: ctx.feature_match_dev(d_desc.data_ptr(), n, d_mdesc.data_ptr(), n, d_corr.data_ptr()), torch, reps=reps)
         out.append(pruned(dict(op="feature_match", workload="%d x %d FPFH descriptors of the cuboid (GPU chain), index build included" % (n, n), ms=wall),
-                          98.0 * n * n, wall, "packed index; flat faces give a plateau of near-identical rows that falls back to the scan"))
+                          98.0 * n * n, wall, "packed index; flat faces give bit-identical rows, which the index holds once"))
     return out
 
 
