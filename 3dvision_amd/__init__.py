@@ -42,7 +42,7 @@ DEPTH_BATCH_MASK_PASSES = 1   # the B masks cross HBM once in tdv_depth_to_cloud
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [
-    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_last_icp_search", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
@@ -183,17 +183,25 @@ class Context:
     """One tdv_ctx (stream + workspace).  Not thread-safe; one per host thread."""
 
     def __init__(self, device=0, stream=None):
+        self.icp_search_name = "auto"
         self._h = C.c_void_p()
         _check(None, lib().tdv_ctx_create(int(device), C.byref(self._h)), "tdv_ctx_create")
         self.device = device
         if stream is not None:
             _check(self._h, lib().tdv_ctx_set_stream(self._h, C.c_void_p(stream)), "tdv_ctx_set_stream")
 
-    ICP_SEARCH = {"auto": 0, "brute": 1, "pruned": 2}
+    ICP_SEARCH = {"auto": 0, "brute": 1, "pruned": 2, "grid": 3}
 
     def set_icp_search(self, mode):
-        """'auto' (by size), 'brute' (the reference's scan) or 'pruned' (exact box-pruned walk); same results."""
+        """'auto' (by size and cell occupancy), 'brute' (the reference's scan), 'pruned' (exact box-pruned walk) or 'grid' (hash grid
+        with cells of 1.25 x the threshold; falls back to 'pruned' when the threshold is large against the spacing); same results."""
         _check(self._h, lib().tdv_ctx_set_icp_search(self._h, self.ICP_SEARCH[mode]), "tdv_ctx_set_icp_search")
+        self.icp_search_name = mode
+
+    def last_icp_search(self):
+        """Name of the search the last ICP / correspondence call ran ('brute', 'pruned', 'grid'; 'auto' before any)."""
+        v = lib().tdv_ctx_last_icp_search(self._h)
+        return {n: k for k, n in self.ICP_SEARCH.items()}[v]
 
     def close(self):
         if self._h:

@@ -40,10 +40,19 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         have_index = true;
     }
     // likewise the model's Morton order and boxes for the ICP correspondence search (built when ICP will take the pruned path)
+    // (the hash grid at this call's ICP threshold first; the Morton order only if the grid cannot be used)
+    const float icp_thr = prm->voxel_size * prm->icp_distance_factor;  // pipeline.cpp:104
+    CellGrid model_grid{}; bool have_grid = false;
     SortedCloud model_sorted{}; bool have_sorted = false;
     if (n_model >= 4096 && ctx->icp_search != TDV_ICP_SEARCH_BRUTE) {
-        TDV_TRY(spatial_sort_cloud(ctx, d_model_xyz, n_model, model_sorted));
-        have_sorted = true;
+        if (ctx->icp_search != TDV_ICP_SEARCH_PRUNED) {
+            TDV_TRY(cell_grid_build(ctx, d_model_xyz, n_model, icp_thr, &model_grid));
+            have_grid = true;                     // (usable or not: ICP looks at the flag and does not build its own)
+        }
+        if (!model_grid.usable) {
+            TDV_TRY(spatial_sort_cloud(ctx, d_model_xyz, n_model, model_sorted));
+            have_sorted = true;
+        }
     }
     // one instance: voxel -> normals + FPFH -> match -> RANSAC -> ICP on context c (its stream, its workspace)
     auto run_instance = [&](tdv_ctx* c, int b) -> int {
@@ -71,9 +80,8 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
                                prm->ransac_confidence, prm->seed, &coarse, nullptr));
         r.coarse_fitness = coarse.fitness; r.coarse_inliers = coarse.inliers;
         tdv_icp_result fine;
-        const float thr = prm->voxel_size * prm->icp_distance_factor;  // pipeline.cpp:104
-        TDV_TRY(icp_run_dev(c, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine,
-                            have_sorted ? &model_sorted : nullptr));
+        TDV_TRY(icp_run_dev(c, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, icp_thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine,
+                            have_sorted ? &model_sorted : nullptr, have_grid ? &model_grid : nullptr));
         std::memcpy(r.T, fine.T, 64);
         r.fitness = fine.fitness; r.rmse = fine.rmse; r.icp_iterations = fine.iterations;
         r.status = 0;

@@ -65,12 +65,12 @@ hipEvent_t event_acquire(tdv_ctx* ctx) { return get_event(ctx); }
 void event_release(tdv_ctx* ctx, hipEvent_t e) { if (e) ctx->event_pool.push_back(e); }
 
 ScopedTimer::ScopedTimer(tdv_ctx* c, int s) : ctx(c), slot(s) {
-    if (!ctx->timing) return;
+    if (!ctx->timing || slot < 0) return;     // slot < 0: nothing to time here
     a = get_event(ctx); b = get_event(ctx);
     if (a) (void)hipEventRecord(a, ctx->stream);
 }
 ScopedTimer::~ScopedTimer() {
-    if (!ctx->timing || !a || !b) return;
+    if (!ctx->timing || slot < 0 || !a || !b) return;
     (void)hipEventRecord(b, ctx->stream);
     ctx->timers[slot].pending.emplace_back(a, b);
 }
@@ -195,16 +195,19 @@ int tdv_ctx_create(int device, tdv_ctx** out) {
     if (const char* e = getenv("TDV_ICP_SEARCH")) {
         if (!strcmp(e, "brute")) c->icp_search = TDV_ICP_SEARCH_BRUTE;
         else if (!strcmp(e, "pruned")) c->icp_search = TDV_ICP_SEARCH_PRUNED;
+        else if (!strcmp(e, "grid")) c->icp_search = TDV_ICP_SEARCH_GRID;
     }
     *out = c;
     return TDV_OK;
 }
 
 int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode) {
-    if (!ctx || mode < TDV_ICP_SEARCH_AUTO || mode > TDV_ICP_SEARCH_PRUNED) return TDV_ERR_BAD_ARG;
+    if (!ctx || mode < TDV_ICP_SEARCH_AUTO || mode > TDV_ICP_SEARCH_GRID) return TDV_ERR_BAD_ARG;
     ctx->icp_search = mode;
     return TDV_OK;
 }
+
+int tdv_ctx_last_icp_search(tdv_ctx* ctx) { return ctx ? ctx->last_icp_search : 0; }
 
 int tdv_ctx_set_stream(tdv_ctx* ctx, void* s) {
     if (!ctx) return TDV_ERR_BAD_ARG;

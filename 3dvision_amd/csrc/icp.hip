@@ -221,6 +221,122 @@ void k_icp_nn_pruned(const float* __restrict__ src, int ns,
     if (lane < PN_PTS && i0 + lane < ns) { out_d2[i0 + lane] = res_d; out_idx[i0 + lane] = res_o; }
 }
 
+// ---- hash-grid search ------------------------------------------------------------------------------------------------
+// ICP accepts a correspondence only within `thr`, and the reference's pipeline sets thr = 0.4 x the voxel size: far below
+// the point spacing.  One LANE per source point looks its neighbourhood up in a hash grid over the target and verifies
+// what it finds with the scan's distance expression, instead of one WAVE per source point walking box levels.
+// Cells are 2.2 thr wide, so per axis a neighbour within thr lies in the query's cell or in ONE adjacent cell, the one on
+// the side of the cell the query sits in: 8 probes of an open-addressing table (16-B entries: key, list head), all loaded
+// before the first is looked at.  The points of a cell form a linked list of original indices (order irrelevant: the
+// lowest (d2, index) is kept).  Every candidate is verified (d2 <= tau), so a key collision or the garbage cell of a
+// far-away query can only cost time.  Completeness: in cell units a pair within thr is at most r = 1/2.2 (1 + 1e-6) apart
+// per axis; a computed coordinate fl(x * inv_cell) is within e = 2^-23 |coordinate| (two roundings) of the real one, i.e.
+// e <= 2^-6 while |coordinate| < 2^17 - which k_grid_insert checks on every target (a query within thr of a target is in
+// range with it).  A query with computed fraction f < 0.5 in cell k sees a neighbour's computed coordinate inside
+// [k - r - 2e, k + 0.5 + r + 2e) and r + 2e < 0.486: cells k - 1 and k; symmetrically k and k + 1 for f >= 0.5.
+constexpr unsigned long long GRID_EMPTY = ~0ull;
+constexpr float GRID_CELL_FACTOR = 2.2f;
+constexpr float GRID_MAX_COORD = 131072.0f;      // 2^17 cells
+constexpr int GRID_MAX_PER_CELL = 8;             // average over the occupied cells above which the grid is not used
+struct __attribute__((aligned(16))) GridEntry { unsigned long long key; int head; int pad; };
+__device__ __forceinline__ unsigned long long grid_key(int ix, int iy, int iz) {
+    return ((unsigned long long)((unsigned)ix & 0x1fffffu) << 42) | ((unsigned long long)((unsigned)iy & 0x1fffffu) << 21) | (unsigned long long)((unsigned)iz & 0x1fffffu);
+}
+__device__ __forceinline__ unsigned grid_slot(unsigned long long key, int shift) { return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+
+// flags[0]: a coordinate out of range / non-finite; flags[1]: occupied cells
+__global__ __launch_bounds__(256)
+void k_grid_insert(const float* __restrict__ tgt, int nt, float inv_cell, GridEntry* table, float4* __restrict__ node,
+                   unsigned mask, int shift, int* __restrict__ flags) {
+    __shared__ int s_new, s_bad;
+    if (threadIdx.x == 0) { s_new = 0; s_bad = 0; }
+    __syncthreads();
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    bool fresh = false, bad = false;
+    if (j < nt) {
+        const float x = tgt[3 * j], y = tgt[3 * j + 1], z = tgt[3 * j + 2];
+        const float fx = x * inv_cell, fy = y * inv_cell, fz = z * inv_cell;
+        bad = !(fabsf(fx) < GRID_MAX_COORD && fabsf(fy) < GRID_MAX_COORD && fabsf(fz) < GRID_MAX_COORD);
+        if (!bad) {
+            const unsigned long long key = grid_key((int)floorf(fx), (int)floorf(fy), (int)floorf(fz));
+            unsigned slot = grid_slot(key, shift);
+            for (;;) {
+                unsigned long long k = table[slot].key;
+                if (k == GRID_EMPTY) { k = atomicCAS(&table[slot].key, GRID_EMPTY, key); if (k == GRID_EMPTY) { fresh = true; break; } }
+                if (k == key) break;
+                slot = (slot + 1) & mask;        // half full at most
+            }
+            node[j] = make_float4(x, y, z, __int_as_float(atomicExch(&table[slot].head, j)));   // the point and the next index of its cell's list
+        }
+    }
+    const unsigned long long mf = __ballot(fresh), mb = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) { if (mf) atomicAdd(&s_new, __popcll(mf)); if (mb) atomicAdd(&s_bad, 1); }
+    __syncthreads();
+    if (threadIdx.x == 0) { if (s_new) atomicAdd(&flags[1], s_new); if (s_bad) atomicOr(&flags[0], 1); }
+}
+
+// the search of one query point p: lowest (d2, original index) among the targets with d2 <= tau, (INFINITY, INT_MAX) if none
+__device__ __forceinline__ void grid_nearest(const GridEntry* __restrict__ table, const float4* __restrict__ node, unsigned mask, int shift,
+                                             float inv_cell, float px, float py, float pz, float tau, float& bd, int& bo) {
+    const float gx = px * inv_cell, gy = py * inv_cell, gz = pz * inv_cell;
+    const float kx = floorf(gx), ky = floorf(gy), kz = floorf(gz);
+    const int cx = (int)kx, cy = (int)ky, cz = (int)kz;
+    const int sx = (gx - kx < 0.5f) ? -1 : 1, sy = (gy - ky < 0.5f) ? -1 : 1, sz = (gz - kz < 0.5f) ? -1 : 1;   // the adjacent cell that can matter
+    unsigned long long key[8]; unsigned slot[8]; uint4 e[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                          // the eight table entries: independent loads, all in flight together
+        key[c] = grid_key(cx + ((c & 1) ? sx : 0), cy + ((c & 2) ? sy : 0), cz + ((c & 4) ? sz : 0));
+        slot[c] = grid_slot(key[c], shift);
+        e[c] = *reinterpret_cast<const uint4*>(&table[slot[c]]);
+    }
+    int j[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        unsigned long long k = ((unsigned long long)e[c].y << 32) | e[c].x;
+        j[c] = (int)e[c].z;
+        while (k != key[c] && k != GRID_EMPTY) {           // linear probing: rarely more than one step
+            slot[c] = (slot[c] + 1) & mask;
+            const uint4 n = *reinterpret_cast<const uint4*>(&table[slot[c]]);
+            k = ((unsigned long long)n.y << 32) | n.x; j[c] = (int)n.z;
+        }
+        if (k != key[c]) j[c] = -1;
+    }
+    bd = INFINITY; bo = INT_MAX;
+    auto take = [&](const float4 t, int idx) {
+        const float ex = px - t.x, ey = py - t.y, ez = pz - t.z;
+        const float d2 = ex * ex + (ey * ey + ez * ez);    // the scan's expression
+        if (d2 <= tau && (d2 < bd || (d2 == bd && idx < bo))) { bd = d2; bo = idx; }
+    };
+    float4 first[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) first[c] = j[c] >= 0 ? node[j[c]] : make_float4(0.f, 0.f, 0.f, __int_as_float(-1));   // the cells' first points, together
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (j[c] < 0) continue;
+        take(first[c], j[c]);
+        int n = __float_as_int(first[c].w);
+        while (n >= 0) { const float4 t = node[n]; take(t, n); n = __float_as_int(t.w); }   // the rest of the list (cells hold one or two points)
+    }
+}
+
+// One lane per source point.  (Running this search inside k_icp_accumulate - one launch per iteration, no correspondence
+// arrays in between - was measured slower, 110 us against 44 + 35 at 200k x 200k: that kernel's 29 double accumulators
+// leave too few waves per SIMD to hide the probes' latency.)
+__global__ __launch_bounds__(256)
+void k_icp_nn_grid(const float* __restrict__ src, int ns, const GridEntry* __restrict__ table, const float4* __restrict__ node,
+                   unsigned mask, int shift, float inv_cell, const IcpState* __restrict__ st, float tau,
+                   float* __restrict__ out_d2, int* __restrict__ out_idx) {
+    if (st->done) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    float px, py, pz;
+    transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+    float bd; int bo;
+    grid_nearest(table, node, mask, shift, inv_cell, px, py, pz, tau, bd, bo);
+    out_d2[i] = bo == INT_MAX ? FLT_MAX : bd;
+    out_idx[i] = bo == INT_MAX ? 0 : bo;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -318,7 +434,7 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
             if (d < best) { best = d; bc = c; }
         }
         int idx = 0;
-        if (direct) {   // pruned search: pd2/pchunk already hold the final (d2, target index)
+        if (direct) {   // pruned / grid search: (best, bc) are the final (d2, target index)
             idx = bc;
         } else if (best < FLT_MAX) {
             idx = bc;
@@ -450,9 +566,37 @@ int alloc_buffers(tdv_ctx* ctx, const NnPlan& p, IcpBuffers& b) {
 
 }  // namespace
 
+int cell_grid_build(tdv_ctx* ctx, const float* d_tgt, int nt, float thr, CellGrid* g) {
+    if (!ctx || !d_tgt || !g || nt <= 0) return TDV_ERR_BAD_ARG;
+    *g = CellGrid{};
+    g->thr = thr; g->n = nt;
+    const float cell = GRID_CELL_FACTOR * thr;
+    const float inv_cell = 1.0f / cell;
+    if (!(thr > 0.f) || !(cell <= FLT_MAX) || !(inv_cell > 0.f) || !(inv_cell <= FLT_MAX)) return TDV_OK;   // usable = 0
+    size_t size = 1024; int log2 = 10;
+    while (size < 2 * (size_t)nt) { size <<= 1; ++log2; }
+    GridEntry* table; float4* node; int* flags;
+    TDV_TRY(ws_alloc(ctx, size, &table));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &node));
+    TDV_TRY(ws_alloc(ctx, 2, &flags));
+    hipStream_t s = ctx->stream;
+    TDV_HIP(ctx, hipMemsetAsync(table, 0xff, size * sizeof(GridEntry), s));      // key = empty, head = -1
+    TDV_HIP(ctx, hipMemsetAsync(flags, 0, 8, s));
+    k_grid_insert<<<(nt + 255) / 256, 256, 0, s>>>(d_tgt, nt, inv_cell, table, node, (unsigned)(size - 1), 64 - log2, flags);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_TRY(pin_reserve(ctx, 64));
+    TDV_HIP(ctx, hipMemcpyAsync(ctx->pin, flags, 8, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    const int* h = reinterpret_cast<const int*>(ctx->pin);
+    const int bad = h[0], cells = h[1];
+    g->table = table; g->node = node; g->mask = (unsigned)(size - 1); g->shift = 64 - log2; g->inv_cell = inv_cell;
+    g->usable = (!bad && cells > 0 && (long long)nt <= (long long)GRID_MAX_PER_CELL * cells) ? 1 : 0;
+    return TDV_OK;
+}
+
 int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
                 const float* T0, float thr, int max_iterations, int point_to_plane, int fixed_iterations,
-                tdv_icp_result* out, const SortedCloud* tgt_sorted) {
+                tdv_icp_result* out, const SortedCloud* tgt_sorted, const CellGrid* tgt_grid) {
     if (!ctx || !d_src || !d_tgt || !T0 || !out || ns < 0 || nt < 0 || max_iterations < 0) return TDV_ERR_BAD_ARG;
     TDV_HIP(ctx, hipSetDevice(ctx->device));
     // result defaults: registration.cpp:309-311
@@ -466,6 +610,15 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     bool pruned = ctx->icp_search == TDV_ICP_SEARCH_PRUNED ||
                   (ctx->icp_search == TDV_ICP_SEARCH_AUTO && nt >= PRUNED_MIN_TARGETS && (double)ns * (double)nt >= PRUNED_MIN_PAIRS);
     if (!(tau < FLT_MAX)) pruned = false;   // unbounded threshold: keep the scan's handling of overflowing distances
+    // hash grid: on request, or by size like the pruned walk; used when its build says the cells are small enough
+    CellGrid cg{};
+    if (tau < FLT_MAX && (ctx->icp_search == TDV_ICP_SEARCH_GRID || (ctx->icp_search == TDV_ICP_SEARCH_AUTO && pruned))) {
+        if (tgt_grid && tgt_grid->n == nt && tgt_grid->thr == thr) cg = *tgt_grid;
+        else TDV_TRY(cell_grid_build(ctx, d_tgt, nt, thr, &cg));
+        if (cg.usable) pruned = true;           // results arrive in the pruned walk's format (one entry per source, original indices)
+        else if (ctx->icp_search == TDV_ICP_SEARCH_GRID) pruned = true;   // fall back to the walk
+    }
+    ctx->last_icp_search = cg.usable ? TDV_ICP_SEARCH_GRID : (pruned ? TDV_ICP_SEARCH_PRUNED : TDV_ICP_SEARCH_BRUTE);
     NnPlan p = make_plan(ns, nt);
     if (pruned) p.nsplit = 1;
     else if (!getenv("TDV_ICP_PPT")) { p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256; }   // measured: 50k x 10k brute 7.6k vs 6.4k iters/s
@@ -478,7 +631,9 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     hipStream_t s = ctx->stream;
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
     SortedCloud st{};
-    if (pruned) {
+    if (cg.usable) {
+        // nothing to prepare
+    } else if (pruned) {
         if (tgt_sorted && tgt_sorted->n == nt) st = *tgt_sorted;   // the batch orders the shared model once
         else TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
     } else {
@@ -487,6 +642,8 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     TDV_CHECK_LAUNCH(ctx);
     const bool p2pl = point_to_plane && d_tgt_normals;
     const int direct = pruned ? 1 : 0;
+    const GridEntry* gtable = cg.usable ? reinterpret_cast<const GridEntry*>(cg.table) : nullptr;
+    const float4* gnode = cg.usable ? reinterpret_cast<const float4*>(cg.node) : nullptr;
     const dim3 grid(p.blocks_x, p.nsplit);
     const int poll = 8;
     int it = 0;
@@ -495,7 +652,9 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
         for (int k = 0; k < burst; ++k) {
             {
                 ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
-                if (pruned)
+                if (gtable)
+                    k_icp_nn_grid<<<(ns + 255) / 256, 256, 0, s>>>(d_src, ns, gtable, gnode, cg.mask, cg.shift, cg.inv_cell, b.st, tau, b.pd2, b.pchunk);
+                else if (pruned)
                     k_icp_nn_pruned<<<(ns + PN_WAVES * PN_PTS - 1) / (PN_WAVES * PN_PTS), 64 * PN_WAVES, 0, s>>>(
                         d_src, ns, st.sx, st.sy, st.sz, st.orig, nt, st.lbox, st.n_leaf, st.tbox, st.n_top, b.st, tau, b.pd2, b.pchunk);
                 else
@@ -528,7 +687,10 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
     TDV_HIP(ctx, hipSetDevice(ctx->device));
     NnPlan p = make_plan(ns, nt);
     p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256;   // one point per thread in the outputs-only pass
-    const bool pruned = ctx->icp_search == TDV_ICP_SEARCH_PRUNED && tau_le(thr) < FLT_MAX;
+    bool pruned = (ctx->icp_search == TDV_ICP_SEARCH_PRUNED || ctx->icp_search == TDV_ICP_SEARCH_GRID) && tau_le(thr) < FLT_MAX;
+    CellGrid grid{};
+    if (pruned && ctx->icp_search == TDV_ICP_SEARCH_GRID) TDV_TRY(cell_grid_build(ctx, d_tgt, nt, thr, &grid));
+    ctx->last_icp_search = grid.usable ? TDV_ICP_SEARCH_GRID : (pruned ? TDV_ICP_SEARCH_PRUNED : TDV_ICP_SEARCH_BRUTE);
     if (pruned) p.nsplit = 1;
     IcpBuffers b;
     TDV_TRY(alloc_buffers(ctx, p, b));
@@ -539,7 +701,10 @@ int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const floa
     hipStream_t s = ctx->stream;
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
     const float tau = tau_le(thr);
-    if (pruned) {   // explicit request only: entries beyond the threshold come back as corr 0 / d2 FLT_MAX
+    if (grid.usable) {
+        k_icp_nn_grid<<<(ns + 255) / 256, 256, 0, s>>>(d_src, ns, reinterpret_cast<const GridEntry*>(grid.table), reinterpret_cast<const float4*>(grid.node),
+                                                       grid.mask, grid.shift, grid.inv_cell, b.st, tau, b.pd2, b.pchunk);
+    } else if (pruned) {   // explicit request only: entries beyond the threshold come back as corr 0 / d2 FLT_MAX
         SortedCloud st{};
         TDV_TRY(spatial_sort_cloud(ctx, d_tgt, nt, st));
         k_icp_nn_pruned<<<(ns + PN_WAVES * PN_PTS - 1) / (PN_WAVES * PN_PTS), 64 * PN_WAVES, 0, s>>>(

@@ -32,7 +32,8 @@ struct tdv_ctx {
     size_t pin_cap = 0;
     char err[512] = {0};
     bool timing = false;
-    int icp_search = 0;      // TDV_ICP_SEARCH_AUTO / _BRUTE / _PRUNED (tdv_ctx_set_icp_search)
+    int icp_search = 0;      // TDV_ICP_SEARCH_AUTO / _BRUTE / _PRUNED / _GRID (tdv_ctx_set_icp_search)
+    int last_icp_search = 0; // the search the last ICP / correspondence call on this ctx actually ran (tdv_ctx_last_icp_search)
     unsigned* scan_ticket = nullptr;  // persistent device word of exclusive_scan_dev (last-workgroup ticket)
     uint16_t* depth_bits = nullptr;   // validity bitmap between the two passes of the batched depth -> cloud (workspace memory of the current call)
     tdv_ctx* helper = nullptr;   // second stream + workspace of the batched pipeline's other lane (owned; created on first use)
@@ -111,10 +112,17 @@ struct IcpOutputs {  // optional per-source outputs of one correspondence pass (
     int* corr = nullptr; float* d2 = nullptr; uint8_t* accepted = nullptr;
 };
 struct SortedCloud;
-// tgt_sorted (optional): the target in Morton order with its boxes, built once by spatial_sort_cloud and reused across calls
+// Hash grid over a target cloud for ICP's correspondence search at one acceptance threshold (icp.hip): cells of 2.2 x
+// the threshold, open-addressing table of (cell key, list head), the points of a cell as a linked list of (x, y, z, next) nodes indexed like the cloud.  Lives
+// in the workspace of the ctx that built it; read-only afterwards.  usable = 0: coordinates too large for the cell
+// arithmetic or too many points per cell (the threshold is large against the spacing) - the caller takes another search.
+struct CellGrid { const void* table; const void* node; unsigned mask; int shift; float inv_cell; float thr; int n; int usable; };
+int cell_grid_build(tdv_ctx* ctx, const float* d_tgt, int nt, float thr, CellGrid* g);
+// tgt_sorted / tgt_grid (optional): the target in Morton order with its boxes (spatial_sort_cloud) resp. its hash grid
+// (cell_grid_build, for this thr), built once and reused across calls
 int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
                 const float* T0, float thr, int max_iterations, int point_to_plane, int fixed_iterations,
-                tdv_icp_result* out, const SortedCloud* tgt_sorted = nullptr);
+                tdv_icp_result* out, const SortedCloud* tgt_sorted = nullptr, const CellGrid* tgt_grid = nullptr);
 int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
                             const float* T, float thr, IcpOutputs outs, int* n_corr);
 int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,

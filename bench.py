@@ -173,6 +173,7 @@ def main():
     nn_ms, nn_launches = ctx.timing_read(tdv.TIMER_ICP_NN)
     sc_ms, sc_launches = ctx.timing_read(tdv.TIMER_RANSAC_SCORE)
     ctx.timing_enable(False)
+    icp_search_used = ctx.last_icp_search()   # before the supplementary scan below changes it
 
     times = torch.tensor([elapsed, t_icp, t_rs], dtype=torch.float64, device=dev)
     if distributed:
@@ -195,7 +196,7 @@ def main():
         sc_avg_ms = sc_ms / max(sc_launches, 1)
         bf_avg_ms = bf_ms / max(bf_launches, 1)
         hyps_total = float(args.steps) * HYPS_PER_STEP
-        pruned_default = n >= 4096 and n * n >= 1e8   # icp.hip: PRUNED_MIN_TARGETS, PRUNED_MIN_PAIRS
+        pruned_default = icp_search_used in ("pruned", "grid")
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): taken from the
         # committed summary of the same command when it covers this workload, else null
         pm = None
@@ -229,7 +230,7 @@ def main():
         }
         # NN search of the timed region.  Algorithmic HBM bytes of one ICP iteration: 12*N_s + 24*N_t + 124
         icp_bytes = 12.0 * n + 24.0 * n + 124
-        nn_kernel = "k_icp_nn_pruned" if pruned_default else "k_icp_nn_scan"
+        nn_kernel = {"grid": "k_icp_nn_grid", "pruned": "k_icp_nn_pruned"}.get(icp_search_used, "k_icp_nn_scan")
         nn_equiv = 8.0 * pairs / max(nn_avg_ms * 1e-3, 1e-12) / 1e12
         nn = {
             "kernel": nn_kernel, "avg_launch_ms": nn_avg_ms, "launches": nn_launches, "total_ms": nn_ms,
@@ -237,8 +238,13 @@ def main():
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": icp_bytes / max(nn_avg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBPS},
             "traffic": traffic(nn_kernel),
         }
-        if pruned_default:
-            nn.update({"bound": "latency (box walk: few pairs evaluated)", "bruteforce_equivalent_tops": nn_equiv,
+        if icp_search_used == "grid":
+            nn.update({"bound": "latency (hash-grid probes: 8 table entries + the points of the occupied cells per source point)",
+                       "search": "grid", "bruteforce_equivalent_tops": nn_equiv,
+                       "note": "exact hash-grid search (cells of 2.2 x the acceptance threshold, one lane per source point): identical "
+                               "correspondences to the scan; no VALU roofline fraction is claimed for it"})
+        elif pruned_default:
+            nn.update({"bound": "latency (box walk: few pairs evaluated)", "search": "pruned", "bruteforce_equivalent_tops": nn_equiv,
                        "note": "exact pruned search: evaluates only boxes that can hold a neighbour within the bound, so the "
                                "brute-force pair count / time exceeds the VALU peak; no VALU roofline fraction is claimed for it"})
         else:
@@ -269,7 +275,7 @@ def main():
             "ransac_hyps_per_s": args.steps * HYPS_PER_STEP * world / t_rs,
             "targets": {"icp_iters_per_s": 50, "ransac_hyps_per_s": 1e6},
             "config": {"workload": "headline: N_s=N_t=%d, point-to-plane ICP (fixed %d iterations, %s correspondence search) + RANSAC scoring (%d hyps), one instance pair per GPU"
-                                   % (n, args.steps, "exact pruned" if pruned_default else "brute-force", args.steps * HYPS_PER_STEP),
+                                   % (n, args.steps, {"grid": "exact hash-grid", "pruned": "exact pruned"}.get(icp_search_used, "brute-force"), args.steps * HYPS_PER_STEP),
                        "n_src": n, "n_tgt": n, "hyps_per_step": HYPS_PER_STEP, "parallelism": "instances sharded, %d rank(s)" % world,
                        "model_bcast_ms": bcast_ms if distributed else None},
             "roofline": roofline,

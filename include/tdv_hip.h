@@ -54,12 +54,19 @@ void* tdv_ctx_get_stream(tdv_ctx* ctx);
 int tdv_ctx_synchronize(tdv_ctx* ctx);
 void tdv_ctx_destroy(tdv_ctx* ctx);
 /* ICP correspondence search.  The reference's kernel is a brute-force scan (cuda/icp.cu:14-55); the pruned search
- * returns the SAME correspondences bit for bit (exact bounding-box lower bounds, lowest index on ties) and only
- * differs in time.  AUTO (default; env TDV_ICP_SEARCH=brute|pruned overrides at ctx creation) picks by size. */
+ * (bounding-box walk over the Morton-ordered target) and the grid search (hash grid with cells of 2.2 x the acceptance
+ * threshold: a neighbour within the threshold lies in 8 cells around the query) return the SAME correspondences bit
+ * for bit (exact lower bounds resp. every candidate verified with the scan's distance expression, lowest index on ties)
+ * and only differ in time.  AUTO (default; env TDV_ICP_SEARCH=brute|pruned|grid overrides at ctx creation) picks by
+ * size and by how many target points a cell holds; GRID falls back to PRUNED when the grid is not usable (threshold
+ * large against the point spacing, or coordinates beyond 2^17 cells). */
 #define TDV_ICP_SEARCH_AUTO 0
 #define TDV_ICP_SEARCH_BRUTE 1
 #define TDV_ICP_SEARCH_PRUNED 2
+#define TDV_ICP_SEARCH_GRID 3
 int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode);
+/* The search the last tdv_icp* / tdv_icp_correspondences call on this ctx ran (BRUTE, PRUNED or GRID; 0 before any). */
+int tdv_ctx_last_icp_search(tdv_ctx* ctx);
 const char* tdv_status_string(int status);
 /* Text of the last HIP error seen by this ctx ("" if none). */
 const char* tdv_last_error(tdv_ctx* ctx);

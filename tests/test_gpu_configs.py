@@ -35,6 +35,10 @@ def test_c2_icp_50k_vs_10k(ctx, orc, synth):
         ctx.set_icp_search("pruned")
         cp = ctx.icp_correspondences(src, tgt, T0, thr)
         b = ctx.icp(src, tgt, nrm, T0, thr, 50, True)
+        ctx.set_icp_search("grid")
+        cg = ctx.icp_correspondences(src, tgt, T0, thr)
+        g2 = ctx.icp(src, tgt, nrm, T0, thr, 50, True)
+        assert ctx.last_icp_search() == "grid"            # the reference's threshold, 0.4 spacings: the grid's regime
     finally:
         ctx.set_icp_search("auto")
     # sampled rows against the oracle (the scan reports every row's nearest target, accepted or not)
@@ -47,9 +51,12 @@ def test_c2_icp_50k_vs_10k(ctx, orc, synth):
     assert acc.sum() > ns // 10
     assert np.array_equal(cp["accepted"], cb["accepted"]) and cp["n_corr"] == cb["n_corr"]
     assert np.array_equal(cp["corr"][acc], cb["corr"][acc]) and cp["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
+    assert np.array_equal(cg["accepted"], cb["accepted"]) and cg["n_corr"] == cb["n_corr"]
+    assert np.array_equal(cg["corr"][acc], cb["corr"][acc]) and cg["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
     # identical ICP runs, and the refinement works at the reference's own threshold
-    assert a.transformation.tobytes() == b.transformation.tobytes()
-    assert (a.iterations, a.n_corr, a.rmse, a.fitness) == (b.iterations, b.n_corr, b.rmse, b.fitness)
+    for o in (b, g2):
+        assert a.transformation.tobytes() == o.transformation.tobytes()
+        assert (a.iterations, a.n_corr, a.rmse, a.fitness) == (o.iterations, o.n_corr, o.rmse, o.fitness)
     ang0, _ = synth.pose_error(T0, T_gt); ang, tr = synth.pose_error(a.transformation, T_gt)
     print("C2: %d iterations, fitness %.3f, angle %.2e -> %.2e rad, translation %.2e m" % (a.iterations, a.fitness, ang0, ang, tr))
     assert ang < ang0 and ang < 2e-3 and tr < 2e-4

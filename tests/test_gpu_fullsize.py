@@ -65,26 +65,31 @@ def test_icp_200k_reproducible_and_converges(ctx, synth, clouds):
 
 
 def test_icp_pruned_search_200k_identical_to_scan(ctx, synth, clouds):
-    """Headline size: the pruned walk and the brute-force scan give the same accepted correspondences (all 200k rows)
-    and the same ICP result bit for bit."""
+    """Headline size: the pruned walk, the hash grid and the brute-force scan give the same accepted correspondences
+    (all 200k rows) and the same ICP result bit for bit — at a threshold of four point spacings (the grid hands over to
+    the walk: some 30 points per cell) and at the reference's 0.4 spacings (the grid's own regime)."""
     src, tgt, nrm, T_gt = clouds
-    T0 = synth.perturb(T_gt)
-    try:
-        ctx.set_icp_search("brute")
-        cb = ctx.icp_correspondences(src, tgt, T0, 0.003)
-        a = ctx.icp(src, tgt, nrm, T0, 0.003, 12, True)
-        ctx.set_icp_search("pruned")
-        cp = ctx.icp_correspondences(src, tgt, T0, 0.003)
-        b = ctx.icp(src, tgt, nrm, T0, 0.003, 12, True)
-    finally:
-        ctx.set_icp_search("auto")
-    acc = cb["accepted"].astype(bool)
-    assert acc.sum() > N // 4
-    assert np.array_equal(cp["accepted"], cb["accepted"]) and cp["n_corr"] == cb["n_corr"]
-    assert np.array_equal(cp["corr"][acc], cb["corr"][acc])
-    assert cp["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
-    assert a.transformation.tobytes() == b.transformation.tobytes()
-    assert (a.iterations, a.n_corr, a.rmse, a.fitness) == (b.iterations, b.n_corr, b.rmse, b.fitness)
+    for thr, T0, grid_runs in ((0.003, synth.perturb(T_gt), False),
+                               (0.4 * float(synth.mean_spacing(N)), synth.perturb(T_gt, angle_deg=0.05, trans=0.0001), True)):
+        try:
+            ctx.set_icp_search("brute")
+            cb = ctx.icp_correspondences(src, tgt, T0, thr)
+            a = ctx.icp(src, tgt, nrm, T0, thr, 12, True)
+            others = {}
+            for mode in ("pruned", "grid"):
+                ctx.set_icp_search(mode)
+                others[mode] = (ctx.icp_correspondences(src, tgt, T0, thr), ctx.icp(src, tgt, nrm, T0, thr, 12, True), ctx.last_icp_search())
+        finally:
+            ctx.set_icp_search("auto")
+        acc = cb["accepted"].astype(bool)
+        assert acc.sum() > (N // 4 if not grid_runs else N // 100)
+        for mode, (cp, b, used) in others.items():
+            assert used == (mode if grid_runs else "pruned")
+            assert np.array_equal(cp["accepted"], cb["accepted"]) and cp["n_corr"] == cb["n_corr"]
+            assert np.array_equal(cp["corr"][acc], cb["corr"][acc])
+            assert cp["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
+            assert a.transformation.tobytes() == b.transformation.tobytes()
+            assert (a.iterations, a.n_corr, a.rmse, a.fitness) == (b.iterations, b.n_corr, b.rmse, b.fitness)
 
 
 def test_feature_match_100k_sampled(ctx, orc, synth):
@@ -196,14 +201,17 @@ def test_searches_500k_sampled(ctx, orc, synth):
     try:
         ctx.set_icp_search("brute")
         cb = ctx.icp_correspondences(src, pts, T0, thr)
-        ctx.set_icp_search("pruned")
-        cp = ctx.icp_correspondences(src, pts, T0, thr)
+        cps = []
+        for mode in ("pruned", "grid"):
+            ctx.set_icp_search(mode)
+            cps.append(ctx.icp_correspondences(src, pts, T0, thr))
     finally:
         ctx.set_icp_search("auto")
     acc = cb["accepted"].astype(bool)
     assert acc.sum() > n // 4
-    assert np.array_equal(cp["accepted"], cb["accepted"]) and cp["n_corr"] == cb["n_corr"]
-    assert np.array_equal(cp["corr"][acc], cb["corr"][acc])
-    assert cp["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
+    for cp in cps:
+        assert np.array_equal(cp["accepted"], cb["accepted"]) and cp["n_corr"] == cb["n_corr"]
+        assert np.array_equal(cp["corr"][acc], cb["corr"][acc])
+        assert cp["d2"][acc].tobytes() == cb["d2"][acc].tobytes()
     ref = orc.icp_correspondences(src[sel], pts, None, T0, thr, point_to_plane=False)
     assert np.array_equal(cb["corr"][sel], ref["corr"]) and cb["d2"][sel].tobytes() == ref["d2"].tobytes()

@@ -77,8 +77,8 @@ def test_radius_lists_fuzz(ctx, orc, kind):
 def test_icp_pruned_correspondences_fuzz(ctx, orc, synth, kind):
     rng = np.random.default_rng(zlib.crc32(kind.encode()) + 2)
     try:
-        ctx.set_icp_search("pruned")
-        for trial in range(3):
+        for trial in range(6):
+            ctx.set_icp_search("pruned" if trial % 2 == 0 else "grid")
             ns, nt = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
             tgt = _make(kind, nt, rng)
             src = _make(kind, ns, rng)

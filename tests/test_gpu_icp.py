@@ -128,9 +128,11 @@ def test_gpu_registration_operator_api(tdv, orc, synth):
 
 # ---- exact pruned correspondence search (same results as the scan, bit for bit) -------------------------------
 
-@pytest.fixture
-def pruned(ctx):
-    ctx.set_icp_search("pruned")
+@pytest.fixture(params=["pruned", "grid"])
+def pruned(ctx, request):
+    """The two exact searches that replace the scan: the box walk, and the hash grid (which hands over to the walk when
+    the threshold is large against the spacing - those cases then test the hand-over)."""
+    ctx.set_icp_search(request.param)
     yield ctx
     ctx.set_icp_search("auto")
 
@@ -150,6 +152,9 @@ def test_pruned_search_matches_oracle(pruned, orc, synth, ns, nt, thr):
     assert got["n_corr"] == ref["n_corr"]
     if thr >= 10.0:
         assert acc.all()   # loose threshold: the seeded walk still returns the true nearest neighbour of every point
+        assert pruned.last_icp_search() == "pruned"      # far too many points per cell for the grid
+    if pruned.icp_search_name == "grid" and (ns, nt, thr) in ((3000, 2000, 0.004), (4097, 1031, 0.004), (6000, 5000, 1e-4)):
+        assert pruned.last_icp_search() == "grid"
 
 
 def test_pruned_search_ties_lowest_index(pruned, orc, synth):
@@ -186,11 +191,16 @@ def test_icp_pruned_and_brute_identical_bits(ctx, synth, p2plane, thr):
         a = ctx.icp(src, tgt, nrm, T0, thr, 30, p2plane)
         ctx.set_icp_search("pruned")
         b = ctx.icp(src, tgt, nrm, T0, thr, 30, p2plane)
+        ctx.set_icp_search("grid")
+        c = ctx.icp(src, tgt, nrm, T0, thr, 30, p2plane)
+        used = ctx.last_icp_search()
     finally:
         ctx.set_icp_search("auto")
-    assert a.transformation.tobytes() == b.transformation.tobytes()
-    assert (a.iterations, a.n_corr) == (b.iterations, b.n_corr)
-    assert a.rmse == b.rmse and a.fitness == b.fitness
+    for o in (b, c):
+        assert a.transformation.tobytes() == o.transformation.tobytes()
+        assert (a.iterations, a.n_corr) == (o.iterations, o.n_corr)
+        assert a.rmse == o.rmse and a.fitness == o.fitness
+    assert used == ("grid" if thr == 0.004 else "pruned")   # 7,000 points of the cuboid are 3.6 mm apart: 0.05 m puts hundreds into a cell
 
 
 @pytest.mark.parametrize("thr", [0.0, -1.0, 1e-30, 1e18])

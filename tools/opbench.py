@@ -153,12 +153,14 @@ def icp_c2(ctx, tdv, synth, torch, dev, reps=3):
     d_s = torch.from_numpy(src).to(dev); d_t = torch.from_numpy(tgt).to(dev); d_n = torch.from_numpy(nrm).to(dev)
     thr = 0.4 * float(synth.mean_spacing(nt))
     out = []
-    for search in ("pruned", "brute"):
+    for search in ("grid", "pruned", "brute"):
         ctx.set_icp_search(search)
         wall = median_ms(lambda: ctx.icp_dev(d_s.data_ptr(), ns, d_t.data_ptr(), d_n.data_ptr(), nt, T0, thr, iters, True, fixed_iterations=True), torch, reps=reps)
-        e = dict(op="icp_c2", workload="C2: 50,000 x 10,000, point-to-plane, %d fixed iterations, threshold 0.4 x spacing, %s search" % (iters, search),
-                 ms=wall, iters_per_s=iters / (wall * 1e-3))
-        out.append(valu(e, 8.0 * ns * nt * iters, wall) if search == "brute" else pruned(e, 8.0 * ns * nt * iters, wall, "box walk"))
+        used = ctx.last_icp_search()
+        e = dict(op="icp_c2", workload="C2: 50,000 x 10,000, point-to-plane, %d fixed iterations, threshold 0.4 x spacing, %s search%s"
+                 % (iters, used, " (what AUTO picks)" if search == "grid" else ""), ms=wall, iters_per_s=iters / (wall * 1e-3))
+        out.append(valu(e, 8.0 * ns * nt * iters, wall) if search == "brute"
+                   else pruned(e, 8.0 * ns * nt * iters, wall, "box walk" if used == "pruned" else "hash grid, cells of 2.2 x the threshold"))
     ctx.set_icp_search("auto")
     return out
 
