@@ -207,6 +207,14 @@ int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode) {
     return TDV_OK;
 }
 
+int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode) {
+    if (!ctx || (mode != TDV_RANSAC_SCORE_FAST && mode != TDV_RANSAC_SCORE_EXACT)) return TDV_ERR_BAD_ARG;
+    ctx->ransac_score_exact = mode == TDV_RANSAC_SCORE_EXACT;
+    return TDV_OK;
+}
+
+double tdv_ctx_last_ransac_rescore(tdv_ctx* ctx) { return ctx ? ctx->last_ransac_rescore : -1.0; }
+
 int tdv_ctx_last_icp_search(tdv_ctx* ctx) { return ctx ? ctx->last_icp_search : 0; }
 
 int tdv_ctx_set_stream(tdv_ctx* ctx, void* s) {

@@ -23,6 +23,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstring>
 #include <algorithm>
 #include <vector>
 
@@ -33,28 +34,44 @@ namespace tdv {
 // p = 0 and q = +inf so that d2 = +inf and they are never inliers.
 // A correspondence outside [0, nt) (caller-supplied lists are not trusted) raises *bad and reads target 0 instead of
 // faulting; the host turns the flag into TDV_ERR_BAD_ARG at its first synchronisation.
+// *pmax receives (integer atomic max on the bits of a non-negative float) the largest |source coordinate|, +inf for a
+// non-finite one or a NaN in a matched target: it scales the rounding band of the fast scoring pass (k_ransac_score_fast).
 __global__ void k_gather_pq(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr,
-                            int ns, int ns_pad, int nt, float* __restrict__ pq, int* __restrict__ bad) {
+                            int ns, int ns_pad, int nt, float* __restrict__ pq, int* __restrict__ bad, unsigned* __restrict__ pmax) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ns_pad) return;
-    float4 a, b;
-    if (i < ns) {
-        int c = corr[i];
-        if ((unsigned)c >= (unsigned)nt) { *bad = 1; c = 0; }
-        a = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], tgt[3 * c]);
-        b = make_float4(tgt[3 * c + 1], tgt[3 * c + 2], 0.f, 0.f);
-    } else {
-        a = make_float4(0.f, 0.f, 0.f, INFINITY);
-        b = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+    float am = 0.f;
+    if (i < ns_pad) {
+        float4 a, b;
+        if (i < ns) {
+            int c = corr[i];
+            if ((unsigned)c >= (unsigned)nt) { *bad = 1; c = 0; }
+            a = make_float4(src[3 * i], src[3 * i + 1], src[3 * i + 2], tgt[3 * c]);
+            b = make_float4(tgt[3 * c + 1], tgt[3 * c + 2], 0.f, 0.f);
+            am = fmaxf(fabsf(a.x), fmaxf(fabsf(a.y), fabsf(a.z)));
+            if (!(am <= FLT_MAX)) am = INFINITY;      // NaN or inf
+            // a NaN target coordinate makes d2 NaN, whose sign bit the fast pass would read as "inlier": such a cloud is
+            // scored with the reference arithmetic throughout (an infinite one gives d2 = +inf in both and is harmless)
+            if (a.w != a.w || b.x != b.x || b.y != b.y) am = INFINITY;
+        } else {
+            a = make_float4(0.f, 0.f, 0.f, INFINITY);
+            b = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+        }
+        reinterpret_cast<float4*>(pq)[2 * (size_t)i] = a;
+        reinterpret_cast<float4*>(pq)[2 * (size_t)i + 1] = b;
     }
-    reinterpret_cast<float4*>(pq)[2 * (size_t)i] = a;
-    reinterpret_cast<float4*>(pq)[2 * (size_t)i + 1] = b;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(pmax, __float_as_uint(am));
 }
 
-// hyp layout: SoA [12][h_pad]: r00 r10 r20 r01 r11 r21 r02 r12 r22 t0 t1 t2 (column-major R).
+__device__ __forceinline__ float tau_mid_default(float sqrt_tau) { return sqrt_tau * sqrt_tau; }
+
+// hyp layout: SoA [14][h_pad]: r00 r10 r20 r01 r11 r21 r02 r12 r22 t0 t1 t2 (column-major R).
 // Invalid (skipped) iterations get NaN so that no comparison is ever true -> 0 inliers.
+// Rows 12, 13 of hyp: the band of the fast scoring pass for this hypothesis (RansacBand below): mid and half-width of
+// the d2 interval inside which the FMA arithmetic and the reference's arithmetic might disagree on `d2 < tau`.
 __global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __restrict__ triples, int count, int h_pad,
-                                    float* __restrict__ hyp) {
+                                    float* __restrict__ hyp, const unsigned* __restrict__ pmax, float sqrt_tau) {
     int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= h_pad) return;
     float o[12];
@@ -94,6 +111,32 @@ __global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) hyp[(size_t)k * h_pad + h] = o[k];
+    // RansacBand.  x_ref = fl((r0 px + (r1 py + r2 pz)) + t) and x_fma = fma(r0, px, fma(r1, py, fma(r2, pz, t))) are both
+    // within gamma_4 resp. gamma_3 of the real value relative to A = |r0||px| + |r1||py| + |r2||pz| + |t| (u = 2^-24), so
+    // they differ by at most 7.1 u A per component; the subtraction of q, the squared norm (three terms, either order)
+    // and the square root add relative errors of a few u.  In distance: |sqrt(d2_ref) - sqrt(d2_fma)| <= 12.3 u A + 12 u s
+    // for distances up to 2 s, s = sqrt(tau).  E = 16 u (A + s) with A bounded over all points by the largest |source
+    // coordinate|; outside [(s - E)^2, (s + E)^2] (widened by 1e-6) both arithmetics give the same side of `d2 < tau`.
+    // A band that is not small against s (coordinates far from the origin, non-finite data, an invalid hypothesis) is
+    // stored as NaN: every chunk of such a lane's wave is then scored with the reference arithmetic.
+    // (a skipped iteration or a padding lane has no band at all - half = 0 - so that it never makes its wave score a chunk
+    // twice; its count is garbage and the host never reads it)
+    float mid = tau_mid_default(sqrt_tau), half = valid ? __builtin_nanf("") : 0.f;
+    if (valid) {
+        const float P = __uint_as_float(*pmax);
+        float A = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) A = fmaxf(A, (fabsf(o[c]) + fabsf(o[3 + c]) + fabsf(o[6 + c])) * P + fabsf(o[9 + c]));
+        const float E = (9.5367431640625e-07f * A + 9.5367431640625e-07f * sqrt_tau) * 1.0001f;
+        if (E < 0.25f * sqrt_tau) {
+            const float lo = sqrt_tau - E, hi = sqrt_tau + E;
+            const float tlo = lo * lo * (1.0f - 1e-6f), thi = hi * hi * (1.0f + 1e-6f);
+            mid = 0.5f * (tlo + thi);
+            half = 0.5f * (thi - tlo) * (1.0f + 1e-5f) + mid * 1e-6f;
+        }
+    }
+    hyp[(size_t)12 * h_pad + h] = mid;
+    hyp[(size_t)13 * h_pad + h] = half;
 }
 
 // ------------------------------------------------------------------ scoring
@@ -155,6 +198,69 @@ void k_ransac_score(const float* __restrict__ hyp, int h_pad, const float* __res
         }
     }
     atomicAdd(&counts[base], cnt);
+}
+
+// The same counts from half the arithmetic.  Parity forbids FMA contraction in the reference's expression, but only
+// its RESULT - which side of tau each d2 falls on - has to be reproduced.  This pass evaluates every (hypothesis, point)
+// with fused multiply-adds (15 packed instructions per two points instead of 26) and classifies by the sign of
+// d2_fma - mid; a test whose d2_fma lies inside the hypothesis' rounding band (RansacBand in k_ransac_hypotheses: the
+// two arithmetics provably agree outside it) makes its wave score that chunk of 8 points again with the reference
+// arithmetic.  The band is about 1e-3 of the threshold wide at metre-scale coordinates, so this happens for a percent or
+// so of the chunks; counts are identical to k_ransac_score's (tests/test_gpu_ransac.py holds the two against each other
+// and against the oracle).
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__global__ __launch_bounds__(RS_BLOCK)
+void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq2,
+                         int n_pchunks, int pchunks_per_split, float tau, int* __restrict__ counts, unsigned long long* __restrict__ rescored) {
+    const int split = blockIdx.y;
+    const int c0 = split * pchunks_per_split;
+    const int c1 = min(n_pchunks, c0 + pchunks_per_split);
+    const int base = blockIdx.x * RS_BLOCK + threadIdx.x;
+    v2f r[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) { const float t = hyp[(size_t)e * h_pad + base]; r[e] = (v2f){t, t}; }
+    const float mid = hyp[(size_t)12 * h_pad + base], half = hyp[(size_t)13 * h_pad + base];
+    const v2f nmid = {-mid, -mid};
+    int cnt = 0;
+    unsigned n_rescored = 0;     // wave-uniform
+    for (int c = c0; c < c1; ++c) {
+        const float* __restrict__ g = pq2 + (size_t)c * (6 * RS_PCH);  // RS_PCH points = RS_PCH/2 records of 12 floats, wave-uniform
+        float v[6 * RS_PCH];
+#pragma unroll
+        for (int e = 0; e < 6 * RS_PCH; ++e) v[e] = g[e];
+        float m = INFINITY;      // smallest |d2_fma - mid| of this lane in the chunk
+        int cf = 0;
+#pragma unroll
+        for (int p = 0; p < RS_PCH / 2; ++p) {
+            const v2f px = {v[12 * p + 0], v[12 * p + 1]}, py = {v[12 * p + 2], v[12 * p + 3]}, pz = {v[12 * p + 4], v[12 * p + 5]};
+            const v2f qx = {v[12 * p + 6], v[12 * p + 7]}, qy = {v[12 * p + 8], v[12 * p + 9]}, qz = {v[12 * p + 10], v[12 * p + 11]};
+            const v2f dx = fma2(r[0], px, fma2(r[3], py, fma2(r[6], pz, r[9]))) - qx;
+            const v2f dy = fma2(r[1], px, fma2(r[4], py, fma2(r[7], pz, r[10]))) - qy;
+            const v2f dz = fma2(r[2], px, fma2(r[5], py, fma2(r[8], pz, r[11]))) - qz;
+            const v2f t = fma2(dx, dx, fma2(dy, dy, dz * dz)) + nmid;
+            m = fminf(m, fminf(fabsf(t.x), fabsf(t.y)));                       // a NaN (invalid hypothesis) leaves m alone: half is NaN there
+            cf += (int)(__float_as_uint(t.x) >> 31) + (int)(__float_as_uint(t.y) >> 31);   // d2_fma < mid
+        }
+        if (__any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
+            ++n_rescored;
+            cf = 0;
+#pragma unroll
+            for (int p = 0; p < RS_PCH / 2; ++p) {
+                const v2f px = {v[12 * p + 0], v[12 * p + 1]}, py = {v[12 * p + 2], v[12 * p + 3]}, pz = {v[12 * p + 4], v[12 * p + 5]};
+                const v2f qx = {v[12 * p + 6], v[12 * p + 7]}, qy = {v[12 * p + 8], v[12 * p + 9]}, qz = {v[12 * p + 10], v[12 * p + 11]};
+                const v2f x = (r[0] * px + (r[3] * py + r[6] * pz)) + r[9];
+                const v2f y = (r[1] * px + (r[4] * py + r[7] * pz)) + r[10];
+                const v2f z = (r[2] * px + (r[5] * py + r[8] * pz)) + r[11];
+                const v2f dx = x - qx, dy = y - qy, dz = z - qz;
+                const v2f d2 = dx * dx + (dy * dy + dz * dz);
+                cf += (d2.x < tau) ? 1 : 0;
+                cf += (d2.y < tau) ? 1 : 0;
+            }
+        }
+        cnt += cf;
+    }
+    atomicAdd(&counts[base], cnt);
+    if (n_rescored && (threadIdx.x & 63) == 0) atomicAdd(rescored, (unsigned long long)n_rescored);   // statistics only (tdv_ctx_last_ransac_rescore)
 }
 
 // error sum of one hypothesis (column-major R in T[0..8], t in T[9..11]) over all points
@@ -223,9 +329,16 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     float* pq = nullptr;
     TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 8, &pq));
     int* d_bad = nullptr;
-    TDV_TRY(ws_alloc(ctx, 1, &d_bad));
-    TDV_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, s));
-    k_gather_pq<<<(ns_pad + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, ns, ns_pad, nt, pq, d_bad);
+    TDV_TRY(ws_alloc(ctx, 4, &d_bad));
+    unsigned* d_pmax = reinterpret_cast<unsigned*>(d_bad + 1);
+    unsigned long long* d_rescored = reinterpret_cast<unsigned long long*>(d_bad + 2);
+    TDV_HIP(ctx, hipMemsetAsync(d_bad, 0, 16, s));
+    double wave_chunks = 0.0;    // wave x chunk pairs scored by the fast pass in this call
+    k_gather_pq<<<(ns_pad + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, ns, ns_pad, nt, pq, d_bad, d_pmax);
+    // sqrt(tau) rounded up: the boundary of `d2 < tau` in distance, for the band of the fast scoring pass
+    const float sqrt_tau = std::nextafter((float)std::sqrt((double)tau), INFINITY);
+    static const bool score_exact_env = getenv("TDV_RANSAC_SCORE") && !strcmp(getenv("TDV_RANSAC_SCORE"), "exact");
+    const bool score_fast = !score_exact_env && !ctx->ransac_score_exact;
     float* pq2 = nullptr;
     TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 6, &pq2));
     k_pack_pq2<<<(ns_pad / 2 + 255) / 256, 256, 0, s>>>(pq, ns_pad, pq2);
@@ -246,7 +359,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     float* hyp[2] = {nullptr, nullptr}; int* counts[2] = {nullptr, nullptr}; int4* d_tri[2] = {nullptr, nullptr};
     double* slabs = nullptr; double* d_out2 = nullptr; float* d_best12 = nullptr;
     for (int q = 0; q < 2; ++q) {
-        TDV_TRY(ws_alloc(ctx, (size_t)12 * h_pad, &hyp[q]));
+        TDV_TRY(ws_alloc(ctx, (size_t)14 * h_pad, &hyp[q]));
         TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &counts[q]));
         TDV_TRY(ws_alloc(ctx, (size_t)batch, &d_tri[q]));
     }
@@ -282,11 +395,15 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     auto enqueue = [&](int q, int cnt) -> int {     // device: hypotheses + scoring + counts back to the host
         TDV_HIP(ctx, hipMemcpyAsync(d_tri[q], h_tri[q], (size_t)cnt * 16, hipMemcpyHostToDevice, s));
         TDV_HIP(ctx, hipMemsetAsync(counts[q], 0, (size_t)h_pad * 4, s));
-        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q]);
+        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q], d_pmax, sqrt_tau);
         const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
         {
             ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
-            k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q]);
+            if (score_fast) {
+                k_ransac_score_fast<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q], d_rescored);
+                wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
+            }
+            else k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q]);
         }
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipMemcpyAsync(h_cnt[q], counts[q], (size_t)cnt * 4, hipMemcpyDeviceToHost, s));
@@ -328,6 +445,11 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         cur = nxt; it0 = it_next; cnt_cur = cnt_next;
     }
     (void)hipStreamSynchronize(s);   // a speculative batch may still be in flight after an early exit
+    ctx->last_ransac_rescore = -1.0;
+    if (score_fast && status == TDV_OK && wave_chunks > 0.0) {
+        unsigned long long h_res = 0;
+        if (hipMemcpy(&h_res, d_rescored, 8, hipMemcpyDeviceToHost) == hipSuccess) ctx->last_ransac_rescore = (double)h_res / wave_chunks;
+    }
     for (int q = 0; q < 2; ++q) event_release(ctx, ev[q]);
     if (status != TDV_OK) return status;
     out->iterations_run = done_iters;

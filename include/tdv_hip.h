@@ -65,6 +65,16 @@ void tdv_ctx_destroy(tdv_ctx* ctx);
 #define TDV_ICP_SEARCH_PRUNED 2
 #define TDV_ICP_SEARCH_GRID 3
 int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode);
+/* RANSAC hypothesis scoring.  FAST (default; env TDV_RANSAC_SCORE=exact overrides) evaluates every (hypothesis, point) with
+ * fused multiply-adds and re-scores, with the reference's unfused arithmetic, every chunk of points in which a distance
+ * falls inside the rounding band where the two could disagree: the inlier counts are those of EXACT, which runs the
+ * reference's arithmetic only (registration.cpp:270-279). */
+#define TDV_RANSAC_SCORE_FAST 0
+#define TDV_RANSAC_SCORE_EXACT 1
+int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode);
+/* Statistics of the last tdv_ransac* call on this ctx: the fraction of (wave, 8-point chunk) pairs the FAST pass scored a
+ * second time with the reference arithmetic (-1 if the call ran in EXACT mode or none has run). */
+double tdv_ctx_last_ransac_rescore(tdv_ctx* ctx);
 /* The search the last tdv_icp* / tdv_icp_correspondences call on this ctx ran (BRUTE, PRUNED or GRID; 0 before any). */
 int tdv_ctx_last_icp_search(tdv_ctx* ctx);
 const char* tdv_status_string(int status);

@@ -96,6 +96,75 @@ def test_ransac_inlier_counts_bit_exact(ctx, orc, synth):
     assert synth.rotation_angle(T_gt[:3, :3], got.transformation[:3, :3]) < 0.05
 
 
+def _both_modes(ctx, *a, **k):
+    """ransac in the default (fast: FMA pass + exact band) and in the exact scoring mode; + the fast pass's rescore share."""
+    try:
+        ctx.set_ransac_score("exact")
+        e = ctx.ransac(*a, **k); assert ctx.last_ransac_rescore() == -1.0
+        ctx.set_ransac_score("fast")
+        f = ctx.ransac(*a, **k); share = ctx.last_ransac_rescore()
+    finally:
+        ctx.set_ransac_score("fast")
+    return e, f, share
+
+
+@pytest.mark.parametrize("offset", [0.0, 3.0, 250.0, 1.0e5])
+def test_ransac_fast_scoring_equals_exact_scoring(ctx, orc, synth, offset):
+    """The FMA scoring pass with its rounding band gives the per-iteration inlier counts of the reference arithmetic:
+    against the exact kernel and the oracle, with the clouds moved away from the origin (the band grows with the
+    coordinates: at 250 m it is a third of the threshold, at 100 km it exceeds it and every chunk is scored exactly)."""
+    ns, nt = 6000, 3000
+    src, tgt, corr, T_gt = _case(synth, ns, nt, good_frac=0.7)
+    shift = np.array([offset, -0.5 * offset, 0.25 * offset], np.float32)
+    src = (src + shift).astype(np.float32); tgt = (tgt + shift).astype(np.float32)
+    voxel, iters = 0.004, 1500
+    e, f, share = _both_modes(ctx, src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=2.0, trace=True)
+    ref = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=2.0, trace=True)
+    assert np.array_equal(e.trace_inliers, ref["inliers"])
+    assert np.array_equal(f.trace_inliers, ref["inliers"]), np.nonzero(f.trace_inliers != ref["inliers"])[0][:10]
+    assert (f.best_iteration, f.inliers, f.fitness, f.rmse) == (e.best_iteration, e.inliers, e.fitness, e.rmse)
+    assert f.transformation.tobytes() == e.transformation.tobytes()
+    print("offset %g m: %.4f of the (wave, chunk) pairs scored twice" % (offset, share))
+    assert 0.0 <= share <= 1.0
+    if offset == 0.0: assert share < 0.6
+    if offset == 1.0e5: assert share >= 0.74     # every wave that holds a hypothesis (1,500 of the 2,048 lanes: 24 of 32 waves)
+
+
+def test_ransac_fast_scoring_points_on_the_threshold(ctx, orc, synth):
+    """Adversarial for the band: matched points placed at the threshold distance and within a few ulps of it, identity-like
+    hypotheses (an exact rigid copy), so that thousands of tests sit inside the band; plus non-finite points."""
+    rng = np.random.default_rng(3)
+    n = 4096
+    tgt, _ = synth.sample_object(n, 11)
+    src = tgt.copy()
+    voxel = 0.002
+    thr = np.float32(voxel * 1.5)
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    scale = np.full(n, thr, np.float64)
+    scale[: n // 4] *= 1.0 + rng.integers(-8, 9, n // 4) * 6e-8           # within a few ulps of the threshold
+    scale[n // 4: n // 2] *= rng.uniform(0.999, 1.001, n // 4)            # inside any band
+    scale[n // 2:] *= rng.uniform(0.0, 2.0, n - n // 2)
+    tgt2 = (tgt.astype(np.float64) + d * scale[:, None]).astype(np.float32)
+    tgt2[5] = [np.inf, 0, 0]; tgt2[6] = [np.nan, 0, 0]; src[7] = [np.nan, np.nan, np.nan]
+    corr = np.arange(n, dtype=np.int32)
+    e, f, share = _both_modes(ctx, src, tgt2, corr=corr, voxel=voxel, max_iterations=600, confidence=2.0, trace=True)
+    ref = orc.ransac(src, tgt2, corr=corr, voxel=voxel, max_iterations=600, confidence=2.0, trace=True)
+    assert np.array_equal(e.trace_inliers, ref["inliers"])
+    assert np.array_equal(f.trace_inliers, ref["inliers"])
+    assert share >= 0.58       # a non-finite source coordinate makes the band unbounded: every wave that holds a hypothesis scores exactly (600 of 1,024 lanes)
+    src[7] = src[8]
+    e, f, share = _both_modes(ctx, src, tgt2, corr=corr, voxel=voxel, max_iterations=600, confidence=2.0, trace=True)
+    ref = orc.ransac(src, tgt2, corr=corr, voxel=voxel, max_iterations=600, confidence=2.0, trace=True)
+    assert np.array_equal(e.trace_inliers, ref["inliers"]) and np.array_equal(f.trace_inliers, ref["inliers"])
+    assert share >= 0.58       # so does a NaN among the matched targets (its d2 is NaN: no sign to classify by)
+    tgt2[6] = [0.5, 0.5, 0.5]  # the infinite target stays: d2 = +inf in both arithmetics
+    e, f, share = _both_modes(ctx, src, tgt2, corr=corr, voxel=voxel, max_iterations=600, confidence=2.0, trace=True)
+    ref = orc.ransac(src, tgt2, corr=corr, voxel=voxel, max_iterations=600, confidence=2.0, trace=True)
+    assert np.array_equal(e.trace_inliers, ref["inliers"]) and np.array_equal(f.trace_inliers, ref["inliers"])
+    assert 0.0 < share < 1.0
+    print("threshold-shell case: %.3f of the (wave, chunk) pairs scored twice" % share)
+
+
 def test_ransac_early_exit_and_skips(ctx, orc, synth):
     """fitness > confidence stops the loop; repeated indices consume an iteration (registration.cpp:240,290)."""
     ns, nt = 40, 30  # tiny cloud: many repeated-index triples
