@@ -279,3 +279,54 @@ def test_mask_png_malformed_inputs_are_rejected(tdv, tmp_path):
         p.write_bytes(data)
         assert tdv.load_mask_png(str(p)) is None, name
     assert tdv.load_mask_png(str(tmp_path / "does_not_exist.png")) is None
+
+
+@pytest.mark.parametrize("offset", [0.0, 1.0, 40.0])
+def test_ransac_fast_scoring_band_covers_the_two_arithmetics(offset):
+    """csrc/ransac.hip RansacBand: the distance of a transformed point to its match evaluated the reference's way
+    (mul, mul, mul, add, add, add per row; squared norm in the reference's order) and the fast pass's way (fused multiply-
+    adds) differ by at most 12.3 u A + 3 u (D_ref + D_fma), A = max over the rows of |r0||px| + |r1||py| + |r2||pz| + |t|;
+    the kernel's band E = 16 u (A_max + sqrt(tau)) is larger for every distance up to twice the threshold.  Millions of
+    random cases in float32 (the fused ops emulated through float64: products of two floats are exact there), rotations
+    with and without noise, points on top of their matches and far from them, coordinates offset from the origin."""
+    rng = np.random.default_rng(17 + int(offset))
+    n = 1500000
+    u = 2.0 ** -24
+    q_, _ = np.linalg.qr(rng.normal(size=(n // 1000, 3, 3)))
+    R = np.repeat(q_, 1000, 0)[:n] + rng.normal(size=(n, 3, 3)) * rng.choice([0.0, 1e-7, 1e-3], (n, 1, 1))
+    R = _f32(R)
+    p = _f32((rng.random((n, 3)) - 0.5) * 0.6 + offset)
+    t = _f32(rng.normal(size=(n, 3)) * 0.3 - (R.astype(np.float64) @ np.full(3, offset)) + offset)
+    thr = 0.003
+    pr = np.einsum("nij,nj->ni", R.astype(np.float64), p.astype(np.float64)) + t          # real arithmetic (f64 is exact enough here)
+    dirs = rng.normal(size=(n, 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    dist = thr * rng.choice([0.0, 0.5, 0.999, 1.0, 1.001, 2.0], n) * (1 + rng.normal(size=n) * 1e-5)
+    q = _f32(pr + dirs * dist[:, None])
+
+    def row_ref(c):
+        a = _f32(R[:, c, 0] * p[:, 0]); b = _f32(R[:, c, 1] * p[:, 1]); cc = _f32(R[:, c, 2] * p[:, 2])
+        return _f32(_f32(a + _f32(b + cc)) + t[:, c])
+
+    def fma(a, b, c):
+        return _f32(a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64))
+
+    def row_fma(c):
+        return fma(R[:, c, 0], p[:, 0], fma(R[:, c, 1], p[:, 1], fma(R[:, c, 2], p[:, 2], t[:, c])))
+
+    dr = [_f32(row_ref(c) - q[:, c]) for c in range(3)]
+    df = [_f32(row_fma(c) - q[:, c]) for c in range(3)]
+    d2_ref = _f32(_f32(dr[0] * dr[0]) + _f32(_f32(dr[1] * dr[1]) + _f32(dr[2] * dr[2])))
+    d2_fma = fma(df[0], df[0], fma(df[1], df[1], _f32(df[2] * df[2])))
+    D_ref = np.sqrt(d2_ref.astype(np.float64)); D_fma = np.sqrt(d2_fma.astype(np.float64))
+    A = (np.abs(R.astype(np.float64)) * np.abs(p.astype(np.float64))[:, None, :]).sum(2) + np.abs(t.astype(np.float64))
+    A = A.max(1)
+    bound = 12.3 * u * A + 3 * u * (D_ref + D_fma)
+    ratio = np.abs(D_ref - D_fma) / np.maximum(bound, 1e-300)
+    print("offset %g: largest |D_ref - D_fma| / bound = %.3f" % (offset, ratio.max()))
+    assert ratio.max() <= 1.0
+    # the kernel's band: A bounded through the largest |coordinate| of the cloud, distances up to twice the threshold
+    P = np.abs(p).max()
+    A_kernel = (np.abs(R.astype(np.float64)).sum(2) * P + np.abs(t.astype(np.float64))).max(1)
+    E = 16 * u * (A_kernel + thr)
+    near = np.maximum(D_ref, D_fma) <= 2 * thr
+    assert (np.abs(D_ref - D_fma)[near] <= E[near]).all()
