@@ -238,7 +238,7 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
             const v2f dy = fma2(r[1], px, fma2(r[4], py, fma2(r[7], pz, r[10]))) - qy;
             const v2f dz = fma2(r[2], px, fma2(r[5], py, fma2(r[8], pz, r[11]))) - qz;
             const v2f t = fma2(dx, dx, fma2(dy, dy, dz * dz)) + nmid;
-            m = fminf(m, fminf(fabsf(t.x), fabsf(t.y)));                       // a NaN (invalid hypothesis) leaves m alone: half is NaN there
+            m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));                       // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
             cf += (int)(__float_as_uint(t.x) >> 31) + (int)(__float_as_uint(t.y) >> 31);   // d2_fma < mid
         }
         if (__any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
