@@ -666,6 +666,18 @@ __device__ __forceinline__ float box_bound(const float (&f)[FD], const float* __
     return lb;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// the descriptors of the K sources of every wave, interleaved: fsk[wave][d][k] = fs[sperm[K wave + k]][d] (a wave past the
+// end of an uneven count repeats the last source, as FmWave does): (q_k[d], q_k+1[d]) is then one aligned SGPR pair
+__global__ void k_fm_interleave_rows(const float* __restrict__ fs, const int* __restrict__ sperm, int ns, int K, float* __restrict__ fsk) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nwave = ((size_t)ns + K - 1) / K;
+    if (e >= nwave * K * FD) return;
+    const size_t w = e / ((size_t)K * FD); const int r = (int)(e % ((size_t)K * FD)), d = r / K, k = r % K;
+    fsk[e] = fs[(size_t)sperm[min((int)(K * w) + k, ns - 1)] * FD + d];
+}
+
 // ---- wave-level helpers (DPP: no LDS traffic) ----------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_f32(float v) {
@@ -700,6 +712,7 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 // Bounds only shrink, so a mask computed earlier can open a leaf too many, never skip one.
 struct FmTables {   // device pointers of a packed index + the per-call source-side arrays (plain struct: passed by value)
     const float* fs; const int* sperm; const int* home_of; int ns;
+    const float* fs2;   // even K: the descriptors of every wave's K sources interleaved, [wave][33][K] (k_fm_interleave_rows); else null
     const float* T; const int* torig; int nleaf, ngroup;
     const float *lbox, *gbox, *pbox, *gpbox;
     const float* sp; const unsigned *amax_t, *amax_s; float pscale;
@@ -713,6 +726,7 @@ struct FmWave {
     const FmTables& t;
     const int lane;
     int src[K];
+    const float* q2 = nullptr;    // even K: this wave's interleaved sources, [33][K] (wave-uniform)
     unsigned long long lkey[K];   // this lane's best (distance bits : original index): unsigned order == (distance, index) order for distances >= 0
     float bound[K];
     float pmargin;
@@ -726,6 +740,7 @@ struct FmWave {
             src[k] = __builtin_amdgcn_readfirstlane(t.sperm[min(s0 + k, t.ns - 1)]);   // past the end: the last source again
             lkey[k] = (unsigned long long)__float_as_uint(FLT_MAX) << 32; bound[k] = FLT_MAX;   // registration.cpp:218-219: only dist < FLT_MAX is ever taken
         }
+        if (K % 2 == 0) q2 = t.fs2 + (size_t)(s0 / K) * (K * FD);
         home = min(t.nleaf - 1, max(0, __builtin_amdgcn_readfirstlane(t.home_of[src[K / 2]])));
         hg = home / FX_GROUP;
         // rounding margin of a principal-coordinate gap (principal_bound_note): 3e-5 * largest |x_d - mean_d| on either side
@@ -737,19 +752,53 @@ struct FmWave {
             for (int k = 0; k < K; ++k) bound[k] = fminf(bound[k], __int_as_float(__builtin_amdgcn_readfirstlane(s_bound[k])));
         }
     }
-    __device__ __forceinline__ void load_leaf(int leaf, float (&row)[FD], int& ro) const {
+    // a lane's row of a leaf: 33 floats kept as 17 aligned register pairs, so that the packed arithmetic below can name
+    // either half of a pair (op_sel) instead of the compiler giving every element a pair of its own
+    struct RowBuf { v2f p[(FD + 1) / 2]; __device__ __forceinline__ float at(int d) const { return (d & 1) ? p[d >> 1].y : p[d >> 1].x; } };
+    __device__ __forceinline__ void load_leaf(int leaf, RowBuf& row, int& ro) const {
         const float* __restrict__ blk = t.T + (size_t)leaf * (FD * FX_LEAF);
 #pragma unroll
-        for (int d = 0; d < FD; ++d) row[d] = blk[d * FX_LEAF + lane];
+        for (int d = 0; d < FD; ++d) { if (d & 1) row.p[d >> 1].y = blk[d * FX_LEAF + lane]; else row.p[d >> 1].x = blk[d * FX_LEAF + lane]; }
+        row.p[FD >> 1].y = 0.f;
         ro = t.torig[(size_t)leaf * FX_LEAF + lane];
     }
-    __device__ __forceinline__ void eval_leaf(const float (&row)[FD], int ro) {
+    __device__ __forceinline__ void eval_leaf(const RowBuf& row, int ro) {
+        if constexpr (K % 2 == 0) {
+            // two sources at once: every op one v_pk_*_f32 on (source k, source k + 1) - the same IEEE operations per
+            // element, half the instructions; the wave's descriptors sit interleaved in memory so that (q_k[d], q_k+1[d]) is
+            // one aligned SGPR pair
+            const float* __restrict__ qk = q2;   // (left to the compiler, the K x 33 values stay in SGPRs across leaves, a few of them
+                                                 // parked in VGPR lanes; re-reading them per leaf through the scalar cache doubled the time)
+            v2f dist[K / 2];
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
+            for (int j = 0; j < K / 2; ++j) dist[j] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int d = 0; d < FD; ++d) {
+                const v2f pr = row.p[d >> 1];
+                const v2f rw = (d & 1) ? __builtin_shufflevector(pr, pr, 1, 1) : __builtin_shufflevector(pr, pr, 0, 0);
+#pragma unroll
+                for (int j = 0; j < K / 2; ++j) {
+                    const v2f q = {qk[K * d + 2 * j], qk[K * d + 2 * j + 1]};
+                    const v2f diff = q - rw;          // registration.cpp:222-224
+                    dist[j] += diff * diff;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) {
+                const unsigned long long k0 = ((unsigned long long)__float_as_uint(dist[j].x) << 32) | (unsigned)ro;
+                const unsigned long long k1 = ((unsigned long long)__float_as_uint(dist[j].y) << 32) | (unsigned)ro;
+                lkey[2 * j] = k0 < lkey[2 * j] ? k0 : lkey[2 * j];
+                lkey[(2 * j + 1) % K] = k1 < lkey[(2 * j + 1) % K] ? k1 : lkey[(2 * j + 1) % K];
+            }
+            ++n_open;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < K && K % 2 != 0; ++k) {
             const float* __restrict__ q = t.fs + (size_t)src[k] * FD;   // wave-uniform -> scalar loads
             float dist = 0.f;
 #pragma unroll
-            for (int d = 0; d < FD; ++d) { const float diff = q[d] - row[d]; dist += diff * diff; }   // registration.cpp:222-224
+            for (int d = 0; d < FD; ++d) { const float diff = q[d] - row.at(d); dist += diff * diff; }   // registration.cpp:222-224
             // strict < on (distance, index): the lowest index among equal distances; NaN and +inf have larger bit patterns than
             // FLT_MAX and are never taken, like `dist < best_dist` in the reference
             const unsigned long long key = ((unsigned long long)__float_as_uint(dist) << 32) | (unsigned)ro;
@@ -769,7 +818,7 @@ struct FmWave {
         }
     }
     __device__ __forceinline__ void open_leaf(int leaf) {
-        float row[FD]; int ro;
+        RowBuf row; int ro;
         load_leaf(leaf, row, ro);
         eval_leaf(row, ro);
     }
@@ -804,8 +853,27 @@ struct FmWave {
         float lb[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) lb[k] = 0.f;
+        if constexpr (K % 2 == 0) {       // packed over pairs of sources, as in eval_leaf
+            const float* __restrict__ qk = q2;
+            v2f lb2[K / 2];
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) lb2[j] = (v2f){0.f, 0.f};
+#pragma unroll 11
+            for (int d = 0; d < FD; ++d) {
+                const float lo = blk[d * 64 + lane], hi = blk[(FD + d) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < K / 2; ++j) {
+                    const v2f q = {qk[K * d + 2 * j], qk[K * d + 2 * j + 1]};
+                    const v2f a = (v2f){lo, lo} - q, b = q - (v2f){hi, hi};
+                    const v2f g = {fmaxf(fmaxf(a.x, b.x), 0.f), fmaxf(fmaxf(a.y, b.y), 0.f)};
+                    lb2[j] += g * g;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K / 2; ++j) { lb[2 * j] = lb2[j].x; lb[(2 * j + 1) % K] = lb2[j].y; }
+        } else
 #pragma unroll 11   // 22 loads in flight; full unrolling hoists all 66 and spills
-        for (int d = 0; d < FD; ++d) {   // one dimension of the 64 boxes at a time: two coalesced loads, K bounds advance
+        for (int d = 0; d < FD && K % 2 != 0; ++d) {   // one dimension of the 64 boxes at a time: two coalesced loads, K bounds advance
             const float lo = blk[d * 64 + lane], hi = blk[(FD + d) * 64 + lane];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -849,7 +917,7 @@ struct FmWave {
         };
         int cur = next();
         if (cur < 0) return true;
-        float a[FD], b[FD]; int roa, rob = 0;
+        RowBuf a, b; int roa, rob = 0;
         load_leaf(cur, a, roa);
         for (;;) {
             if (n_open >= budget) return false;
@@ -1294,9 +1362,16 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     k_fm_bucket_hist<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, hist);
     TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
     k_fm_scatter<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, start, cursor, sperm);
-    FmTables t{d_fs, sperm, home, ns, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, ix.pbox, ix.gpbox, sp, ix.amax, amax_s, ix.pscale};
     static const int force_k = getenv("TDV_FM_K") ? atoi(getenv("TDV_FM_K")) : 0;   // tuning knob (sources per wave)
     const int k = force_k ? force_k : 2;
+    float* fs2 = nullptr;
+    if (k >= 2) {
+        const int kk = k >= 4 ? 4 : 2;
+        const size_t n2 = ((size_t)ns + kk - 1) / kk * kk * FD;
+        TDV_TRY(ws_alloc(ctx, n2, &fs2));
+        k_fm_interleave_rows<<<(unsigned)((n2 + 255) / 256), 256, 0, s>>>(d_fs, sperm, ns, kk, fs2);
+    }
+    FmTables t{d_fs, sperm, home, ns, fs2, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, ix.pbox, ix.gpbox, sp, ix.amax, amax_s, ix.pscale};
     if (k >= 4) return launch_fm_query<4>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
     if (k >= 2) return launch_fm_query<2>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
     return launch_fm_query<1>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
