@@ -440,9 +440,14 @@ __global__ void k_fm_project(const float* __restrict__ f, int n, const float* __
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, am = 0.f;
     if (i < n) { principal_coords(f + (size_t)i * FD, basis, a0, a1, a2, am); p0[i] = a0; p1[i] = a1; p2[i] = a2; }
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(am));
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, __float_as_uint(am));
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax, s_max);
 }
 
 // Bit-identical target rows (the descriptor of a flat patch: a quarter of the relief model's rows are two such values)
@@ -628,11 +633,16 @@ __global__ void k_fm_locate(const float* __restrict__ fs, int ns, const float* _
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, am = 0.f;
     if (i < ns) principal_coords(fs + (size_t)i * FD, basis, a0, a1, a2, am);
-    {
+    {   // one atomic per workgroup (per wave they queue on one address for longer than the kernel's own work takes)
+        __shared__ unsigned s_max;
+        if (threadIdx.x == 0) s_max = 0u;
+        __syncthreads();
         float wm = am;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wm = fmaxf(wm, __shfl_xor(wm, off, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(wm));
+        if ((threadIdx.x & 63) == 0) atomicMax(&s_max, __float_as_uint(wm));
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(amax, s_max);
     }
     if (i >= ns) return;
     *reinterpret_cast<float4*>(sp + (size_t)i * 4) = make_float4(a0, a1, a2, 0.f);

@@ -59,9 +59,15 @@ __global__ void k_gather_pq(const float* __restrict__ src, const float* __restri
         reinterpret_cast<float4*>(pq)[2 * (size_t)i] = a;
         reinterpret_cast<float4*>(pq)[2 * (size_t)i + 1] = b;
     }
+    // one atomic per workgroup: thousands of them on one address would cost more than the gather itself
+    __shared__ unsigned s_max;
+    if (threadIdx.x == 0) s_max = 0u;
+    __syncthreads();
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(pmax, __float_as_uint(am));
+    if ((threadIdx.x & 63) == 0 && am > 0.f) atomicMax(&s_max, __float_as_uint(am));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_max) atomicMax(pmax, s_max);
 }
 
 __device__ __forceinline__ float tau_mid_default(float sqrt_tau) { return sqrt_tau * sqrt_tau; }
@@ -260,7 +266,13 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
         cnt += cf;
     }
     atomicAdd(&counts[base], cnt);
-    if (n_rescored && (threadIdx.x & 63) == 0) atomicAdd(rescored, (unsigned long long)n_rescored);   // statistics only (tdv_ctx_last_ransac_rescore)
+    // statistics only (tdv_ctx_last_ransac_rescore): one atomic per workgroup
+    __shared__ unsigned s_rescored;
+    if (threadIdx.x == 0) s_rescored = 0u;
+    __syncthreads();
+    if (n_rescored && (threadIdx.x & 63) == 0) atomicAdd(&s_rescored, n_rescored);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rescored) atomicAdd(rescored, (unsigned long long)s_rescored);
 }
 
 // error sum of one hypothesis (column-major R in T[0..8], t in T[9..11]) over all points
