@@ -645,9 +645,12 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     const GridEntry* gtable = cg.usable ? reinterpret_cast<const GridEntry*>(cg.table) : nullptr;
     const float4* gnode = cg.usable ? reinterpret_cast<const float4*>(cg.node) : nullptr;
     const dim3 grid(p.blocks_x, p.nsplit);
-    const int poll = 8;
+    // iterations are enqueued in bursts between two looks at the state; once `done` is set the remaining launches of a burst
+    // return at once.  The reference's stopping rule fires after 3-4 iterations in the pipeline's setting (0.4-voxel
+    // threshold from a RANSAC start), so the first burst is short; fixed-iteration runs take long bursts.
     int it = 0;
     while (it < max_iterations) {
+        const int poll = fixed_iterations ? 32 : (it == 0 ? 4 : 8);
         int burst = std::min(poll, max_iterations - it);
         for (int k = 0; k < burst; ++k) {
             {
