@@ -458,13 +458,15 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     }
     (void)hipStreamSynchronize(s);   // a speculative batch may still be in flight after an early exit
     ctx->last_ransac_rescore = -1.0;
-    if (score_fast && status == TDV_OK && wave_chunks > 0.0) {
-        unsigned long long h_res = 0;
-        if (hipMemcpy(&h_res, d_rescored, 8, hipMemcpyDeviceToHost) == hipSuccess) ctx->last_ransac_rescore = (double)h_res / wave_chunks;
-    }
     for (int q = 0; q < 2; ++q) event_release(ctx, ev[q]);
     if (status != TDV_OK) return status;
     out->iterations_run = done_iters;
+    // statistics of the fast pass: read back on the ctx's stream with the final results (h_o2[2] is free: out2 is 2 doubles of 64 B)
+    unsigned long long* h_res = reinterpret_cast<unsigned long long*>(h_o2 + 4);
+    *h_res = 0;
+    const bool want_stats = score_fast && wave_chunks > 0.0;
+    if (want_stats) TDV_HIP(ctx, hipMemcpyAsync(h_res, d_rescored, 8, hipMemcpyDeviceToHost, s));
+    if (best_iter < 0 && want_stats) TDV_HIP(ctx, hipStreamSynchronize(s));
     if (best_iter >= 0) {
         k_ransac_rmse_partial<<<rblocks, 256, 0, s>>>(pq, ns, d_best12, tau, slabs);
         k_ransac_rmse_final<<<1, 256, 0, s>>>(slabs, rblocks, d_out2);
@@ -472,6 +474,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         TDV_HIP(ctx, hipMemcpyAsync(h_b12, d_best12, 48, hipMemcpyDeviceToHost, s));
         TDV_HIP(ctx, hipMemcpyAsync(h_o2, d_out2, 16, hipMemcpyDeviceToHost, s));
         TDV_HIP(ctx, hipStreamSynchronize(s));
+        if (want_stats) ctx->last_ransac_rescore = (double)*h_res / wave_chunks;
         for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) out->T[c * 4 + r] = h_b12[c * 3 + r];
         out->T[12] = h_b12[9]; out->T[13] = h_b12[10]; out->T[14] = h_b12[11];
         out->fitness = best_fitness;
@@ -483,6 +486,8 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
             snprintf(ctx->err, sizeof(ctx->err), "ransac: rmse pass counted %d inliers, scoring pass %d", (int)(h_o2[1] + 0.5), best_inliers);
             return TDV_ERR_INTERNAL;
         }
+    } else if (want_stats) {
+        ctx->last_ransac_rescore = (double)*h_res / wave_chunks;
     }
     return TDV_OK;
 }
