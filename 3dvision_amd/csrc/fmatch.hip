@@ -223,6 +223,18 @@ __global__ void k_fm_boxes(const float* __restrict__ T, int nt, int nbox, float*
     bmin[e] = mn; bmax[e] = mx;
 }
 
+// The set bit of m nearest to position c, the higher one on a tie (the inside-out order c, c+1, c-1, c+2, ... restricted to
+// the set bits), or -1: two shifts, a find-first and a count-leading on the wave's scalar unit instead of walking the
+// positions one by one (that walk was 2,000 of the 4,800 instructions of a wave of the descriptor search).
+__device__ __forceinline__ int nearest_set_bit(unsigned long long m, int c) {
+    if (!m) return -1;
+    const unsigned long long up = m >> c;                                  // bit 0 = position c
+    const unsigned long long dn = c > 0 ? m << (64 - c) : 0ull;            // bit 63 = position c - 1
+    const int du = up ? __ffsll((long long)up) - 1 : 128;
+    const int dd = dn ? __clzll((long long)dn) + 1 : 128;
+    return du <= dd ? c + du : c - dd;
+}
+
 // box visited at position v of the inside-out order centred at box c (bijection onto [0, nbox))
 __device__ __forceinline__ int visit_inside_out(int v, int c, int nbox) {
     const int L = c, R = nbox - 1 - c;
@@ -915,15 +927,15 @@ struct FmWave {
     // Returns false when the leaf budget ran out before the group was finished (pass A: the caller gives the sources up).
     __device__ __forceinline__ bool visit_group(int g, unsigned budget = 0xffffffffu) {
         const int l0 = g * FX_GROUP, cnt = min(FX_GROUP, t.nleaf - l0);
+        if (cnt <= 0) return true;        // a group past the end: its empty box "passes" for a NaN query (every gap is NaN -> 0)
         unsigned long long m = leaf_mask(g);
         const int centre = (g == hg) ? home - l0 : (g < hg ? cnt - 1 : 0);   // enter a neighbouring group from the home side
-        int u = 0;
+        if (cnt < 64) m &= (1ull << cnt) - 1ull;
         auto next = [&]() -> int {
-            while (m && u < cnt) {
-                const int l = visit_inside_out(u++, centre, cnt);
-                if ((m >> l) & 1ull) { m &= ~(1ull << l); return l0 + l; }
-            }
-            return -1;
+            const int l = nearest_set_bit(m, centre);
+            if (l < 0) return -1;
+            m &= ~(1ull << l);
+            return l0 + l;
         };
         int cur = next();
         if (cur < 0) return true;
@@ -984,9 +996,9 @@ void k_fm_query(FmTables t, int blocks_per_xcd, int leaf_limit, int heavy_groups
         unsigned long long m = w.group_mask(c);
         const int g0 = c * 64, cnt = min(64, t.ngroup - g0);
         const int centre = w.hg < g0 ? 0 : (w.hg >= g0 + cnt ? cnt - 1 : w.hg - g0);
-        for (int u = 0; u < cnt && m; ++u) {
-            const int g = visit_inside_out(u, centre, cnt);
-            if (!((m >> g) & 1ull)) continue;
+        if (cnt < 64) m &= (1ull << cnt) - 1ull;
+        while (m) {
+            const int g = nearest_set_bit(m, centre);
             if ((int)w.n_open >= leaf_limit || !w.visit_group(g0 + g, (unsigned)leaf_limit)) {
                 overflow = true;
                 groups_left = __popcll(m) + 64 * (nchunk - 1 - c);
@@ -1061,6 +1073,7 @@ void k_fm_query_overflow(FmTables t, const int* __restrict__ overflow_count, con
 #pragma unroll
             for (int k = 0; k < K; ++k) w.bound[k] = keep[k];
             const int g0 = c * 64;
+            if (t.ngroup - g0 < 64) m &= (1ull << (t.ngroup - g0)) - 1ull;    // groups past the end (see visit_group)
             while (m) {
                 const int g = __builtin_ctzll(m);
                 m &= m - 1;

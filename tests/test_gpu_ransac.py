@@ -231,6 +231,16 @@ def test_feature_match_pruned_degenerate_rows(ctx, orc, synth):
     got = ctx.feature_match(fs, ft)
     ref = orc.feature_match(fs, ft)
     assert np.array_equal(got, ref)
+    # NaN sources open every box - the empty ones past the end of the index included (every gap is NaN -> 0) - run out of
+    # their leaf budget and take their wave-mates with them into the overflow passes: repeated, with the workspace in
+    # different states, so that a read past the tables shows
+    rng = np.random.default_rng(5)
+    for trial in range(8):
+        fs2 = fs.copy()
+        for i in rng.integers(0, ns, 6): fs2[i, rng.integers(0, 33)] = np.nan
+        fs2[rng.integers(0, ns)] = np.nan
+        ctx.feature_match(synth.random_features(4200 + 53 * trial, 30 + trial), synth.random_features(2300 + trial, 40))
+        assert np.array_equal(ctx.feature_match(fs2, ft), orc.feature_match(fs2, ft)), trial
     assert got[3] == 0 and got[10] == 0 and not np.isin(got[np.arange(ns) != 3], [77]).any()
 
 
