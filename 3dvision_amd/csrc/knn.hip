@@ -520,9 +520,9 @@ void k_fpfh(const float* __restrict__ xyz, int n, const int* __restrict__ order,
     const int lane = threadIdx.x & 63;
     const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * FP_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;   // wave-uniform
-    const int i = order[t];
+    const int i = __builtin_amdgcn_readfirstlane(order[t]);          // wave-uniform, and known to the compiler as such:
     const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
-    const int cnt = nbr_cnt[i];
+    const int cnt = __builtin_amdgcn_readfirstlane(nbr_cnt[i]);      // the loop conditions below stay on the scalar unit
     // neighbours r = lane and r = 64 + lane: index, weight 1/dist, or skipped (self, coincident point)
     int j[2]; float w[2]; bool use[2];
 #pragma unroll
@@ -537,24 +537,32 @@ void k_fpfh(const float* __restrict__ xyz, int n, const int* __restrict__ order,
             if (!(dist < 1e-8f)) { use[h] = true; w[h] = 1.0f / dist; }
         }
     }
-    const unsigned long long um0 = __ballot(use[0]), um1 = __ballot(use[1]);
     const int d = min(lane, 32);
     float f = spfh[(size_t)i * 33 + d];
-    // eight rows in flight per step (the gathers are latency-bound otherwise); the adds stay in list order
+    // Eight rows in flight per step (the gathers are latency-bound otherwise); the adds stay in list order.  The loop is
+    // bound by its instruction count, not by the rows' bytes (SQ counters: 817 vector + 731 scalar instructions per wave
+    // before, most of the scalar ones per-neighbour decoding): a neighbour's row offset and weight come out of the lanes
+    // with one v_readlane each, the address is one vector add on a fixed base, the list's two halves are walked separately,
+    // and an entry that is not to be added (self, a coincident point, the lanes past the end of the list) needs no test: its
+    // weight is +0 and its row offset 0, SPFH rows are finite and non-negative, so it adds w * val = +0 to a sum that is
+    // never -0 — the same bits as skipping it.
+    const unsigned row_off[2] = {use[0] ? (unsigned)j[0] * 33u : 0u, use[1] ? (unsigned)j[1] * 33u : 0u};   // in floats; < 2^32 for n < 1.3e8
     constexpr int FU = 8;
-    for (int r0 = 0; r0 < cnt; r0 += FU) {
-        float val[FU], wr[FU]; bool ok[FU];
 #pragma unroll
-        for (int u = 0; u < FU; ++u) {
-            const int r = r0 + u;
-            const int h = (r >> 6) & 1, l = r & 63;
-            ok[u] = r < cnt && (((h ? um1 : um0) >> l) & 1ull);   // wave-uniform
-            const int jr = __shfl(h ? j[1] : j[0], l, 64);
-            wr[u] = __shfl(h ? w[1] : w[0], l, 64);
-            val[u] = ok[u] ? spfh[(size_t)jr * 33 + d] : 0.f;
+    for (int h = 0; h < 2; ++h) {
+        const int nh = min(64, cnt - 64 * h);            // wave-uniform
+        for (int l0 = 0; l0 < nh; l0 += FU) {            // (nh <= 0: no pass)
+            float val[FU], wr[FU];
+#pragma unroll
+            for (int u = 0; u < FU; ++u) {
+                const int l = l0 + u;                    // <= 63: nh <= 64 and FU divides 64
+                const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)row_off[h], l) + (unsigned)d;
+                wr[u] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(w[h]), l));
+                val[u] = spfh[o];
+            }
+#pragma unroll
+            for (int u = 0; u < FU; ++u) f = f + wr[u] * val[u];
         }
-#pragma unroll
-        for (int u = 0; u < FU; ++u) f = ok[u] ? f + wr[u] * val[u] : f;
     }
     float sum = 0.f;
     for (int b = 0; b < 33; ++b) sum += __shfl(f, b, 64);   // d = 0..32 in order, as the CPU loop
@@ -682,6 +690,7 @@ int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* 
 namespace {
 int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, const ScanPlan& p, const int* order, const int* nbr, const int* cnt,
                     float* d_desc, int* d_nbr, int* d_nbr_cnt) {
+    if ((size_t)n * 33 > 0xffffffffull) return TDV_ERR_BAD_ARG;   // k_fpfh addresses SPFH rows with 32-bit float offsets (130 M points)
     float* spfh;
     TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
     hipStream_t s = ctx->stream;
