@@ -465,11 +465,16 @@ void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n,
     const int lane = threadIdx.x & 63;
     const int t = xcd_contiguous_block(blockIdx.x, gridDim.x) * FP_WAVES + (threadIdx.x >> 6);
     if (t >= n) return;   // wave-uniform
-    const int i = order[t];
+    const int i = __builtin_amdgcn_readfirstlane(order[t]);
     const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
     const float ux = nrm[3 * (size_t)i], uy = nrm[3 * (size_t)i + 1], uz = nrm[3 * (size_t)i + 2];
-    const int cnt = nbr_cnt[i];
-    int mine = 0;   // lane b < 33 counts bin b
+    const int cnt = __builtin_amdgcn_readfirstlane(nbr_cnt[i]);
+    // the histogram: 33 LDS counters per wave, three integer atomic adds per pair (33 ballots + lane selects per 64 pairs
+    // were a quarter of the kernel's instructions; integer counts do not depend on the order)
+    __shared__ int hist[FP_WAVES][64];
+    int* myhist = hist[threadIdx.x >> 6];
+    myhist[lane] = 0;
+    __builtin_amdgcn_wave_barrier();
     for (int r0 = 0; r0 < cnt; r0 += 64) {
         const int r = r0 + lane;
         const int j = r < cnt ? nbr[(size_t)i * FP_MAXNN + r] : i;
@@ -494,14 +499,10 @@ void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n,
                 bin_t = min(max((int)(((double)theta / 3.14159265358979323846 + (double)1.0f) * (double)5.5f), 0), 10);
             }
         }
-#pragma unroll
-        for (int b = 0; b < 11; ++b) {
-            const int ca = __popcll(__ballot(valid && bin_a == b));
-            const int cp = __popcll(__ballot(valid && bin_p == b));
-            const int ct = __popcll(__ballot(valid && bin_t == b));
-            mine += lane == b ? ca : (lane == 11 + b ? cp : (lane == 22 + b ? ct : 0));
-        }
+        if (valid) { atomicAdd(&myhist[bin_a], 1); atomicAdd(&myhist[11 + bin_p], 1); atomicAdd(&myhist[22 + bin_t], 1); }
     }
+    __builtin_amdgcn_wave_barrier();
+    const int mine = myhist[lane];   // lane b < 33: the count of bin b
     const float hv = (float)mine;   // = the CPU's sum of 1.0f increments (counts stay far below 2^24)
     float sum = 0.f;
     for (int b = 0; b < 33; ++b) sum += __shfl(hv, b, 64);
