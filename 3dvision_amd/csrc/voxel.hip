@@ -222,16 +222,31 @@ __global__ void k_voxel_leader_list(const int* __restrict__ leader, const int* _
                                      (int)floorf(xyz[3 * (size_t)i + 2] * inv), i);
 }
 
-// exclusive scan of n ints in TWO launches: per-block (1024) reduce whose LAST workgroup (atomic ticket) scans the block
-// sums, then the local scan.  (Round 1 used three launches; the scan sits on every grouping path — voxel x2, Morton
-// order, descriptor buckets, batched depth — and each launch costs ~5 us on a path that is launch-bound anyway.)
+// exclusive scan of n ints in TWO launches: per-block (4096 items: 1024 threads x 4) reduce whose LAST workgroup (atomic
+// ticket) scans the block sums, then the local scan.  (Round 1 used three launches; the scan sits on every grouping path —
+// voxel x2, Morton order, descriptor buckets, batched depth — and each launch costs ~5 us on a path that is launch-bound
+// anyway.  Four items per thread: a quarter of the workgroups, tickets and barriers for the 524k-bucket tables of the voxel
+// hash, whose scan took 50 us with one item per thread.)
+constexpr int SCAN_IPT = 4;
+constexpr int SCAN_BLOCK_ITEMS = 1024 * SCAN_IPT;
+__device__ __forceinline__ void scan_load4(const int* __restrict__ in, int n, int i0, int (&x)[SCAN_IPT]) {
+    if (i0 + SCAN_IPT <= n && (((size_t)in & 15) == 0)) {
+        const int4 q = *reinterpret_cast<const int4*>(in + i0);
+        x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < SCAN_IPT; ++e) x[e] = i0 + e < n ? in[i0 + e] : 0;
+    }
+}
 __global__ __launch_bounds__(1024)
 void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums, int* __restrict__ total, unsigned* __restrict__ ticket) {
     __shared__ int w[16];
     __shared__ int carry_s;
     __shared__ bool is_last;
-    int i = blockIdx.x * 1024 + threadIdx.x;
-    int v = i < n ? in[i] : 0;
+    const int i0 = (blockIdx.x * 1024 + threadIdx.x) * SCAN_IPT;
+    int x[SCAN_IPT];
+    scan_load4(in, n, i0, x);
+    int v = (x[0] + x[1]) + (x[2] + x[3]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = v;
@@ -252,8 +267,8 @@ void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums, in
     volatile int* vs = sums;                                    // written by other workgroups of this launch
     for (int b0 = 0; b0 < nblocks; b0 += 1024) {
         int k = b0 + threadIdx.x;
-        int x = k < nblocks ? vs[k] : 0;
-        int incl = x;
+        int xs = k < nblocks ? vs[k] : 0;
+        int incl = xs;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
         if (lane == 63) w[wave] = incl;
@@ -261,7 +276,7 @@ void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums, in
         int wbase = 0;
         for (int q = 0; q < wave; ++q) wbase += w[q];
         int carry = carry_s;
-        if (k < nblocks) vs[k] = carry + wbase + incl - x;
+        if (k < nblocks) vs[k] = carry + wbase + incl - xs;
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
         __syncthreads();
@@ -272,16 +287,20 @@ __global__ __launch_bounds__(1024)
 void k_scan_local(const int* __restrict__ in, int n, const int* __restrict__ sums, int* __restrict__ out) {
     __shared__ int wsum[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int i = blockIdx.x * 1024 + threadIdx.x;
-    int v = i < n ? in[i] : 0;
+    const int i0 = (blockIdx.x * 1024 + threadIdx.x) * SCAN_IPT;
+    int x[SCAN_IPT];
+    scan_load4(in, n, i0, x);
+    const int v = (x[0] + x[1]) + (x[2] + x[3]);
     int incl = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     int wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += wsum[w];
-    if (i < n) out[i] = sums[blockIdx.x] + wbase + incl - v;
+    for (int q = 0; q < wave; ++q) wbase += wsum[q];
+    int run = sums[blockIdx.x] + wbase + incl - v;          // exclusive prefix of this thread's first item
+#pragma unroll
+    for (int e = 0; e < SCAN_IPT; ++e) { if (i0 + e < n) out[i0 + e] = run; run += x[e]; }
 }
 
 // one lane per run head: sequential sum over the run (ascending input index), mean -> out[rank]
@@ -391,7 +410,7 @@ private:
 // exclusive scan of n ints on the ctx stream; *d_total receives the sum (device pointer)
 int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_total) {
     if (n <= 0) return TDV_OK;
-    const int sblocks = (n + 1023) / 1024;
+    const int sblocks = (n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS;
     int* sums;
     TDV_TRY(ws_alloc(ctx, (size_t)sblocks, &sums));
     hipStream_t s = ctx->stream;
@@ -424,7 +443,7 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     uint4* rec; int *leader, *rank, *sums, *d_total;
     TDV_TRY(ws_alloc(ctx, n_pow2, &rec));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &rank));
-    const int sblocks = (n + 1023) / 1024;
+    const int sblocks = (n + SCAN_BLOCK_ITEMS - 1) / SCAN_BLOCK_ITEMS;
     TDV_TRY(ws_alloc(ctx, (size_t)sblocks, &sums));
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
     TDV_TRY(pin_reserve(ctx, 64));
