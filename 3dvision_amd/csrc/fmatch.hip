@@ -1361,25 +1361,21 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     while ((ix.nleaf >> bucket_shift) > FMP_BUCKETS) ++bucket_shift;
     int *home, *bucket_of, *sperm, *hist, *cursor, *start, *d_total; float* sp; unsigned* amax_s;
     int *overflow_count, *overflow_list, *overflow_src, *part_j; float* part_d;
-    TDV_TRY(ws_alloc(ctx, 2, &overflow_count));
+    int* zeroed;                                                   // hist | cursor | overflow_count[2] | amax_s: one memset
+    TDV_TRY(ws_alloc(ctx, (size_t)2 * FMP_BUCKETS + 4, &zeroed));
+    hist = zeroed; cursor = zeroed + FMP_BUCKETS; overflow_count = zeroed + 2 * FMP_BUCKETS; amax_s = reinterpret_cast<unsigned*>(zeroed + 2 * FMP_BUCKETS + 2);
     TDV_TRY(ws_alloc(ctx, (size_t)2 * ns + 8, &overflow_list));   // two halves: pass-B class, scan class
     TDV_TRY(ws_alloc(ctx, (size_t)ns + 8, &overflow_src));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &part_d));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &part_j));
     TDV_TRY(ws_alloc(ctx, (size_t)ns * 4, &sp));
-    TDV_TRY(ws_alloc(ctx, 1, &amax_s));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &home));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &bucket_of));
     TDV_TRY(ws_alloc(ctx, (size_t)ns, &sperm));
-    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &hist));
-    TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS, &cursor));
     TDV_TRY(ws_alloc(ctx, (size_t)FMP_BUCKETS + 1, &start));
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
     ScopedTimer tm(ctx, TDV_TIMER_FEATURE_MATCH);
-    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)FMP_BUCKETS * 4, s));
-    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)FMP_BUCKETS * 4, s));
-    TDV_HIP(ctx, hipMemsetAsync(amax_s, 0, 4, s));
-    TDV_HIP(ctx, hipMemsetAsync(overflow_count, 0, 8, s));
+    TDV_HIP(ctx, hipMemsetAsync(zeroed, 0, ((size_t)2 * FMP_BUCKETS + 4) * 4, s));
     k_fm_locate<<<(ns + 255) / 256, 256, 0, s>>>(d_fs, ns, ix.basis, ix.S0, ix.S1, ix.b0, ix.b1, ix.col_leaf0, ix.leaf_p2, bucket_shift, home, bucket_of, sp, amax_s);
     const int sblocks = (ns + FMP_SORT_BLOCK - 1) / FMP_SORT_BLOCK;
     k_fm_bucket_hist<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, hist);

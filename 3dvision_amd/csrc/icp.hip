@@ -559,8 +559,7 @@ int alloc_buffers(tdv_ctx* ctx, const NnPlan& p, IcpBuffers& b) {
     TDV_TRY(ws_alloc(ctx, (size_t)p.nsplit * p.ns_pad, &b.pchunk));
     TDV_TRY(ws_alloc(ctx, (size_t)p.acc_blocks * ACC_NV, &b.slabs));
     TDV_TRY(ws_alloc(ctx, 1, &b.st));
-    TDV_TRY(ws_alloc(ctx, 1, &b.ticket));
-    TDV_HIP(ctx, hipMemsetAsync(b.ticket, 0, 4, ctx->stream));
+    b.ticket = ctx->scan_ticket + 1;     // the ctx's persistent ticket words (zero between launches: the last workgroup resets it)
     return TDV_OK;
 }
 

@@ -600,16 +600,15 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     int bits = 12;
     while (bits < MORTON_MAX_BUCKET_BITS && (1ll << bits) < (long long)per_point * n) bits += 1;
     const int nbuckets = 1 << bits;
-    TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &hist));
-    TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &cursor));
+    TDV_TRY(ws_alloc(ctx, (size_t)2 * nbuckets, &hist));          // hist | cursor: one memset
+    cursor = hist + nbuckets;
     TDV_TRY(ws_alloc(ctx, (size_t)nbuckets, &start));
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
     const int bblocks = std::min(1024, (n + 255) / 256);
     TDV_TRY(ws_alloc(ctx, (size_t)bblocks * 6, &part));
     TDV_TRY(ws_alloc(ctx, 6, &bbox));
     so.sx = soa; so.sy = soa + pad; so.sz = soa + 2 * (size_t)pad;
-    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)nbuckets * 4, s));
-    TDV_HIP(ctx, hipMemsetAsync(cursor, 0, (size_t)nbuckets * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(hist, 0, (size_t)2 * nbuckets * 4, s));
     k_bbox_partial<<<bblocks, 256, 0, s>>>(d_xyz, n, part);
     k_bbox_final<<<1, 64, 0, s>>>(part, bblocks, bbox);
     k_morton_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, bbox, bits, bucket_of, hist);

@@ -77,9 +77,10 @@ __device__ __forceinline__ float tau_mid_default(float sqrt_tau) { return sqrt_t
 // Rows 12, 13 of hyp: the band of the fast scoring pass for this hypothesis (RansacBand below): mid and half-width of
 // the d2 interval inside which the FMA arithmetic and the reference's arithmetic might disagree on `d2 < tau`.
 __global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __restrict__ triples, int count, int h_pad,
-                                    float* __restrict__ hyp, const unsigned* __restrict__ pmax, float sqrt_tau) {
+                                    float* __restrict__ hyp, const unsigned* __restrict__ pmax, float sqrt_tau, int* __restrict__ counts) {
     int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= h_pad) return;
+    counts[h] = 0;                       // the scoring kernel adds its point-splits' counts here (one memset launch less per batch)
     float o[12];
     bool valid = false;
     int4 tr = make_int4(0, 0, 0, 0);
@@ -340,11 +341,13 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     const int ns_pad = (int)align_up((size_t)ns, (size_t)RS_PCH * 64);
     float* pq = nullptr;
     TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 8, &pq));
+    // one device block: [0] bad index flag, [1] largest |source coordinate|, [2..3] rescored chunks (u64), [16..27] the winning
+    // hypothesis, [32..35] its error sum and inlier count (2 doubles): one memset at the start, one copy back at the end
     int* d_bad = nullptr;
-    TDV_TRY(ws_alloc(ctx, 4, &d_bad));
+    TDV_TRY(ws_alloc(ctx, 40, &d_bad));
     unsigned* d_pmax = reinterpret_cast<unsigned*>(d_bad + 1);
     unsigned long long* d_rescored = reinterpret_cast<unsigned long long*>(d_bad + 2);
-    TDV_HIP(ctx, hipMemsetAsync(d_bad, 0, 16, s));
+    TDV_HIP(ctx, hipMemsetAsync(d_bad, 0, 160, s));
     double wave_chunks = 0.0;    // wave x chunk pairs scored by the fast pass in this call
     k_gather_pq<<<(ns_pad + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, ns, ns_pad, nt, pq, d_bad, d_pmax);
     // sqrt(tau) rounded up: the boundary of `d2 < tau` in distance, for the band of the fast scoring pass
@@ -377,19 +380,20 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     }
     const int rblocks = (ns + 255) / 256;
     TDV_TRY(ws_alloc(ctx, (size_t)2 * rblocks, &slabs));
-    TDV_TRY(ws_alloc(ctx, 2, &d_out2));
-    TDV_TRY(ws_alloc(ctx, 12, &d_best12));
+    d_best12 = reinterpret_cast<float*>(d_bad + 16);
+    d_out2 = reinterpret_cast<double*>(d_bad + 32);
     // pinned: 2 x triples (int4 * batch) | 2 x counts (int * batch) | best12 (12 floats) | out2 (2 doubles)
     const size_t sz_tri = align_up((size_t)batch * 16, 64), sz_cnt = align_up((size_t)batch * 4, 64);
-    const size_t pin_b12 = 2 * sz_tri + 2 * sz_cnt, pin_o2 = pin_b12 + 64, pin_bad = pin_o2 + 64, pin_total = pin_bad + 64;
+    const size_t pin_b12 = 2 * sz_tri + 2 * sz_cnt, pin_bad = pin_b12 + 192, pin_total = pin_bad + 64;   // pin_b12: the 160-byte result block
     TDV_TRY(pin_reserve(ctx, pin_total));
     int* h_bad = reinterpret_cast<int*>(ctx->pin + pin_bad);
     *h_bad = 0;
     TDV_HIP(ctx, hipMemcpyAsync(h_bad, d_bad, 4, hipMemcpyDeviceToHost, s));   // lands before the first batch's counts
     int4* h_tri[2] = {reinterpret_cast<int4*>(ctx->pin), reinterpret_cast<int4*>(ctx->pin + sz_tri)};
     int* h_cnt[2] = {reinterpret_cast<int*>(ctx->pin + 2 * sz_tri), reinterpret_cast<int*>(ctx->pin + 2 * sz_tri + sz_cnt)};
-    float* h_b12 = reinterpret_cast<float*>(ctx->pin + pin_b12);
-    double* h_o2 = reinterpret_cast<double*>(ctx->pin + pin_o2);
+    const int* h_block = reinterpret_cast<const int*>(ctx->pin + pin_b12);      // host copy of d_bad[0..40): same layout
+    const float* h_b12 = reinterpret_cast<const float*>(h_block + 16);
+    const double* h_o2 = reinterpret_cast<const double*>(h_block + 32);
     hipEvent_t ev[2] = {event_acquire(ctx), event_acquire(ctx)};   // from the ctx's pool: no create/destroy per call
     if (!ev[0] || !ev[1]) { event_release(ctx, ev[0]); event_release(ctx, ev[1]); return TDV_ERR_OOM; }
 
@@ -406,8 +410,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     };
     auto enqueue = [&](int q, int cnt) -> int {     // device: hypotheses + scoring + counts back to the host
         TDV_HIP(ctx, hipMemcpyAsync(d_tri[q], h_tri[q], (size_t)cnt * 16, hipMemcpyHostToDevice, s));
-        TDV_HIP(ctx, hipMemsetAsync(counts[q], 0, (size_t)h_pad * 4, s));
-        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q], d_pmax, sqrt_tau);
+        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q], d_pmax, sqrt_tau, counts[q]);
         const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
         {
             ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
@@ -461,18 +464,18 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     for (int q = 0; q < 2; ++q) event_release(ctx, ev[q]);
     if (status != TDV_OK) return status;
     out->iterations_run = done_iters;
-    // statistics of the fast pass: read back on the ctx's stream with the final results (h_o2[2] is free: out2 is 2 doubles of 64 B)
-    unsigned long long* h_res = reinterpret_cast<unsigned long long*>(h_o2 + 4);
-    *h_res = 0;
+    // the result block comes back in one copy: winning hypothesis, its error sum and count, the fast pass's statistics
+    const unsigned long long* h_res = reinterpret_cast<const unsigned long long*>(h_block + 2);
     const bool want_stats = score_fast && wave_chunks > 0.0;
-    if (want_stats) TDV_HIP(ctx, hipMemcpyAsync(h_res, d_rescored, 8, hipMemcpyDeviceToHost, s));
-    if (best_iter < 0 && want_stats) TDV_HIP(ctx, hipStreamSynchronize(s));
+    if (best_iter < 0 && want_stats) {
+        TDV_HIP(ctx, hipMemcpyAsync(ctx->pin + pin_b12, d_bad, 160, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+    }
     if (best_iter >= 0) {
         k_ransac_rmse_partial<<<rblocks, 256, 0, s>>>(pq, ns, d_best12, tau, slabs);
         k_ransac_rmse_final<<<1, 256, 0, s>>>(slabs, rblocks, d_out2);
         TDV_CHECK_LAUNCH(ctx);
-        TDV_HIP(ctx, hipMemcpyAsync(h_b12, d_best12, 48, hipMemcpyDeviceToHost, s));
-        TDV_HIP(ctx, hipMemcpyAsync(h_o2, d_out2, 16, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipMemcpyAsync(ctx->pin + pin_b12, d_bad, 160, hipMemcpyDeviceToHost, s));
         TDV_HIP(ctx, hipStreamSynchronize(s));
         if (want_stats) ctx->last_ransac_rescore = (double)*h_res / wave_chunks;
         for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) out->T[c * 4 + r] = h_b12[c * 3 + r];
