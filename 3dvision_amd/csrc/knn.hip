@@ -143,15 +143,21 @@ __global__ void k_leaf_boxes(const float* __restrict__ sx, const float* __restri
     if (lane < 3) lb[(size_t)lane * n_leaf + leaf] = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
     else if (lane < 6) lb[(size_t)lane * n_leaf + leaf] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
 }
-__global__ void k_top_boxes(const float* __restrict__ lb, int n_leaf, int n_top, float* __restrict__ tb) {
-    int u = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per group: lane = leaf (a lane per group walking its 64 leaves one after the other took 14 us for 37 groups)
+__global__ __launch_bounds__(64)
+void k_top_boxes(const float* __restrict__ lb, int n_leaf, int n_top, float* __restrict__ tb) {
+    const int u = blockIdx.x, lane = threadIdx.x;
     if (u >= n_top) return;
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int c = u * 64; c < min(n_leaf, u * 64 + 64); ++c)
+    const int c = u * 64 + lane;
+    float mn[3], mx[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], lb[(size_t)a * n_leaf + c]); mx[a] = fmaxf(mx[a], lb[(size_t)(3 + a) * n_leaf + c]); }
+    for (int a = 0; a < 3; ++a) { mn[a] = c < n_leaf ? lb[(size_t)a * n_leaf + c] : INFINITY; mx[a] = c < n_leaf ? lb[(size_t)(3 + a) * n_leaf + c] : -INFINITY; }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { tb[(size_t)a * n_top + u] = mn[a]; tb[(size_t)(3 + a) * n_top + u] = mx[a]; }
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64)); }
+    if (lane < 3) tb[(size_t)lane * n_top + u] = lane == 0 ? mn[0] : (lane == 1 ? mn[1] : mn[2]);
+    else if (lane < 6) tb[(size_t)lane * n_top + u] = lane == 3 ? mx[0] : (lane == 4 ? mx[1] : mx[2]);
 }
 
 // Lower bound on the reference's float d2 = dx*dx + (dy*dy + dz*dz) between ANY query inside [qmin,qmax] and ANY target
@@ -620,7 +626,7 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_leaf, &so.lbox));
     TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_top, &so.tbox));
     k_leaf_boxes<<<(so.n_leaf + 3) / 4, 256, 0, s>>>(so.sx, so.sy, so.sz, so.n_leaf, so.lbox);
-    k_top_boxes<<<(so.n_top + 255) / 256, 256, 0, s>>>(so.lbox, so.n_leaf, so.n_top, so.tbox);
+    k_top_boxes<<<so.n_top, 64, 0, s>>>(so.lbox, so.n_leaf, so.n_top, so.tbox);
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
