@@ -173,6 +173,48 @@ def test_all_instance_clouds_camera_parameter_fuzz(ctx, orc, seed):
             assert flat[3 * off[b]:3 * off[b + 1]].tobytes() == ref_xyz.tobytes(), (seed, b, shift)
 
 
+def test_all_instance_clouds_mask_rules_every_byte_value(ctx, orc, tdv):
+    """The four-bytes-at-once mask rules of the tiled pass against per-pixel numpy: `> 10`, `!= 0` and `== label` over
+    every byte value (0..255 side by side in every row), labels 1..255 (label = instance + 1: 255 instances of one
+    label image), and one depth frame per instance chosen through frame_of_instance."""
+    rng = np.random.default_rng(11)
+    h, w = 32, 256                                     # 8,192 pixels: 8 tiles
+    raw = rng.integers(1, 2000, (3, h, w)).astype(np.uint16)     # three frames
+    raw[:, ::7, ::5] = 0
+    ramp = np.tile(np.arange(256, dtype=np.uint8), (h, 1))       # every byte value in every row
+    dev = torch.device("cuda", 0)
+    d_raw = torch.from_numpy(raw.view(np.int16)).to(dev)
+    fx, fy, cx, cy, zmax, scale = 300.0, 310.0, 128.5, 15.5, 1.7, 1000.0
+
+    def run(masks_np, n_inst, mask_format, mask_mode, n_frames, fmap):
+        d_masks = torch.from_numpy(masks_np).to(dev)
+        cap = n_inst * h * w
+        d_xyz = torch.zeros((cap, 3), dtype=torch.float32, device=dev)
+        off = ctx.depth_to_cloud_batch_dev(d_raw.data_ptr(), d_masks.data_ptr(), None, n_inst, w, h, scale, fx, fy, cx, cy, zmax, d_xyz.data_ptr(), None, cap,
+                                           mask_format=mask_format, mask_mode=mask_mode, n_frames=n_frames, frame_of_instance=fmap)
+        return off, d_xyz.cpu().numpy()
+
+    def expect(frame, keep):
+        depth = raw[frame].astype(np.float32) * np.float32(1.0 / scale)
+        depth = np.where(keep, depth, np.float32(0)).astype(np.float32)
+        return orc.unproject(depth, None, fx, fy, cx, cy, zmax)[0]
+
+    # stacked masks, both threshold rules, frames 0 / 1 / 2 / 1 / 0
+    stacked = np.stack([np.roll(ramp, 17 * b, axis=1) for b in range(5)])
+    fmap = np.array([0, 1, 2, 1, 0], np.int32)
+    for mode, rule in ((tdv.TDV_MASK_THRESHOLD10, lambda m: m > 10), (tdv.TDV_MASK_NONZERO, lambda m: m != 0)):
+        off, xyz = run(stacked, 5, 0, mode, 3, fmap)
+        for b in range(5):
+            ref = expect(fmap[b], rule(stacked[b]))
+            assert off[b + 1] - off[b] == len(ref) and xyz[off[b]:off[b + 1]].tobytes() == ref.tobytes(), (mode, b)
+    # one label image, 255 instances: instance b keeps the pixels whose value is b + 1 (value 0 belongs to nobody)
+    off, xyz = run(ramp, 255, 1, tdv.TDV_MASK_THRESHOLD10, 1, None)
+    for b in (0, 1, 9, 10, 126, 127, 128, 199, 253, 254):
+        ref = expect(0, ramp == b + 1)
+        assert off[b + 1] - off[b] == len(ref) > 0 and xyz[off[b]:off[b + 1]].tobytes() == ref.tobytes(), b
+    assert off[255] == sum(len(expect(0, ramp == v)) for v in range(1, 256))
+
+
 @pytest.mark.parametrize("n,voxel,k", [(3, 0.01, 30), (40, 0.002, 30), (200, 0.004, 30), (3000, 0.002, 8), (5000, 0.01, 64)])
 def test_model_prep_small_clouds(ctx, tdv, synth, n, voxel, k):
     """tdv_prepare_model_dev (one radius search shared by normals and FPFH, kNN only for the deficient points) equals
