@@ -220,3 +220,30 @@ def test_pruned_search_threshold_edges(pruned, orc, synth, thr):
         assert acc[:300].all()          # d2 = 0 passes the inclusive test
     if thr < 0:
         assert not acc.any()
+
+
+@pytest.mark.parametrize("offset,expect_grid", [(0.0, True), (-37.5, True), (50.0, True), (114.0, True), (116.5, False), (4000.0, False)])
+def test_grid_search_far_from_the_origin(ctx, orc, synth, offset, expect_grid):
+    """The hash grid's completeness argument is about rounding of cell coordinates: clouds moved away from the origin, on
+    both sides of it, up to the 2^17-cell limit of the build (threshold 0.4 mm -> cells of 0.88 mm -> 115.3 m) and beyond
+    it, where the search hands over to the box walk.  Accepted correspondences identical to the oracle's scan."""
+    ns, nt = 6000, 5000
+    src, tgt, nrm, T_gt = _pair(synth, ns, nt)
+    shift = np.array([offset, -offset * 0.5, offset * 0.25], np.float32)
+    tgt = (tgt + shift).astype(np.float32)
+    T = synth.perturb(T_gt, angle_deg=0.05, trans=0.0002).astype(np.float64)
+    T[:3, 3] += shift.astype(np.float64)
+    T = T.astype(np.float32)
+    thr = 0.0004
+    ref = orc.icp_correspondences(src, tgt, None, T, thr, point_to_plane=False)
+    try:
+        ctx.set_icp_search("grid")
+        got = ctx.icp_correspondences(src, tgt, T, thr)
+        used = ctx.last_icp_search()
+    finally:
+        ctx.set_icp_search("auto")
+    assert used == ("grid" if expect_grid else "pruned")
+    acc = ref["accepted"].astype(bool)
+    assert np.array_equal(got["accepted"], ref["accepted"]) and got["n_corr"] == ref["n_corr"]
+    assert np.array_equal(got["corr"][acc], ref["corr"][acc]) and got["d2"][acc].tobytes() == ref["d2"][acc].tobytes()
+    if abs(offset) < 60: assert acc.sum() > 50        # (far out the float grid is coarser than the threshold: few or no matches)
