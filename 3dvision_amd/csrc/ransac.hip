@@ -244,7 +244,9 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
             const v2f dx = fma2(r[0], px, fma2(r[3], py, fma2(r[6], pz, r[9]))) - qx;
             const v2f dy = fma2(r[1], px, fma2(r[4], py, fma2(r[7], pz, r[10]))) - qy;
             const v2f dz = fma2(r[2], px, fma2(r[5], py, fma2(r[8], pz, r[11]))) - qz;
-            const v2f t = fma2(dx, dx, fma2(dy, dy, dz * dz)) + nmid;
+            // d2_fma - mid as one chain ending in -mid: its own rounding, at most 3 u mid = 1.5 u s in distance, sits inside
+            // the 3.7 u A + 4 u s that the band's E keeps in reserve over the proven bound
+            const v2f t = fma2(dx, dx, fma2(dy, dy, fma2(dz, dz, nmid)));
             m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));                       // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
             cf += (int)(__float_as_uint(t.x) >> 31) + (int)(__float_as_uint(t.y) >> 31);   // d2_fma < mid
         }
