@@ -236,6 +236,7 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
 #pragma unroll
         for (int e = 0; e < 6 * RS_PCH; ++e) v[e] = g[e];
         float m = INFINITY;      // smallest |d2_fma - mid| of this lane in the chunk
+        unsigned sgn = 0u;       // the signs of d2_fma - mid, shifted in one per test (1 = below mid = inlier)
         int cf = 0;
 #pragma unroll
         for (int p = 0; p < RS_PCH / 2; ++p) {
@@ -248,8 +249,10 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
             // the 3.7 u A + 4 u s that the band's E keeps in reserve over the proven bound
             const v2f t = fma2(dx, dx, fma2(dy, dy, fma2(dz, dz, nmid)));
             m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));                       // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
-            cf += (int)(__float_as_uint(t.x) >> 31) + (int)(__float_as_uint(t.y) >> 31);   // d2_fma < mid
+            sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.x), 31);      // sgn = sgn << 1 | sign(t.x)
+            sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.y), 31);
         }
+        cf = __popc(sgn);
         if (__any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
             ++n_rescored;
             cf = 0;

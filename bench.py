@@ -216,20 +216,20 @@ def main():
 
         # Scoring kernel of the timed region.  Reference arithmetic (k_ransac_score): per hypothesis-point 18 ops transform +
         # 3 sub + 5 squared norm + 1 compare + 1 count = 28 VALU lane-ops (issued as packed f32 pairs).  Default
-        # (k_ransac_score_fast): 16.9 lane-ops per hypothesis-point in the FMA pass (per 8 points 60 packed instructions -
-        # 48 fma, 12 add - and 15 scalar-f32 ones) + 28 for every (wave, chunk) pair scored again exactly
+        # (k_ransac_score_fast): 16.6 lane-ops per hypothesis-point in the FMA pass (per 8 points 60 packed instructions -
+        # 48 fma, 12 add - and 13 scalar-f32 ones) + 28 for every (wave, chunk) pair scored again exactly
         # (rescore_share, counted by the kernel).  An FMA is ONE lane-op here, as in the peak (lane-instructions, not flops).
         # Algorithmic HBM bytes per launch: the packed pairs once (24 B per point) + 48 B per hypothesis in, 4 B out.
         sc_hyps_per_launch = hyps_total / max(sc_launches, 1)
         fast = rescore_share >= 0.0
-        ops_per_test = (16.9 + 28.0 * rescore_share) if fast else 28.0
+        ops_per_test = (16.6 + 28.0 * rescore_share) if fast else 28.0
         sc_tops = ops_per_test * n * hyps_total / max(sc_ms * 1e-3, 1e-12) / 1e12
         sc_bytes = 24.0 * n + 52.0 * sc_hyps_per_launch
         sc_kernel = "k_ransac_score_fast" if fast else "k_ransac_score"
         score = {
             "kernel": sc_kernel, "bound": "valu_f32",
             "achieved": sc_tops, "peak": VALU_PEAK_TOPS,
-            "unit": ("T VALU lane-ops/s executed: %.1f per hypothesis-point = 16.9 in the FMA pass + 28 x the %.3f of the (wave, chunk) pairs "
+            "unit": ("T VALU lane-ops/s executed: %.1f per hypothesis-point = 16.6 in the FMA pass + 28 x the %.3f of the (wave, chunk) pairs "
                      "scored again with the reference arithmetic; same inlier counts as the 28-op reference arithmetic" % (ops_per_test, rescore_share))
                     if fast else "Tops/s (f32 VALU, FMA contraction forbidden by parity; 28 ops per hypothesis-point)",
             "frac": sc_tops / VALU_PEAK_TOPS, "avg_launch_ms": sc_avg_ms, "launches": sc_launches,
