@@ -35,6 +35,7 @@
 #include <cfloat>
 #include <climits>
 #include <cmath>
+#include <cstdlib>
 #include <algorithm>
 
 namespace tdv {
@@ -237,7 +238,7 @@ void k_icp_nn_pruned(const float* __restrict__ src, int ns,
 constexpr unsigned long long GRID_EMPTY = ~0ull;
 constexpr float GRID_CELL_FACTOR = 2.2f;
 constexpr float GRID_MAX_COORD = 131072.0f;      // 2^17 cells
-constexpr int GRID_MAX_PER_CELL = 8;             // average over the occupied cells above which the grid is not used
+constexpr int GRID_MAX_PER_CELL = 32;            // average over the occupied cells above which the grid is not used (measured at 200k x 200k, threshold in spacings: 2 -> 19 per cell, grid 0.13 ms vs walk 0.20; 4 -> 77 per cell, 0.37 vs 0.21)
 struct __attribute__((aligned(16))) GridEntry { unsigned long long key; int head; int pad; };
 __device__ __forceinline__ unsigned long long grid_key(int ix, int iy, int iz) {
     return ((unsigned long long)((unsigned)ix & 0x1fffffu) << 42) | ((unsigned long long)((unsigned)iy & 0x1fffffu) << 21) | (unsigned long long)((unsigned)iz & 0x1fffffu);
@@ -589,7 +590,8 @@ int cell_grid_build(tdv_ctx* ctx, const float* d_tgt, int nt, float thr, CellGri
     const int* h = reinterpret_cast<const int*>(ctx->pin);
     const int bad = h[0], cells = h[1];
     g->table = table; g->node = node; g->mask = (unsigned)(size - 1); g->shift = 64 - log2; g->inv_cell = inv_cell;
-    g->usable = (!bad && cells > 0 && (long long)nt <= (long long)GRID_MAX_PER_CELL * cells) ? 1 : 0;
+    static const int max_per_cell = getenv("TDV_GRID_MAX_PER_CELL") ? atoi(getenv("TDV_GRID_MAX_PER_CELL")) : GRID_MAX_PER_CELL;   // tuning knob
+    g->usable = (!bad && cells > 0 && (long long)nt <= (long long)max_per_cell * cells) ? 1 : 0;
     return TDV_OK;
 }
 
