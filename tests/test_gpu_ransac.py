@@ -130,6 +130,21 @@ def test_ransac_fast_scoring_equals_exact_scoring(ctx, orc, synth, offset):
     if offset == 1.0e5: assert share >= 0.74     # every wave that holds a hypothesis (1,500 of the 2,048 lanes: 24 of 32 waves)
 
 
+@pytest.mark.parametrize("scale", [1.0e-3, 1.0, 37.0, 1.0e4])
+def test_ransac_fast_scoring_over_magnitudes(ctx, orc, synth, scale):
+    """The band is relative (E = 16 u (A + s)): the same scene in millimetres, metres, and larger units, with a matching
+    voxel size, gives the exact counts in both scoring modes."""
+    ns, nt = 5000, 2500
+    src, tgt, corr, _ = _case(synth, ns, nt, seed=7, good_frac=0.6)
+    src = (src * np.float32(scale)).astype(np.float32); tgt = (tgt * np.float32(scale)).astype(np.float32)
+    voxel = 0.004 * scale
+    e, f, share = _both_modes(ctx, src, tgt, corr=corr, voxel=voxel, max_iterations=1200, confidence=2.0, trace=True)
+    ref = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=1200, confidence=2.0, trace=True)
+    assert np.array_equal(e.trace_inliers, ref["inliers"]) and np.array_equal(f.trace_inliers, ref["inliers"])
+    assert f.transformation.tobytes() == e.transformation.tobytes() and (f.best_iteration, f.inliers) == (e.best_iteration, e.inliers)
+    assert 0.0 <= share < 0.7 and ref["inliers"].max() > 0.2 * ns
+
+
 def test_ransac_fast_scoring_points_on_the_threshold(ctx, orc, synth):
     """Adversarial for the band: matched points placed at the threshold distance and within a few ulps of it, identity-like
     hypotheses (an exact rigid copy), so that thousands of tests sit inside the band; plus non-finite points."""
