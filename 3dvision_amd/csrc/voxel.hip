@@ -90,6 +90,21 @@ void k_bitonic_global_step(uint4* __restrict__ rec, size_t n_pairs, unsigned k, 
     if (sw) { rec[i] = b; rec[i + j] = a; }
 }
 
+// two global passes in one launch (strides j and j / 2, both >= BT_TILE): a thread holds the four records its two
+// compare-exchanges per pass touch.  The sort of 131k-262k records is a chain of ~30 tiny launches; this removes a third.
+__global__ __launch_bounds__(256)
+void k_bitonic_global_step2(uint4* __restrict__ rec, size_t n_quads, unsigned k, unsigned j) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_quads) return;
+    const size_t h = j >> 1;                                              // the second stride
+    const size_t i = ((t / h) * ((size_t)j << 1)) + (t % h);              // bits j and h of i are clear
+    uint4 a = rec[i], b = rec[i + h], c = rec[i + j], d = rec[i + j + h];
+    const bool asc = ((i & (size_t)k) == 0);                              // k > j: the same for all four
+    cmpxchg(a, c, asc); cmpxchg(b, d, asc);                               // stride j
+    cmpxchg(a, b, asc); cmpxchg(c, d, asc);                               // stride j / 2
+    rec[i] = a; rec[i + h] = b; rec[i + j] = c; rec[i + j + h] = d;
+}
+
 // all passes with stride < BT_TILE of merge stage k, inside LDS
 __global__ __launch_bounds__(BT_THREADS)
 void k_bitonic_local_merge(uint4* __restrict__ rec, unsigned k) {
@@ -113,8 +128,14 @@ int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2) {
     const unsigned tiles = (unsigned)(n_pow2 / BT_TILE);
     k_bitonic_local_sort<<<tiles, BT_THREADS, 0, s>>>(rec);
     for (size_t k = (size_t)BT_TILE << 1; k <= n_pow2; k <<= 1) {
-        for (size_t j = k >> 1; j >= BT_TILE; j >>= 1)
-            k_bitonic_global_step<<<(unsigned)((n_pow2 / 2 + 255) / 256), 256, 0, s>>>(rec, n_pow2 / 2, (unsigned)k, (unsigned)j);
+        for (size_t j = k >> 1; j >= BT_TILE; j >>= 1) {
+            if ((j >> 1) >= BT_TILE) {
+                k_bitonic_global_step2<<<(unsigned)((n_pow2 / 4 + 255) / 256), 256, 0, s>>>(rec, n_pow2 / 4, (unsigned)k, (unsigned)j);
+                j >>= 1;
+            } else {
+                k_bitonic_global_step<<<(unsigned)((n_pow2 / 2 + 255) / 256), 256, 0, s>>>(rec, n_pow2 / 2, (unsigned)k, (unsigned)j);
+            }
+        }
         k_bitonic_local_merge<<<tiles, BT_THREADS, 0, s>>>(rec, (unsigned)k);
     }
     TDV_CHECK_LAUNCH(ctx);
