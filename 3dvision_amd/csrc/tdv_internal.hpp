@@ -168,6 +168,9 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
                          float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out);
 
 int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
+// every segment [d_seg_start[c], d_seg_start[c + 1]) sorted on its own in one launch; segments of at most segment_sort_max_len() records
+int segment_sort_records_dev(tdv_ctx* ctx, uint4* rec, const int* d_seg_start, int nseg);
+int segment_sort_max_len();
 size_t sort_pow2(size_t n);
 int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_total);  // voxel.hip
 // Morton-ordered copy of a cloud with the bounding boxes of its 64-point leaves and 4096-point groups (workspace memory):

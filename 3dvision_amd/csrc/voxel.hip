@@ -142,6 +142,39 @@ int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2) {
     return TDV_OK;
 }
 
+// Every segment [seg_start[c], seg_start[c + 1]) of rec sorted on its own, one workgroup and one launch for all of them:
+// for segments of at most BT_TILE records (the caller checks), e.g. the columns of the descriptor index, whose records
+// only have to be ordered inside their column.
+__global__ __launch_bounds__(BT_THREADS)
+void k_bitonic_segment_sort(uint4* __restrict__ rec, const int* __restrict__ seg_start) {
+    __shared__ uint4 s[BT_TILE];
+    const int c0 = seg_start[blockIdx.x], m = seg_start[blockIdx.x + 1] - c0;
+    if (m <= 1) return;
+    const int t = threadIdx.x;
+    const uint4 pad = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    s[t] = t < m ? rec[(size_t)c0 + t] : pad;
+    s[t + BT_THREADS] = t + BT_THREADS < m ? rec[(size_t)c0 + t + BT_THREADS] : pad;
+    __syncthreads();
+    int span = 2;
+    while (span < m) span <<= 1;                      // the padded power of two that holds the segment
+    for (int k = 2; k <= span; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int i = ((t / j) * (j << 1)) + (t % j);
+            if (i + j < span) cmpxchg(s[i], s[i + j], (i & k) == 0);
+            __syncthreads();
+        }
+    }
+    if (t < m) rec[(size_t)c0 + t] = s[t];
+    if (t + BT_THREADS < m) rec[(size_t)c0 + t + BT_THREADS] = s[t + BT_THREADS];
+}
+int segment_sort_records_dev(tdv_ctx* ctx, uint4* rec, const int* d_seg_start, int nseg) {
+    if (nseg <= 0) return TDV_OK;
+    k_bitonic_segment_sort<<<nseg, BT_THREADS, 0, ctx->stream>>>(rec, d_seg_start);
+    TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+int segment_sort_max_len() { return BT_TILE; }
+
 // ---- grouping by hashing (the default; the bitonic sort above is the fallback) -------------------------------------
 // Members of a voxel only have to become one run in ascending input index; the order of the runs is irrelevant
 // (positions come from the leader scan).  So: bucket = hash(cell) into >= 2n buckets (counting sort, integer atomics),
