@@ -381,7 +381,7 @@ int feature_match_keyorder_dev(tdv_ctx* ctx, const float* d_fs, int ns, const fl
 // FPFH descriptors of a surface live close to a 3-D manifold of R^33 (96 % of their variance in three principal
 // directions on the relief part).  The targets are therefore packed sort-tile-recursive along those directions:
 // equal-count slabs along p0, equal-count columns along p1 inside every slab, rows sorted along p2 inside every column
-// (three sorts of 16-B records; slab / column counts proportional to the spread, chosen on the host from the
+// (two full sorts of 16-B records and one segmented sort inside the columns; slab / column counts proportional to the spread, chosen on the host from the
 // eigenvalues).  Columns are padded to a multiple of 64 rows (+inf rows that never win), so a leaf = 64 consecutive
 // rows never straddles two columns; group = 64 consecutive leaves.  Offline study on real descriptors
 // (tools/studies/feature_match_pca_tree.py): a wave of 64 neighbouring sources has to open 2.3 % of the leaves with
