@@ -338,6 +338,24 @@ void k_icp_nn_grid(const float* __restrict__ src, int ns, const GridEntry* __res
     out_idx[i] = bo == INT_MAX ? 0 : bo;
 }
 
+// Sum over the 64 lanes with DPP row operations on the two halves of the double (no LDS crossbar round trips, unlike
+// __shfl_down): valid in lane 63.  A fixed order, like the shuffle tree it replaces.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v += dpp_f64<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(v);    // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(v);    // row_mirror: every lane of a 16-lane row holds the row sum
+    v += dpp_f64<0x142, 0xA>(v);    // row_bcast15 into rows 1 and 3 (a disabled row receives +0)
+    v += dpp_f64<0x143, 0xC>(v);    // row_bcast31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -482,8 +500,8 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        double s = wave_sum(v[k]);
-        if (lane == 0) red[wave][k] = s;
+        const double s = wave_sum_lane63(v[k]);
+        if (lane == 63) red[wave][k] = s;
     }
     __syncthreads();
     if (threadIdx.x < ACC_NV) {
