@@ -468,7 +468,11 @@ constexpr int DE_TPW = DE_TPW_VALUE;   // tiles per wave
 // workgroups can be launched (151k waves, most of them gone after one load; 19 % of the wave slots occupied — SQ counters
 // in profiles/r2): a wave therefore takes DE_TPW tiles, strided by the number of waves of its instance so that every wave
 // gets its share of the contiguous band of occupied tiles, and loads all their bitmap words before it looks at the first.
-template <bool FAST_DIV>
+// ROWS (pixel count a multiple of 1,024: whole tiles only): the 64-bit validity mask of round j IS the j-th 8-byte word of
+// the tile's 128-byte row of the bitmap, at a wave-uniform address — the wave reads the 16 masks of a tile with two
+// scalar loads instead of assembling each from four v_readlane (the SQ counters showed 755 scalar next to 840 vector
+// instructions per wave, most of them this assembling).
+template <bool FAST_DIV, bool ROWS>
 __global__ __launch_bounds__(DE_BLOCK)
 void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ bgr0, const uint16_t* __restrict__ bits,
                        int width, size_t n, float inv_scale, float fx, float fy, float cx, float cy, int ntiles,
@@ -476,7 +480,7 @@ void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict_
     __shared__ __attribute__((aligned(16))) uint16_t zraw[DE_BLOCK / 64][DB_TILE];
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int first = blockIdx.x * (DE_BLOCK / 64) + wave, stride = gridDim.x * (DE_BLOCK / 64);
+    const int first = __builtin_amdgcn_readfirstlane(blockIdx.x * (DE_BLOCK / 64) + wave), stride = gridDim.x * (DE_BLOCK / 64);   // wave-uniform, and known as such
     const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
     const uint16_t* __restrict__ raw = raw0 + frame * n;
     const uint8_t* __restrict__ bgr = (rgb && bgr0) ? bgr0 + frame * n * 3 : nullptr;
@@ -511,10 +515,20 @@ void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict_
         unsigned row = (unsigned)(t0 / (size_t)width);
         unsigned col = (unsigned)(t0 - (size_t)row * (size_t)width) + (unsigned)lane;
         while (col >= (unsigned)width) { col -= (unsigned)width; ++row; }
-#pragma unroll 1
+        unsigned long long mrow[ROWS ? DB_PX : 1];
+        if (ROWS) {
+            const unsigned long long* __restrict__ mp = reinterpret_cast<const unsigned long long*>(bits + (size_t)b * (n / DB_PX)) + (size_t)tile * DB_PX;   // wave-uniform: scalar loads
+#pragma unroll
+            for (int j = 0; j < DB_PX; ++j) mrow[j] = mp[j];
+        }
+#pragma unroll ROWS ? DB_PX : 1
         for (int j = 0; j < DB_PX; ++j) {                             // round j: pixels t0 + 64 j .. + 63
-            const unsigned m_lo = (unsigned)__builtin_amdgcn_readlane((int)word, 4 * j) | ((unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 1) << 16);
-            const unsigned m_hi = (unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 2) | ((unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 3) << 16);
+            unsigned m_lo, m_hi;
+            if (ROWS) { m_lo = (unsigned)mrow[ROWS ? j : 0]; m_hi = (unsigned)(mrow[ROWS ? j : 0] >> 32); }
+            else {
+                m_lo = (unsigned)__builtin_amdgcn_readlane((int)word, 4 * j) | ((unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 1) << 16);
+                m_hi = (unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 2) | ((unsigned)__builtin_amdgcn_readlane((int)word, 4 * j + 3) << 16);
+            }
             if (m_lo | m_hi) {                                        // wave-uniform
                 if ((m_lo & bit_lo) | (m_hi & bit_hi)) {
                     const float z = (float)zraw[wave][64 * j + lane] * inv_scale;   // pipeline.cpp:47
@@ -646,10 +660,11 @@ int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_
         const int ntiles = (int)((n + DB_TILE - 1) / DB_TILE);
         const int tiles_per_block = (DE_BLOCK / 64) * DE_TPW;
         const dim3 grid((ntiles + tiles_per_block - 1) / tiles_per_block, n_inst);
-        if (emit_fast_div_ok(fx, fy, cx, cy, inv_scale, w, h))
-            k_depth_emit_bits<true><<<grid, DE_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_bgr, ctx->depth_bits, w, n, inv_scale, fx, fy, cx, cy, ntiles, d_offsets, d_xyz, d_rgb);
-        else
-            k_depth_emit_bits<false><<<grid, DE_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_bgr, ctx->depth_bits, w, n, inv_scale, fx, fy, cx, cy, ntiles, d_offsets, d_xyz, d_rgb);
+        const bool fd = emit_fast_div_ok(fx, fy, cx, cy, inv_scale, w, h), rows = n % DB_TILE == 0;
+#define TDV_EMIT(FD, RW) k_depth_emit_bits<FD, RW><<<grid, DE_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_bgr, ctx->depth_bits, w, n, inv_scale, fx, fy, cx, cy, ntiles, d_offsets, d_xyz, d_rgb)
+        if (fd) { if (rows) TDV_EMIT(true, true); else TDV_EMIT(true, false); }
+        else { if (rows) TDV_EMIT(false, true); else TDV_EMIT(false, false); }
+#undef TDV_EMIT
     } else {
         const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
         k_emit_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, d_bgr, w, n, stacked, inv_scale, mask_mode,
