@@ -235,15 +235,22 @@ void k_icp_nn_pruned(const float* __restrict__ src, int ns,
 // e <= 2^-6 while |coordinate| < 2^17 - which k_grid_insert checks on every target (a query within thr of a target is in
 // range with it).  A query with computed fraction f < 0.5 in cell k sees a neighbour's computed coordinate inside
 // [k - r - 2e, k + 0.5 + r + 2e) and r + 2e < 0.486: cells k - 1 and k; symmetrically k and k + 1 for f >= 0.5.
-constexpr unsigned long long GRID_EMPTY = ~0ull;
+constexpr unsigned GRID_EMPTY = ~0u;
+#ifndef GRID_SLOTS_PER_POINT_X4
+#define GRID_SLOTS_PER_POINT_X4 8      // table slots per target point, in quarters (8 = the power of two >= 2 n)
+#endif
 constexpr float GRID_CELL_FACTOR = 2.2f;
 constexpr float GRID_MAX_COORD = 131072.0f;      // 2^17 cells
 constexpr int GRID_MAX_PER_CELL = 32;            // average over the occupied cells above which the grid is not used (measured at 200k x 200k, threshold in spacings: 2 -> 19 per cell, grid 0.13 ms vs walk 0.20; 4 -> 77 per cell, 0.37 vs 0.21)
-struct __attribute__((aligned(16))) GridEntry { unsigned long long key; int head; int pad; };
+struct __attribute__((aligned(8))) GridEntry { unsigned tag; int head; };   // tag: 32 bits of the cell key's hash (two cells that share a tag and a probe chain share a list: every candidate is verified anyway)
 __device__ __forceinline__ unsigned long long grid_key(int ix, int iy, int iz) {
     return ((unsigned long long)((unsigned)ix & 0x1fffffu) << 42) | ((unsigned long long)((unsigned)iy & 0x1fffffu) << 21) | (unsigned long long)((unsigned)iz & 0x1fffffu);
 }
 __device__ __forceinline__ unsigned grid_slot(unsigned long long key, int shift) { return (unsigned)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+__device__ __forceinline__ unsigned grid_tag(unsigned long long key) {
+    const unsigned t = (unsigned)((key * 0xD6E8FEB86659FD93ull) >> 32);
+    return t == GRID_EMPTY ? GRID_EMPTY - 1u : t;
+}
 
 // flags[0]: a coordinate out of range / non-finite; flags[1]: occupied cells
 __global__ __launch_bounds__(256)
@@ -260,11 +267,12 @@ void k_grid_insert(const float* __restrict__ tgt, int nt, float inv_cell, GridEn
         bad = !(fabsf(fx) < GRID_MAX_COORD && fabsf(fy) < GRID_MAX_COORD && fabsf(fz) < GRID_MAX_COORD);
         if (!bad) {
             const unsigned long long key = grid_key((int)floorf(fx), (int)floorf(fy), (int)floorf(fz));
+            const unsigned tag = grid_tag(key);
             unsigned slot = grid_slot(key, shift);
             for (;;) {
-                unsigned long long k = table[slot].key;
-                if (k == GRID_EMPTY) { k = atomicCAS(&table[slot].key, GRID_EMPTY, key); if (k == GRID_EMPTY) { fresh = true; break; } }
-                if (k == key) break;
+                unsigned k = table[slot].tag;
+                if (k == GRID_EMPTY) { k = atomicCAS(&table[slot].tag, GRID_EMPTY, tag); if (k == GRID_EMPTY) { fresh = true; break; } }
+                if (k == tag) break;
                 slot = (slot + 1) & mask;        // half full at most
             }
             node[j] = make_float4(x, y, z, __int_as_float(atomicExch(&table[slot].head, j)));   // the point and the next index of its cell's list
@@ -283,24 +291,25 @@ __device__ __forceinline__ void grid_nearest(const GridEntry* __restrict__ table
     const float kx = floorf(gx), ky = floorf(gy), kz = floorf(gz);
     const int cx = (int)kx, cy = (int)ky, cz = (int)kz;
     const int sx = (gx - kx < 0.5f) ? -1 : 1, sy = (gy - ky < 0.5f) ? -1 : 1, sz = (gz - kz < 0.5f) ? -1 : 1;   // the adjacent cell that can matter
-    unsigned long long key[8]; unsigned slot[8]; uint4 e[8];
+    unsigned tag[8], slot[8]; uint2 e[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {                          // the eight table entries: independent loads, all in flight together
-        key[c] = grid_key(cx + ((c & 1) ? sx : 0), cy + ((c & 2) ? sy : 0), cz + ((c & 4) ? sz : 0));
-        slot[c] = grid_slot(key[c], shift);
-        e[c] = *reinterpret_cast<const uint4*>(&table[slot[c]]);
+    for (int c = 0; c < 8; ++c) {                          // the eight table entries: independent 8-byte loads, all in flight together
+        const unsigned long long key = grid_key(cx + ((c & 1) ? sx : 0), cy + ((c & 2) ? sy : 0), cz + ((c & 4) ? sz : 0));
+        tag[c] = grid_tag(key);
+        slot[c] = grid_slot(key, shift);
+        e[c] = *reinterpret_cast<const uint2*>(&table[slot[c]]);
     }
     int j[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        unsigned long long k = ((unsigned long long)e[c].y << 32) | e[c].x;
-        j[c] = (int)e[c].z;
-        while (k != key[c] && k != GRID_EMPTY) {           // linear probing: rarely more than one step
+        unsigned k = e[c].x;
+        j[c] = (int)e[c].y;
+        while (k != tag[c] && k != GRID_EMPTY) {           // linear probing: rarely more than one step
             slot[c] = (slot[c] + 1) & mask;
-            const uint4 n = *reinterpret_cast<const uint4*>(&table[slot[c]]);
-            k = ((unsigned long long)n.y << 32) | n.x; j[c] = (int)n.z;
+            const uint2 n = *reinterpret_cast<const uint2*>(&table[slot[c]]);
+            k = n.x; j[c] = (int)n.y;
         }
-        if (k != key[c]) j[c] = -1;
+        if (k != tag[c]) j[c] = -1;
     }
     bd = INFINITY; bo = INT_MAX;
     auto take = [&](const float4 t, int idx) {
@@ -592,7 +601,7 @@ int cell_grid_build(tdv_ctx* ctx, const float* d_tgt, int nt, float thr, CellGri
     const float inv_cell = 1.0f / cell;
     if (!(thr > 0.f) || !(cell <= FLT_MAX) || !(inv_cell > 0.f) || !(inv_cell <= FLT_MAX)) return TDV_OK;   // usable = 0
     size_t size = 1024; int log2 = 10;
-    while (size < 2 * (size_t)nt) { size <<= 1; ++log2; }
+    while (size < (size_t)GRID_SLOTS_PER_POINT_X4 * (size_t)nt / 4) { size <<= 1; ++log2; }
     GridEntry* table; float4* node; int* flags;
     TDV_TRY(ws_alloc(ctx, size, &table));
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &node));
