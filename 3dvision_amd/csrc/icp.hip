@@ -227,9 +227,9 @@ void k_icp_nn_pruned(const float* __restrict__ src, int ns,
 // the point spacing.  One LANE per source point looks its neighbourhood up in a hash grid over the target and verifies
 // what it finds with the scan's distance expression, instead of one WAVE per source point walking box levels.
 // Cells are 2.2 thr wide, so per axis a neighbour within thr lies in the query's cell or in ONE adjacent cell, the one on
-// the side of the cell the query sits in: 8 probes of an open-addressing table (16-B entries: key, list head), all loaded
+// the side of the cell the query sits in: 8 probes of an open-addressing table (8-B entries: 32-bit tag of the cell key, list head), all loaded
 // before the first is looked at.  The points of a cell form a linked list of original indices (order irrelevant: the
-// lowest (d2, index) is kept).  Every candidate is verified (d2 <= tau), so a key collision or the garbage cell of a
+// lowest (d2, index) is kept).  Every candidate is verified (d2 <= tau), so a tag collision or the garbage cell of a
 // far-away query can only cost time.  Completeness: in cell units a pair within thr is at most r = 1/2.2 (1 + 1e-6) apart
 // per axis; a computed coordinate fl(x * inv_cell) is within e = 2^-23 |coordinate| (two roundings) of the real one, i.e.
 // e <= 2^-6 while |coordinate| < 2^17 - which k_grid_insert checks on every target (a query within thr of a target is in

@@ -115,7 +115,7 @@ struct IcpOutputs {  // optional per-source outputs of one correspondence pass (
 };
 struct SortedCloud;
 // Hash grid over a target cloud for ICP's correspondence search at one acceptance threshold (icp.hip): cells of 2.2 x
-// the threshold, open-addressing table of (cell key, list head), the points of a cell as a linked list of (x, y, z, next) nodes indexed like the cloud.  Lives
+// the threshold, open-addressing table of (32-bit cell tag, list head), the points of a cell as a linked list of (x, y, z, next) nodes indexed like the cloud.  Lives
 // in the workspace of the ctx that built it; read-only afterwards.  usable = 0: coordinates too large for the cell
 // arithmetic or too many points per cell (the threshold is large against the spacing) - the caller takes another search.
 struct CellGrid { const void* table; const void* node; unsigned mask; int shift; float inv_cell; float thr; int n; int usable; };
