@@ -12,6 +12,11 @@
 
 namespace tdv {
 
+__global__ void k_gather_i32(const int* __restrict__ in, const int* __restrict__ idx, int n, int* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = in[idx[p]];
+}
+
 int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr, const uint8_t* d_masks, int n_instances,
                        const tdv_batch_params* prm, const float* d_model_xyz, const float* d_model_normals,
                        const float* d_model_fpfh, int n_model, tdv_instance_result* results) {
@@ -54,6 +59,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
             have_sorted = true;
         }
     }
+    static const bool coherent_stages = !(getenv("TDV_BATCH_COHERENT") && atoi(getenv("TDV_BATCH_COHERENT")) == 0);   // A/B knob
     // one instance: voxel -> normals + FPFH -> match -> RANSAC -> ICP on context c (its stream, its workspace)
     auto run_instance = [&](tdv_ctx* c, int b) -> int {
         tdv_instance_result& r = results[b];
@@ -66,16 +72,36 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         float* xyz = all_xyz + (size_t)off[b] * 3;
         float* vx; int v = 0;
         TDV_TRY(ws_alloc(c, (size_t)n * 3, &vx));
-        TDV_TRY(voxel_downsample_dev(c, xyz, nullptr, n, prm->voxel_size, prm->voxel_order, vx, nullptr, n, &v));
+        // The reference's container order scatters neighbouring voxels over the whole array, which costs the per-point stages
+        // (radius search, SPFH / FPFH gathers, descriptor search) their locality.  Those stages are per point: they run on the
+        // same voxels in first-occurrence order (image order: coherent), with every neighbour list ordered by the reference
+        // POSITIONS of its members — so each point's normal, descriptor and match carry the bits they have in the reference
+        // order — and only the correspondences are permuted.  RANSAC (which draws points by position) and ICP (whose sums
+        // run over positions) see the cloud in the reference's order.
+        const bool coherent = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE && coherent_stages && prm->normals_k <= 100;
+        VoxelBothOrders both{nullptr, nullptr, nullptr};
+        if (coherent) {
+            TDV_TRY(ws_alloc(c, (size_t)n * 3, &both.first_xyz));
+            TDV_TRY(ws_alloc(c, (size_t)n, &both.ref2first));
+            TDV_TRY(ws_alloc(c, (size_t)n, &both.first2ref));
+        }
+        TDV_TRY(voxel_downsample_dev(c, xyz, nullptr, n, prm->voxel_size, prm->voxel_order, vx, nullptr, n, &v, coherent ? &both : nullptr));
         r.n_voxels = v;
         float *nrm, *fpfh; int* corr;
         TDV_TRY(ws_alloc(c, (size_t)v * 3, &nrm));
         TDV_TRY(ws_alloc(c, (size_t)v * 33, &fpfh));
         TDV_TRY(ws_alloc(c, (size_t)v, &corr));
-        TDV_TRY(normals_fpfh_dev(c, vx, v, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor, nrm, fpfh));
+        int* corr_stage = corr;
+        if (coherent) TDV_TRY(ws_alloc(c, (size_t)v, &corr_stage));
+        TDV_TRY(normals_fpfh_dev(c, coherent ? both.first_xyz : vx, v, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor, nrm, fpfh,
+                                 coherent ? both.first2ref : nullptr, coherent ? both.ref2first : nullptr));
         tdv_ransac_result coarse;
-        if (have_index && v >= 4096) TDV_TRY(feature_match_indexed_dev(c, fpfh, v, model_index, corr));
-        else TDV_TRY(feature_match_dev(c, fpfh, v, d_model_fpfh, n_model, corr));
+        if (have_index && v >= 4096) TDV_TRY(feature_match_indexed_dev(c, fpfh, v, model_index, corr_stage));
+        else TDV_TRY(feature_match_dev(c, fpfh, v, d_model_fpfh, n_model, corr_stage));
+        if (coherent && v > 0) {
+            k_gather_i32<<<(v + 255) / 256, 256, 0, c->stream>>>(corr_stage, both.ref2first, v, corr);
+            TDV_CHECK_LAUNCH(c);
+        }
         TDV_TRY(ransac_run_dev(c, vx, v, d_model_xyz, n_model, nullptr, nullptr, corr, prm->voxel_size, prm->ransac_max_iterations,
                                prm->ransac_confidence, prm->seed, &coarse, nullptr));
         r.coarse_fitness = coarse.fitness; r.coarse_inliers = coarse.inliers;
@@ -98,7 +124,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // 3 / 4 / 6 lanes 525 / 514 / 532.  Hence 8 resp. 3 lanes by default; TDV_BATCH_LANES overrides (1 = the caller's
     // thread only, at most 12).
     static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;
-    const int lanes_default = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 8 : 3;
+    const int lanes_default = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 10 : 3;
     const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 12), n_instances));
     std::vector<tdv_ctx*> lane_ctx{ctx};
     for (tdv_ctx* c = ctx; (int)lane_ctx.size() < want; c = c->helper) {

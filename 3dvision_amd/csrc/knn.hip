@@ -252,7 +252,9 @@ __global__ __launch_bounds__(64 * QW_WAVES)
 void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, const float* __restrict__ sz,
                   const int* __restrict__ orig, int n, int n_leaf, const float* __restrict__ lbox, int n_top, const float* __restrict__ tbox,
                   const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, float bound0, int seed_own,
-                  int k, int stride, int* __restrict__ lists, int* __restrict__ cnt_out) {
+                  int k, int stride, int* __restrict__ lists, int* __restrict__ cnt_out,
+                  const int* __restrict__ okey /* sorted position -> tie-break id (null: orig) */,
+                  const int* __restrict__ key2idx /* tie-break id -> array index written to the lists (null: the id itself) */) {
     constexpr int ROW = 64 * R;
     __shared__ unsigned long long rows[QW_WAVES][ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -328,7 +330,7 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
             if (!am) return;
         }
         const int at = wcnt + __popcll(am & ((1ull << lane) - 1ull));
-        if (acc) row[at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig[pidx];
+        if (acc) row[at] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)(okey ? okey[pidx] : orig[pidx]);
         wcnt += __popcll(am);
     };
 
@@ -384,7 +386,7 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int e = r * 64 + lane;
-        if (e < c) lists[(size_t)i0 * stride + e] = (int)(unsigned)key[r];   // a row per query: coalesced
+        if (e < c) lists[(size_t)i0 * stride + e] = key2idx ? key2idx[(int)(unsigned)key[r]] : (int)(unsigned)key[r];   // a row per query: coalesced
     }
     if (lane == 0) cnt_out[i0] = c;
 }
@@ -591,7 +593,10 @@ ScanPlan make_scan_plan(int n) {
     return p;
 }
 
-struct Sorted { float *sx, *sy, *sz; int* orig; float *lbox, *tbox; int n_leaf, n_top; };
+// okey / key2idx (optional): ties in (d2, id) order are broken by okey[position] instead of the array index, and the lists
+// receive key2idx[id] — the batch runs these stages on the voxel cloud in first-occurrence order (spatially coherent: the
+// gathers of the estimators stay local) while ordering every list as the reference's container order would.
+struct Sorted { float *sx, *sy, *sz; int* orig; float *lbox, *tbox; int n_leaf, n_top; const int* okey = nullptr; const int* key2idx = nullptr; };
 
 // Morton sort of the cloud: sorted SoA coordinates (padded with +inf) and the original index of each position
 int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sorted& so) {
@@ -655,7 +660,7 @@ int query_to_lists(tdv_ctx* ctx, const Sorted& so, int n, const ScanPlan& p, int
     const unsigned grid = (unsigned)((nqq + QW_WAVES - 1) / QW_WAVES);
     ScopedTimer tm(ctx, timer);
 #define TDV_QW(RR) k_query_wave<RR, QW_SEED_SPAN, QW_BEST_FIRST><<<grid, 64 * QW_WAVES, 0, s>>>(so.sx, so.sy, so.sz, so.orig, n, so.n_leaf, so.lbox, so.n_top, so.tbox, \
-                                                            qsel, nqq, bound, bound0, seed_own, k, k, lists, cnt)
+                                                            qsel, nqq, bound, bound0, seed_own, k, k, lists, cnt, so.okey, so.key2idx)
     if (k <= 64) TDV_QW(2);
     else if (k <= 192) TDV_QW(4);
     else if (k <= 448) TDV_QW(8);
@@ -726,11 +731,19 @@ int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, i
 // spatial sort and ONE full scan: the radius lists are sorted by (d2, idx), so wherever a point has >= k
 // neighbours in radius its k nearest neighbours are the first k entries; only the deficient points (isolated
 // points, silhouette edges) go through a kNN scan, as a subset.  Results are identical to the two separate calls.
-int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc) {
+__global__ void k_gather_ids(const int* __restrict__ orig, const int* __restrict__ ids, int n, int n_pad, int* __restrict__ okey) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n_pad) okey[p] = p < n ? ids[orig[p]] : INT_MAX;
+}
+
+int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc,
+                     const int* d_tie_ids, const int* d_tie_ids_inv) {
     if (!ctx || n < 0 || k <= 0 || k > 255 || (n > 0 && (!d_xyz || !d_normals || !d_desc))) return TDV_ERR_BAD_ARG;
+    if ((d_tie_ids == nullptr) != (d_tie_ids_inv == nullptr)) return TDV_ERR_BAD_ARG;
     if (n == 0) return TDV_OK;
     const int kk = std::min(k, n);
     if (kk > FP_MAXNN) {  // a radius list (cap 100) cannot serve as the kNN list: the two plain calls
+        if (d_tie_ids) return TDV_ERR_BAD_ARG;   // (the batch never gets here: its k is the reference's 30)
         TDV_TRY(estimate_normals_dev(ctx, d_xyz, n, k, d_normals, nullptr));
         return compute_fpfh_dev(ctx, d_xyz, d_normals, n, radius, d_desc, nullptr, nullptr);
     }
@@ -739,6 +752,13 @@ int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radiu
     hipStream_t s = ctx->stream;
     Sorted so; int *nbr, *cnt, *flag, *pos, *qsel, *d_total, *listsK, *cntK;
     TDV_TRY(spatial_sort(ctx, d_xyz, n, p, so));
+    if (d_tie_ids) {
+        const int pad = std::max(p.n_pad, (int)align_up((size_t)p.nt_pad, 16));
+        int* okey;
+        TDV_TRY(ws_alloc(ctx, (size_t)pad, &okey));
+        k_gather_ids<<<(pad + 255) / 256, 256, 0, s>>>(so.orig, d_tie_ids, n, pad, okey);
+        so.okey = okey; so.key2idx = d_tie_ids_inv;
+    }
     TDV_TRY(ws_alloc(ctx, (size_t)FP_MAXNN * p.n_pad, &nbr));
     TDV_TRY(ws_alloc(ctx, (size_t)p.n_pad, &cnt));
     TDV_TRY(radius_to_lists(ctx, so, n, p, FP_MAXNN, r2, nbr, cnt));

@@ -164,8 +164,11 @@ int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_
 int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* d_normals, int* d_knn);
 int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
                      float* d_desc, int* d_nbr, int* d_nbr_cnt);
+// With TDV_VOXEL_ORDER_REFERENCE, `both` (optional) also receives the cloud in first-occurrence order and the permutation
+// between the two orders: out_xyz[p] == first_xyz[ref2first[p]], first2ref[ref2first[p]] == p (each of capacity entries).
+struct VoxelBothOrders { float* first_xyz; int* ref2first; int* first2ref; };
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                         float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out);
+                         float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, const VoxelBothOrders* both = nullptr);
 
 int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
 // every segment [d_seg_start[c], d_seg_start[c + 1]) sorted on its own in one launch; segments of at most segment_sort_max_len() records
@@ -180,7 +183,10 @@ struct SortedCloud { float *sx, *sy, *sz; int* orig; float *lbox, *tbox; int n, 
 int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out);
 
 // normals + FPFH in one go, sharing one spatial sort and one radius scan (batch path; identical results)
-int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc);                                      // padded record count for sort_records_dev
+// d_tie_ids / d_tie_ids_inv (optional, both or neither): neighbour lists are ordered by (d2, d_tie_ids[index]) instead of
+// (d2, index) — the results are those of the cloud permuted so that point i sits at position d_tie_ids[i]
+int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc,
+                     const int* d_tie_ids = nullptr, const int* d_tie_ids_inv = nullptr);                                      // padded record count for sort_records_dev
 
 int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr, const uint8_t* d_masks, int n_instances,
                        const tdv_batch_params* prm, const float* d_model_xyz, const float* d_model_normals,

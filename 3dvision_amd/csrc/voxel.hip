@@ -384,10 +384,12 @@ void k_voxel_means(const uint4* __restrict__ rec, int n, const float* __restrict
 
 // out[p] = in[rank[order_first[p]]]
 __global__ void k_voxel_permute(const float* __restrict__ in_xyz, const float* __restrict__ in_rgb, const int* __restrict__ rank,
-                                const int* __restrict__ order_first, int v, float* __restrict__ out_xyz, float* __restrict__ out_rgb) {
+                                const int* __restrict__ order_first, int v, float* __restrict__ out_xyz, float* __restrict__ out_rgb,
+                                int* __restrict__ ref2first, int* __restrict__ first2ref) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= v) return;
     int s = rank[order_first[p]];
+    if (ref2first) { ref2first[p] = s; first2ref[s] = p; }
     out_xyz[3 * (size_t)p] = in_xyz[3 * (size_t)s]; out_xyz[3 * (size_t)p + 1] = in_xyz[3 * (size_t)s + 1]; out_xyz[3 * (size_t)p + 2] = in_xyz[3 * (size_t)s + 2];
     if (in_rgb && out_rgb) { out_rgb[3 * (size_t)p] = in_rgb[3 * (size_t)s]; out_rgb[3 * (size_t)p + 1] = in_rgb[3 * (size_t)s + 1]; out_rgb[3 * (size_t)p + 2] = in_rgb[3 * (size_t)s + 2]; }
 }
@@ -477,17 +479,18 @@ int exclusive_scan_dev(tdv_ctx* ctx, const int* d_in, int n, int* d_out, int* d_
 size_t sort_pow2(size_t n) { size_t p = BT_TILE; while (p < n) p <<= 1; return p; }
 
 static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                                 float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort);
+                                 float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort, const VoxelBothOrders* both);
 
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                         float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out) {
-    return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false);
+                         float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, const VoxelBothOrders* both) {
+    return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
 }
 
 static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
-                                 float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort) {
+                                 float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, bool full_sort, const VoxelBothOrders* both) {
     if (!ctx || !n_out || n < 0 || capacity < 0 || !(voxel > 0.f) || (n > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
     if (order != TDV_VOXEL_ORDER_FIRST && order != TDV_VOXEL_ORDER_REFERENCE) return TDV_ERR_BAD_ARG;
+    if (both && (order != TDV_VOXEL_ORDER_REFERENCE || !both->first_xyz || !both->ref2first || !both->first2ref)) return TDV_ERR_BAD_ARG;
     *n_out = 0;
     if (n == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
@@ -539,7 +542,7 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     if (hashed) TDV_HIP(ctx, hipMemcpyAsync(h_total + 1, d_too_big, 4, hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
     if (hashed && h_total[1])   // a bucket too large for the per-lane sort (very coarse grid): redo with the full sort
-        return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, true);
+        return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, true, both);
     const int v = *h_total;
     *n_out = v;
     if (v > capacity) return TDV_ERR_BAD_ARG;
@@ -551,7 +554,8 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     }
     // reference order: replay the container on the host to get its iteration order
     float *tmp_xyz, *tmp_rgb = nullptr; int* d_order;
-    TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_xyz));
+    if (both) tmp_xyz = both->first_xyz;
+    else TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_xyz));
     if (d_rgb && d_out_rgb) TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_rgb));
     TDV_TRY(ws_alloc(ctx, (size_t)v, &d_order));
     if (hashed) k_voxel_compact<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, n, mean_xyz, mean_rgb, v, tmp_xyz, tmp_rgb);
@@ -595,7 +599,8 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), real_map ? "std::unordered_map" : "emulation");
     if (n_first != v) { snprintf(ctx->err, sizeof(ctx->err), "voxel: host replay listed %d voxels, device %d", n_first, v); return TDV_ERR_INTERNAL; }
     TDV_HIP(ctx, hipMemcpyAsync(d_order, order_pinned, (size_t)v * 4, hipMemcpyHostToDevice, s));
-    k_voxel_permute<<<(v + 255) / 256, 256, 0, s>>>(tmp_xyz, tmp_rgb, rank, d_order, v, d_out_xyz, d_out_rgb);
+    k_voxel_permute<<<(v + 255) / 256, 256, 0, s>>>(tmp_xyz, tmp_rgb, rank, d_order, v, d_out_xyz, d_out_rgb,
+                                                    both ? both->ref2first : nullptr, both ? both->first2ref : nullptr);
     TDV_CHECK_LAUNCH(ctx);
     TDV_HIP(ctx, hipStreamSynchronize(s));  // the pinned staging is reused by the next call
     return TDV_OK;

@@ -141,3 +141,48 @@ def test_instances_sharing_frames(ctx, tdv, synth, scene):
     with pytest.raises(tdv.TdvError):
         ctx.depth_to_cloud_batch_dev(d_depth.data_ptr(), d_masks.data_ptr(), None, N_INST, cs.W, cs.H, cs.SCALE, cs.F, cs.F, cs.CX, cs.CY, cs.ZMAX,
                                      d_xyz.data_ptr(), None, cap, n_frames=N_INST, frame_of_instance=np.array([0, 1, 3], np.int32))
+
+
+def test_batched_chain_tie_heavy_terraces(ctx, tdv, synth):
+    """Terraces of constant depth seen head-on: pixels and voxel means sit on lattices, so nearly every neighbour list holds
+    runs of exactly equal distances, whose order is decided by the members' positions in the reference's container order.
+    The batch computes normals, descriptors and matches on the first-occurrence order with those positions as tie-break ids
+    (csrc/batch.hip); it has to return what the operators return on the reference-ordered cloud, bit for bit."""
+    dev = torch.device("cuda", 0)
+    w, h, f = 256, 192, 500.0
+    intr = dict(fx=f, fy=f, cx=w / 2.0, cy=h / 2.0)
+    voxel, scale, zmax = 0.004, 1000.0, 1.5
+    v, u = np.mgrid[0:h, 0:w]
+
+    def frame(shift, seed):
+        steps = ((u + shift) // 24 + 2 * ((v + 2 * shift) // 16)) % 5
+        bumps = np.random.default_rng(seed).integers(0, 2, (h // 16 + 2, w // 24 + 2))[(v + 2 * shift) // 16, (u + shift) // 24]
+        d = (500 + 6 * steps + 3 * bumps).astype(np.uint16)
+        m = np.zeros((h, w), np.uint8); m[8:h - 8, 8:w - 8] = 255
+        return d, m
+
+    md, mm = frame(0, 5)
+    depth = np.stack([frame(3, 5)[0], frame(7, 5)[0]]); masks = np.stack([mm, mm])
+    raw, _ = ctx.depth_to_cloud(md, mm, None, scale, f, f, w / 2.0, h / 2.0, zmax)
+    d_raw = torch.from_numpy(raw).to(dev)
+    d_mx = torch.empty_like(d_raw); d_mn = torch.empty_like(d_raw); d_mf = torch.empty((len(raw), 33), dtype=torch.float32, device=dev)
+    nm = ctx.prepare_model_dev(d_raw.data_ptr(), len(raw), voxel, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), order=tdv.TDV_VOXEL_ORDER_REFERENCE)
+    mx = d_mx[:nm].cpu().numpy(); mn = d_mn[:nm].cpu().numpy(); mf = d_mf[:nm].cpu().numpy()
+    prm = tdv.batch_params(width=w, height=h, scale_to_meters=scale, zmax=zmax, voxel_size=voxel, ransac_max_iterations=1500,
+                           icp_max_iterations=10, voxel_order=tdv.TDV_VOXEL_ORDER_REFERENCE, n_frames=2, **intr)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev)
+    res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 2, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+    tied = 0
+    for b, r in enumerate(res):
+        xyz, _ = ctx.depth_to_cloud(depth[b], masks[b], None, scale, f, f, w / 2.0, h / 2.0, zmax)
+        src, _ = ctx.voxel_downsample(xyz, None, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
+        nrm, knn = ctx.estimate_normals(src, 30, want_knn=True)
+        d2 = ((src[knn] - src[:, None, :]) ** 2).sum(2)
+        tied += int((np.diff(d2, axis=1) == 0).sum())
+        fp = ctx.compute_fpfh(src, nrm, voxel * 5.0)
+        coarse = ctx.ransac(src, mx, fs=fp, ft=mf, voxel=voxel, max_iterations=1500, confidence=0.999)
+        fine = ctx.icp(src, mx, mn, coarse.transformation, voxel * 0.4, 10, True)
+        assert r["status"] == 0 and r["n_voxels"] == len(src)
+        assert r["coarse_inliers"] == coarse.inliers and r["coarse_fitness"] == coarse.fitness
+        assert r["T"].tobytes() == fine.transformation.tobytes() and r["fitness"] == fine.fitness and r["rmse"] == fine.rmse
+    assert tied > 1000, tied      # the scene does what it was built for
