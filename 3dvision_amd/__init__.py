@@ -202,7 +202,7 @@ class Context:
     def set_ransac_score(self, mode):
         """'fast' (default: FMA pass, chunks inside the rounding band re-scored with the reference arithmetic) or 'exact'
         (the reference arithmetic only); same inlier counts."""
-        _check(self._h, lib().tdv_ctx_set_ransac_score(self._h, {"fast": 0, "exact": 1}[mode]), "tdv_ctx_set_ransac_score")
+        _check(self._h, lib().tdv_ctx_set_ransac_score(self._h, {"fast": 0, "exact": 1, "matrix": 2}[mode]), "tdv_ctx_set_ransac_score")
 
     def last_ransac_rescore(self):
         """Fraction of (wave, 8-point chunk) pairs the last RANSAC call scored a second time exactly (-1 in 'exact' mode)."""

@@ -208,8 +208,8 @@ int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode) {
 }
 
 int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode) {
-    if (!ctx || (mode != TDV_RANSAC_SCORE_FAST && mode != TDV_RANSAC_SCORE_EXACT)) return TDV_ERR_BAD_ARG;
-    ctx->ransac_score_exact = mode == TDV_RANSAC_SCORE_EXACT;
+    if (!ctx || (mode != TDV_RANSAC_SCORE_FAST && mode != TDV_RANSAC_SCORE_EXACT && mode != TDV_RANSAC_SCORE_MATRIX)) return TDV_ERR_BAD_ARG;
+    ctx->ransac_score_mode = mode;
     return TDV_OK;
 }
 

@@ -77,7 +77,8 @@ __device__ __forceinline__ float tau_mid_default(float sqrt_tau) { return sqrt_t
 // Rows 12, 13 of hyp: the band of the fast scoring pass for this hypothesis (RansacBand below): mid and half-width of
 // the d2 interval inside which the FMA arithmetic and the reference's arithmetic might disagree on `d2 < tau`.
 __global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __restrict__ triples, int count, int h_pad,
-                                    float* __restrict__ hyp, const unsigned* __restrict__ pmax, float sqrt_tau, int* __restrict__ counts) {
+                                    float* __restrict__ hyp, const unsigned* __restrict__ pmax, float sqrt_tau, int* __restrict__ counts,
+                                    float band_u /* E = band_u (A + s): 16 u for the FMA pass, 24 u for the matrix-core pass */) {
     int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= h_pad) return;
     counts[h] = 0;                       // the scoring kernel adds its point-splits' counts here (one memset launch less per batch)
@@ -134,7 +135,7 @@ __global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __
         float A = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) A = fmaxf(A, (fabsf(o[c]) + fabsf(o[3 + c]) + fabsf(o[6 + c])) * P + fabsf(o[9 + c]));
-        const float E = (9.5367431640625e-07f * A + 9.5367431640625e-07f * sqrt_tau) * 1.0001f;
+        const float E = (band_u * A + band_u * sqrt_tau) * 1.0001f;
         if (E < 0.25f * sqrt_tau) {
             const float lo = sqrt_tau - E, hi = sqrt_tau + E;
             const float tlo = lo * lo * (1.0f - 1e-6f), thi = hi * hi * (1.0f + 1e-6f);
@@ -281,6 +282,172 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
     if (threadIdx.x == 0 && s_rescored) atomicAdd(rescored, (unsigned long long)s_rescored);
 }
 
+// ------------------------------------------------------------------ scoring on the matrix cores (A/B variant, not the default)
+// R p + t is a [3H x 4] x [4 x N] product, so the transform can run on the matrix cores (v_mfma_f32_32x32x2_f32, twice for
+// K = 4 with a row of ones under the points for t) and leave the vector ALUs the subtraction of q, the squared norm and the
+// classification: 27 vector instructions per 32 points x 10 hypotheses (320 tests) instead of 73 per 8 points x 64
+// hypotheses (512 tests).  Built, parity-green (tests/test_gpu_ransac.py runs every scoring test in this mode too) and
+// MEASURED SLOWER than k_ransac_score_fast: 5.4 ms against 4.0 ms per 65,536 hypotheses x 200k points on the same box
+// (profiles/r2/history/ransac_score_matrix_cores.md).  The probes recorded there show why: the f32 matrix instruction and
+// the vector instructions of a SIMD do not overlap — the kernel's time is the SUM of its matrix time (3.1 ms alone) and its
+// vector time, from one wave or from four per SIMD — and the K = 4 product spends a quarter of its multiply-adds on the
+// constant row and a sixteenth on the unused accumulator row, so per test the matrix pipe is slower than nine packed FMAs.
+// Kept behind TDV_RANSAC_SCORE_MATRIX / TDV_RANSAC_SCORE=mfma as the record of that experiment.
+//
+// Counts stay the reference's: the classification is the band scheme of k_ransac_score_fast (sign of d2 - mid outside the
+// rounding band, the reference arithmetic inside it), with the band widened from 16 u to 24 u (A + s) for the accumulation
+// of the matrix core — taken as at most one rounding per product and per addition of the K = 4 chain, i.e. within gamma_8 of
+// the real value where the FMA chain is within gamma_3: 5 u A more per component, 8.7 u A in distance; an assumption about
+// the hardware's arithmetic that only the count-for-count tests against the exact kernel back — and taken as the union over
+// the wave's 10 hypotheses.
+//
+// Accumulator layout (32 x 32 tile, 16 registers per lane): lane l holds column l % 32 (a point), rows
+// 8 (v / 4) + 4 (l / 32) + v % 4 for v = 0..15.  Rows are assigned so that the x, y, z of one (hypothesis, point) meet in
+// one lane and two hypotheses share aligned register pairs (packed f32 operations): each half of the wave owns 5
+// hypotheses a..e: v0..5 = ax bx ay by az bz, v6..11 = cx dx cy dy cz dz, v12..14 = ex ey ez, v15 unused.
+typedef float v16f __attribute__((ext_vector_type(16)));
+#ifndef RM_WAVES_VALUE
+#define RM_WAVES_VALUE 8
+#endif
+constexpr int RM_WAVES = RM_WAVES_VALUE;          // hypothesis groups per workgroup, walking the same points
+constexpr int RM_HPW = 10;           // hypotheses per wave
+constexpr int RM_REC_FLOATS = 1280;  // per record of 4 tiles (128 points): [b0 | b1 | qx | qy | qz][lane][tile] — one 16-B load per lane and array
+constexpr unsigned long long RM_E_OF_V = 0xF444323232101010ull, RM_C_OF_V = 0x0210221100221100ull;   // nibble v: hypothesis a..e, component
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// B operands as the lanes read them: lane l of tile j holds b0 = (l < 32 ? px : py), b1 = (l < 32 ? pz : 1) of point l % 32, and q of that point
+__global__ void k_pack_pq3(const float* __restrict__ pq, int ns_pad, int n_rec, float* __restrict__ pq3) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // (point, half)
+    if (idx >= n_rec * 256) return;
+    const int i = idx >> 1, hf = idx & 1;
+    float px = 0.f, py = 0.f, pz = 0.f, qx = INFINITY, qy = INFINITY, qz = INFINITY;   // padding: never an inlier
+    if (i < ns_pad) { const float* a = pq + (size_t)i * 8; px = a[0]; py = a[1]; pz = a[2]; qx = a[3]; qy = a[4]; qz = a[5]; }
+    float* o = pq3 + (size_t)(i >> 7) * RM_REC_FLOATS + (hf * 32 + (i & 31)) * 4 + ((i >> 5) & 3);
+    o[0] = hf ? py : px; o[256] = hf ? 1.f : pz; o[512] = qx; o[768] = qy; o[1024] = qz;
+}
+
+__global__ __launch_bounds__(64 * RM_WAVES)
+void k_ransac_score_mfma(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq3, int n_rec, int rec_per_split,
+                         float tau, int* __restrict__ counts, unsigned long long* __restrict__ rescored) {
+    __shared__ float s_hyp[RM_WAVES][RM_HPW][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hf = lane >> 5, col = lane & 31;
+    const int hb = (blockIdx.x * RM_WAVES + wave) * RM_HPW;
+    const int g0 = blockIdx.y * rec_per_split, g1 = min(n_rec, g0 + rec_per_split);
+    // A operand: lane l supplies row l % 32, k = l / 32 (first instruction: k = 0, 1; second: k = 2, 3 with t as column 3)
+    float a0 = 0.f, a1 = 0.f;
+    {
+        const int v = 4 * (col >> 3) + (col & 3), hfrow = (col >> 2) & 1;
+        const int e = (int)((RM_E_OF_V >> (4 * v)) & 15), c = (int)((RM_C_OF_V >> (4 * v)) & 15);
+        const int h = hb + hfrow * 5 + e;
+        if (e < 5 && h < h_pad) { a0 = hyp[(size_t)(c + 3 * hf) * h_pad + h]; a1 = hyp[(size_t)(c + 3 * (hf + 2)) * h_pad + h]; }
+    }
+    for (int idx = lane; idx < RM_HPW * 12; idx += 64) {
+        const int h = idx / 12, e = idx - 12 * h;
+        s_hyp[wave][h][e] = (hb + h < h_pad) ? hyp[(size_t)e * h_pad + hb + h] : __builtin_nanf("");
+    }
+    __syncthreads();
+    // one band for the wave: the union of its hypotheses' bands (a skipped iteration has none; an unbounded one makes every tile exact)
+    float lo = INFINITY, hi = -INFINITY; bool unbounded = false;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        const int h = hb + hf * 5 + e;
+        if (h < h_pad) {
+            const float mid_h = hyp[(size_t)12 * h_pad + h], half_h = hyp[(size_t)13 * h_pad + h];
+            if (half_h != 0.f) { lo = fminf(lo, mid_h - half_h); hi = fmaxf(hi, mid_h + half_h); unbounded |= half_h != half_h; }
+        }
+    }
+    lo = fminf(lo, __shfl_xor(lo, 32, 64)); hi = fmaxf(hi, __shfl_xor(hi, 32, 64));
+    unbounded = __any(unbounded);
+    float mid = tau, half = 0.f;
+    if (lo <= hi) { mid = 0.5f * (lo + hi); half = 0.5f * (hi - lo) * (1.0f + 1e-5f) + mid * 1e-6f; }
+    if (unbounded) half = __builtin_nanf("");
+    const v2f nmid2 = {-mid, -mid};
+    const float (*rt)[12] = &s_hyp[wave][hf * 5];
+
+    int cnt[5] = {0, 0, 0, 0, 0};
+    unsigned sgn[5] = {0u, 0u, 0u, 0u, 0u};     // signs of d2 - mid, one bit per tile (1 = below mid = inlier), harvested every 32 tiles
+    unsigned n_rescored = 0;
+    const v16f zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // subtract q, square, classify: 25 vector instructions for the lane's 5 hypotheses x 1 point
+    auto classify = [&](const v16f& d, float b0, float b1, float qx, float qy, float qz) {
+        const v2f q2x = {qx, qx}, q2y = {qy, qy}, q2z = {qz, qz};
+        const v2f dxab = (v2f){d[0], d[1]} - q2x, dyab = (v2f){d[2], d[3]} - q2y, dzab = (v2f){d[4], d[5]} - q2z;
+        const v2f dxcd = (v2f){d[6], d[7]} - q2x, dycd = (v2f){d[8], d[9]} - q2y, dzcd = (v2f){d[10], d[11]} - q2z;
+        const v2f dxye = (v2f){d[12], d[13]} - (v2f){qx, qy};
+        const float dze = d[14] - qz;
+        const v2f tab = fma2(dxab, dxab, fma2(dyab, dyab, fma2(dzab, dzab, nmid2)));
+        const v2f tcd = fma2(dxcd, dxcd, fma2(dycd, dycd, fma2(dzcd, dzcd, nmid2)));
+        const float tee = __builtin_fmaf(dxye.x, dxye.x, __builtin_fmaf(dxye.y, dxye.y, __builtin_fmaf(dze, dze, -mid)));
+        float m = fminf(fminf(fabsf(tab.x), fabsf(tab.y)), fabsf(tee));
+        m = fminf(fminf(m, fabsf(tcd.x)), fabsf(tcd.y));
+        sgn[0] = __builtin_amdgcn_alignbit(sgn[0], __float_as_uint(tab.x), 31);
+        sgn[1] = __builtin_amdgcn_alignbit(sgn[1], __float_as_uint(tab.y), 31);
+        sgn[2] = __builtin_amdgcn_alignbit(sgn[2], __float_as_uint(tcd.x), 31);
+        sgn[3] = __builtin_amdgcn_alignbit(sgn[3], __float_as_uint(tcd.y), 31);
+        sgn[4] = __builtin_amdgcn_alignbit(sgn[4], __float_as_uint(tee), 31);
+        if (__any(!(m >= half))) {     // a test of this tile lies inside the band: the reference arithmetic decides the tile
+            ++n_rescored;
+            const float px = __shfl(b0, col, 64), py = __shfl(b0, col + 32, 64), pz = __shfl(b1, col, 64);
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                const float* r = rt[e];
+                const float x = (r[0] * px + (r[3] * py + r[6] * pz)) + r[9];
+                const float y = (r[1] * px + (r[4] * py + r[7] * pz)) + r[10];
+                const float z = (r[2] * px + (r[5] * py + r[8] * pz)) + r[11];
+                const float dx = x - qx, dy = y - qy, dz = z - qz;
+                const float d2 = dx * dx + (dy * dy + dz * dz);
+                sgn[e] = (sgn[e] & ~1u) | ((d2 < tau) ? 1u : 0u);
+            }
+        }
+    };
+    auto transform = [&](float b0, float b1) {
+        v16f d = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, zero16, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, d, 0, 0, 0);
+    };
+    auto load5 = [&](int g, v4f (&r)[5]) {
+        const v4f* __restrict__ rec = reinterpret_cast<const v4f*>(pq3 + (size_t)g * RM_REC_FLOATS) + lane;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) r[a] = rec[a * 64];
+    };
+    if (g0 < g1) {
+        v4f cur[5], nxt[5];
+        load5(g0, cur);
+        int since = 0;
+        for (int g = g0; g < g1; ++g) {
+            load5(min(g + 1, g1 - 1), nxt);       // the next record's operands are in flight while this one is scored
+            // the matrix pipe works on tile j + 1 while the vector pipe classifies tile j
+            v16f dA = transform(cur[0][0], cur[1][0]);
+            v16f dB = transform(cur[0][1], cur[1][1]);
+            classify(dA, cur[0][0], cur[1][0], cur[2][0], cur[3][0], cur[4][0]);
+            dA = transform(cur[0][2], cur[1][2]);
+            classify(dB, cur[0][1], cur[1][1], cur[2][1], cur[3][1], cur[4][1]);
+            dB = transform(cur[0][3], cur[1][3]);
+            classify(dA, cur[0][2], cur[1][2], cur[2][2], cur[3][2], cur[4][2]);
+            classify(dB, cur[0][3], cur[1][3], cur[2][3], cur[3][3], cur[4][3]);
+            if (++since == 8) {
+                since = 0;
+#pragma unroll
+                for (int e = 0; e < 5; ++e) { cnt[e] += __popc(sgn[e]); sgn[e] = 0u; }
+            }
+#pragma unroll
+            for (int a = 0; a < 5; ++a) cur[a] = nxt[a];
+        }
+#pragma unroll
+        for (int e = 0; e < 5; ++e) cnt[e] += __popc(sgn[e]);
+    }
+    // a hypothesis' count: the sum over the 32 lanes (points) of its half
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        int c = cnt[e];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (col == 0 && hb + hf * 5 + e < h_pad) atomicAdd(&counts[hb + hf * 5 + e], c);
+    }
+    if (n_rescored && lane == 0) atomicAdd(rescored, (unsigned long long)n_rescored);
+}
+
 // error sum of one hypothesis (column-major R in T[0..8], t in T[9..11]) over all points
 __global__ __launch_bounds__(256)
 void k_ransac_rmse_partial(const float* __restrict__ pq, int ns, const float* __restrict__ hyp12, float tau,
@@ -358,10 +525,18 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     // sqrt(tau) rounded up: the boundary of `d2 < tau` in distance, for the band of the fast scoring pass
     const float sqrt_tau = std::nextafter((float)std::sqrt((double)tau), INFINITY);
     static const bool score_exact_env = getenv("TDV_RANSAC_SCORE") && !strcmp(getenv("TDV_RANSAC_SCORE"), "exact");
-    const bool score_fast = !score_exact_env && !ctx->ransac_score_exact;
-    float* pq2 = nullptr;
-    TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 6, &pq2));
-    k_pack_pq2<<<(ns_pad / 2 + 255) / 256, 256, 0, s>>>(pq, ns_pad, pq2);
+    const bool score_fast = !score_exact_env && ctx->ransac_score_mode != TDV_RANSAC_SCORE_EXACT;
+    static const bool score_mfma_env = getenv("TDV_RANSAC_SCORE") && !strcmp(getenv("TDV_RANSAC_SCORE"), "mfma");
+    const bool score_mfma = score_fast && (score_mfma_env || ctx->ransac_score_mode == TDV_RANSAC_SCORE_MATRIX);
+    float* pq2 = nullptr; float* pq3 = nullptr;
+    const int n_rec = (ns + 127) / 128;
+    if (score_mfma) {
+        TDV_TRY(ws_alloc(ctx, (size_t)n_rec * RM_REC_FLOATS, &pq3));
+        k_pack_pq3<<<n_rec, 256, 0, s>>>(pq, ns_pad, n_rec, pq3);
+    } else {
+        TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 6, &pq2));
+        k_pack_pq2<<<(ns_pad / 2 + 255) / 256, 256, 0, s>>>(pq, ns_pad, pq2);
+    }
     TDV_CHECK_LAUNCH(ctx);
 
     // batch size: enough hypotheses to fill the chip, bounded for early exit granularity
@@ -415,11 +590,20 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     };
     auto enqueue = [&](int q, int cnt) -> int {     // device: hypotheses + scoring + counts back to the host
         TDV_HIP(ctx, hipMemcpyAsync(d_tri[q], h_tri[q], (size_t)cnt * 16, hipMemcpyHostToDevice, s));
-        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q], d_pmax, sqrt_tau, counts[q]);
+        k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q], d_pmax, sqrt_tau, counts[q],
+                                                                 (score_mfma ? 24.f : 16.f) * 5.9604644775390625e-08f);
         const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
         {
             ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
-            if (score_fast) {
+            if (score_mfma) {
+                const int groups = (cnt + RM_HPW - 1) / RM_HPW, gblocks = (groups + RM_WAVES - 1) / RM_WAVES;
+                int splits = std::max(1, std::min((16384 + groups - 1) / groups, std::max(1, n_rec / 16)));
+                const int rec_per_split = (n_rec + splits - 1) / splits;
+                splits = (n_rec + rec_per_split - 1) / rec_per_split;
+                k_ransac_score_mfma<<<dim3(gblocks, splits), 64 * RM_WAVES, 0, s>>>(hyp[q], h_pad, pq3, n_rec, rec_per_split, tau, counts[q], d_rescored);
+                wave_chunks += (double)gblocks * RM_WAVES * 4.0 * (double)n_rec;
+            }
+            else if (score_fast) {
                 k_ransac_score_fast<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q], d_rescored);
                 wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
             }

@@ -103,6 +103,14 @@ def _both_modes(ctx, *a, **k):
         e = ctx.ransac(*a, **k); assert ctx.last_ransac_rescore() == -1.0
         ctx.set_ransac_score("fast")
         f = ctx.ransac(*a, **k); share = ctx.last_ransac_rescore()
+        # and the matrix-core variant of the fast pass (csrc/ransac.hip, k_ransac_score_mfma: an A/B kernel, same band scheme)
+        ctx.set_ransac_score("matrix")
+        m = ctx.ransac(*a, **k); share_m = ctx.last_ransac_rescore()
+        assert 0.0 <= share_m <= 1.0
+        if e.trace_inliers is not None:
+            assert np.array_equal(m.trace_inliers, e.trace_inliers), np.nonzero(m.trace_inliers != e.trace_inliers)[0][:10]
+        assert (m.best_iteration, m.inliers, m.fitness, m.rmse) == (e.best_iteration, e.inliers, e.fitness, e.rmse)
+        assert m.transformation.tobytes() == e.transformation.tobytes()
     finally:
         ctx.set_ransac_score("fast")
     return e, f, share
