@@ -42,7 +42,7 @@ DEPTH_BATCH_MASK_PASSES = 1   # the B masks cross HBM once in tdv_depth_to_cloud
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [
-    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_last_icp_search", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_last_icp_search", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
@@ -109,6 +109,7 @@ def lib():
             l.tdv_version.restype = C.c_char_p
             l.tdv_ctx_get_stream.restype = C.c_void_p
             l.tdv_ctx_last_ransac_rescore.restype = C.c_double
+            l.tdv_ctx_last_ransac_scored.restype = C.c_double
             _lib = l
     return _lib
 
@@ -207,6 +208,11 @@ class Context:
     def last_ransac_rescore(self):
         """Fraction of (wave, 8-point chunk) pairs the last RANSAC call scored a second time exactly (-1 in 'exact' mode)."""
         return float(lib().tdv_ctx_last_ransac_rescore(self._h))
+
+    def last_ransac_scored(self):
+        """Share of the (hypothesis, point) tests the last RANSAC call evaluated (< 1: calls without a trace stop scoring a
+        hypothesis that can no longer beat the best count of the earlier batches; same result)."""
+        return float(lib().tdv_ctx_last_ransac_scored(self._h))
 
     def last_icp_search(self):
         """Name of the search the last ICP / correspondence call ran ('brute', 'pruned', 'grid'; 'auto' before any)."""

@@ -215,6 +215,8 @@ int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode) {
 
 double tdv_ctx_last_ransac_rescore(tdv_ctx* ctx) { return ctx ? ctx->last_ransac_rescore : -1.0; }
 
+double tdv_ctx_last_ransac_scored(tdv_ctx* ctx) { return ctx ? ctx->last_ransac_scored : 1.0; }
+
 int tdv_ctx_last_icp_search(tdv_ctx* ctx) { return ctx ? ctx->last_icp_search : 0; }
 
 int tdv_ctx_set_stream(tdv_ctx* ctx, void* s) {

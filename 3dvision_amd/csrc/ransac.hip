@@ -217,17 +217,39 @@ void k_ransac_score(const float* __restrict__ hyp, int h_pad, const float* __res
 // so of the chunks; counts are identical to k_ransac_score's (tests/test_gpu_ransac.py holds the two against each other
 // and against the oracle).
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+// Exact bail-out (RansacPlan, below): with plan != nullptr the kernel scores only a part of the points.  phase 1: every
+// hypothesis of the batch over the first plan[0] chunks; phase 2: the hypotheses listed in `list` (plan[1] of them: those
+// that can still beat the best count of the earlier batches) over the remaining chunks.
 __global__ __launch_bounds__(RS_BLOCK)
 void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq2,
-                         int n_pchunks, int pchunks_per_split, float tau, int* __restrict__ counts, unsigned long long* __restrict__ rescored) {
-    const int split = blockIdx.y;
-    const int c0 = split * pchunks_per_split;
-    const int c1 = min(n_pchunks, c0 + pchunks_per_split);
-    const int base = blockIdx.x * RS_BLOCK + threadIdx.x;
+                         int n_pchunks, int pchunks_per_split, float tau, int* __restrict__ counts, unsigned long long* __restrict__ rescored,
+                         const int* __restrict__ plan, const int* __restrict__ list, int phase) {
+    int split = blockIdx.y, hblock = blockIdx.x;
+    const int c_split = plan ? plan[0] : n_pchunks;
+    int n_list = 0;
+    if (phase == 2) {
+        // Few hypothesis blocks are left, and the points reach the scalar cache through the XCD's L2: a workgroup that walks a
+        // point range alone misses on every chunk (measured 1.2 ms for 5 % of the work).  Workgroups are therefore renumbered so
+        // that an XCD (workgroup id mod 8) runs ALL surviving hypothesis blocks of one point range next to each other, as the
+        // full grid does with its 8 hypothesis blocks per XCD and range.
+        n_list = plan[1];
+        const int n_blk = (n_list + RS_BLOCK - 1) / RS_BLOCK;
+        if (n_blk == 0) return;
+        const int id = blockIdx.x + gridDim.x * blockIdx.y, xcd = id & 7, j = id >> 3;
+        split = c_split / pchunks_per_split + (j / n_blk) * 8 + xcd;
+        hblock = j % n_blk;
+    }
+    int c0 = split * pchunks_per_split;
+    int c1 = min(n_pchunks, c0 + pchunks_per_split);
+    const int slot = hblock * RS_BLOCK + threadIdx.x;
+    int base = slot;
+    if (phase == 1) c1 = min(c1, c_split);
+    else if (phase == 2) { c0 = max(c0, c_split); base = slot < n_list ? list[slot] : -1; }
+    if (c0 >= c1) return;                                    // workgroup-uniform
     v2f r[12];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) { const float t = hyp[(size_t)e * h_pad + base]; r[e] = (v2f){t, t}; }
-    const float mid = hyp[(size_t)12 * h_pad + base], half = hyp[(size_t)13 * h_pad + base];
+    for (int e = 0; e < 12; ++e) { const float t = base >= 0 ? hyp[(size_t)e * h_pad + base] : __builtin_nanf(""); r[e] = (v2f){t, t}; }
+    const float mid = base >= 0 ? hyp[(size_t)12 * h_pad + base] : tau, half = base >= 0 ? hyp[(size_t)13 * h_pad + base] : 0.f;   // a lane without a hypothesis has no band
     const v2f nmid = {-mid, -mid};
     int cnt = 0;
     unsigned n_rescored = 0;     // wave-uniform
@@ -272,14 +294,54 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
         }
         cnt += cf;
     }
-    atomicAdd(&counts[base], cnt);
-    // statistics only (tdv_ctx_last_ransac_rescore): one atomic per workgroup
+    if (base >= 0) atomicAdd(&counts[base], cnt);
+    // statistics only (tdv_ctx_last_ransac_rescore / _scored): two atomics per workgroup — (wave, chunk) pairs scored, and scored twice
     __shared__ unsigned s_rescored;
     if (threadIdx.x == 0) s_rescored = 0u;
     __syncthreads();
     if (n_rescored && (threadIdx.x & 63) == 0) atomicAdd(&s_rescored, n_rescored);
     __syncthreads();
-    if (threadIdx.x == 0 && s_rescored) atomicAdd(rescored, (unsigned long long)s_rescored);
+    if (threadIdx.x == 0) {
+        if (s_rescored) atomicAdd(rescored, (unsigned long long)s_rescored);
+        atomicAdd(rescored + 1, (unsigned long long)(RS_BLOCK / 64) * (unsigned long long)(c1 - c0));
+    }
+}
+
+// RansacPlan — exact bail-out.  The loop of ransacRegistration (registration.cpp:284-290) uses an iteration's inlier count only
+// to ask whether it beats the best so far (strictly) — the early exit `fitness > confidence` can fire only on such a new best,
+// the loop having stopped otherwise when the earlier best passed it.  So a hypothesis whose count over the first chunks plus
+// ALL the remaining points cannot exceed the best count of the EARLIER batches needs no exact count: it is scored over the
+// prefix only, and whatever partial count the host reads for it compares as the true one would.  The best hypothesis itself
+// always survives, so the returned transform, inlier count, fitness, rmse and iteration are the reference's.  The running best
+// stays on the device (no host round trip between batches): plan = { chunks in phase 1, survivors, best count so far }.
+// Used only when the caller asked for no per-iteration trace.
+__global__ void k_ransac_plan(int* __restrict__ plan, int ns, int n_pchunks) {
+    const int best = plan[2];
+    int c_split = n_pchunks;
+    const int rest = best - max(best / 10, 1);               // points left to phase 2: a hypothesis with under a tenth of the best count in the prefix is dropped
+    if (rest >= ns / 8)                                      // (below an eighth of the points two launches cost more than they save)
+        c_split = min(n_pchunks, (ns - rest + RS_PCH - 1) / RS_PCH);
+    plan[0] = c_split; plan[1] = 0;
+}
+__global__ void k_ransac_select(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int ns, int* __restrict__ plan, int* __restrict__ list) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c_split = plan[0], best = plan[2];
+    const int rest = max(0, ns - min(ns, c_split * RS_PCH));     // (the padding past ns is never an inlier)
+    const bool keep = h < count && triples[h].w != 0 && rest > 0 && counts[h] + rest > best;
+    const unsigned long long m = __ballot(keep);
+    if (!m) return;
+    const int lane = threadIdx.x & 63;
+    int at = 0;
+    if (lane == 0) at = atomicAdd(&plan[1], __popcll(m));
+    at = __shfl(at, 0, 64);
+    if (keep) list[at + __popcll(m & ((1ull << lane) - 1ull))] = h;
+}
+__global__ void k_ransac_best(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int* __restrict__ plan) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = (h < count && triples[h].w != 0) ? counts[h] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, 64));
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(&plan[2], c);
 }
 
 // ------------------------------------------------------------------ scoring on the matrix cores (A/B variant, not the default)
@@ -513,7 +575,8 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     const int ns_pad = (int)align_up((size_t)ns, (size_t)RS_PCH * 64);
     float* pq = nullptr;
     TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 8, &pq));
-    // one device block: [0] bad index flag, [1] largest |source coordinate|, [2..3] rescored chunks (u64), [16..27] the winning
+    // one device block: [0] bad index flag, [1] largest |source coordinate|, [2..3] rescored chunks, [4..5] scored chunks (u64 each),
+    // [8..10] the bail-out plan (phase-1 chunks, survivors, best count so far), [16..27] the winning
     // hypothesis, [32..35] its error sum and inlier count (2 doubles): one memset at the start, one copy back at the end
     int* d_bad = nullptr;
     TDV_TRY(ws_alloc(ctx, 40, &d_bad));
@@ -528,6 +591,11 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     const bool score_fast = !score_exact_env && ctx->ransac_score_mode != TDV_RANSAC_SCORE_EXACT;
     static const bool score_mfma_env = getenv("TDV_RANSAC_SCORE") && !strcmp(getenv("TDV_RANSAC_SCORE"), "mfma");
     const bool score_mfma = score_fast && (score_mfma_env || ctx->ransac_score_mode == TDV_RANSAC_SCORE_MATRIX);
+    static const bool bailout_env_off = getenv("TDV_RANSAC_BAILOUT") && atoi(getenv("TDV_RANSAC_BAILOUT")) == 0;   // A/B knob
+    // RansacPlan; calls of a single batch have no earlier batch to take a best count from (C4's 10,000 iterations: a short first
+    // batch was tried for them and lost 2 % - their best fitness is 0.1-0.2, so at most a fifth of the points could be left out)
+    const bool bailout = score_fast && !score_mfma && !trace_inliers && !bailout_env_off && max_iterations > 65536;
+    int* d_plan = d_bad + 8;
     float* pq2 = nullptr; float* pq3 = nullptr;
     const int n_rec = (ns + 127) / 128;
     if (score_mfma) {
@@ -553,11 +621,13 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     // the GPU scores batch k; results are consumed in iteration order, so the outcome is that of the sequential loop
     float* hyp[2] = {nullptr, nullptr}; int* counts[2] = {nullptr, nullptr}; int4* d_tri[2] = {nullptr, nullptr};
     double* slabs = nullptr; double* d_out2 = nullptr; float* d_best12 = nullptr;
+    int* d_list = nullptr;
     for (int q = 0; q < 2; ++q) {
         TDV_TRY(ws_alloc(ctx, (size_t)14 * h_pad, &hyp[q]));
         TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &counts[q]));
         TDV_TRY(ws_alloc(ctx, (size_t)batch, &d_tri[q]));
     }
+    if (bailout) TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &d_list));   // one list: phase 2 of a batch has run before the next batch's selection (stream order)
     const int rblocks = (ns + 255) / 256;
     TDV_TRY(ws_alloc(ctx, (size_t)2 * rblocks, &slabs));
     d_best12 = reinterpret_cast<float*>(d_bad + 16);
@@ -578,8 +648,10 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     if (!ev[0] || !ev[1]) { event_release(ctx, ev[0]); event_release(ctx, ev[1]); return TDV_ERR_OOM; }
 
     TripleStream stream_idx(seed, (uint64_t)ns);   // sequential over the whole run (registration.cpp:235-239)
+    // with the bail-out a shorter first batch establishes a best count for the rest
+    const int first_batch = bailout ? 8 * RS_HYP_PER_BLOCK : batch;
     auto prepare = [&](int q, int it0) -> int {    // host: draw + pack the triples of one batch
-        const int cnt = std::min(batch, max_iterations - it0);
+        const int cnt = std::min(it0 == 0 ? first_batch : batch, max_iterations - it0);
         uint64_t d[3];
         for (int k = 0; k < cnt; ++k) {
             stream_idx.next(d);
@@ -604,7 +676,20 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                 wave_chunks += (double)gblocks * RM_WAVES * 4.0 * (double)n_rec;
             }
             else if (score_fast) {
-                k_ransac_score_fast<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q], d_rescored);
+                // point splits for THIS launch's hypothesis blocks (counts are accumulated by atomics, so they may differ per launch)
+                int ps = std::max(1, std::min(std::min((RS_WG_TARGET + hb - 1) / hb, std::max(1, n_pchunks / 32)), 512));
+                const int per = (n_pchunks + ps - 1) / ps;
+                ps = (n_pchunks + per - 1) / per;
+                if (bailout) {
+                    k_ransac_plan<<<1, 1, 0, s>>>(d_plan, ns, n_pchunks);
+                    k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, nullptr, 1);
+                    k_ransac_select<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], ns, d_plan, d_list);
+                    // (phase 2 renumbers its workgroups per XCD: 8 point ranges x the surviving hypothesis blocks at a time, so its grid is padded to whole groups of 8 ranges)
+                    k_ransac_score_fast<<<dim3(hb, (ps + 7) / 8 * 8), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, d_list, 2);
+                    k_ransac_best<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], d_plan);
+                } else {
+                    k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, nullptr, nullptr, 0);
+                }
                 wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
             }
             else k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q]);
@@ -649,7 +734,14 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         cur = nxt; it0 = it_next; cnt_cur = cnt_next;
     }
     (void)hipStreamSynchronize(s);   // a speculative batch may still be in flight after an early exit
-    ctx->last_ransac_rescore = -1.0;
+    ctx->last_ransac_rescore = -1.0; ctx->last_ransac_scored = 1.0;
+    // statistics of the fast pass: (wave, chunk) pairs scored twice / scored (the FMA kernel counts the latter itself: the
+    // bail-out leaves chunks out), and the scored share of all pairs
+    auto stats = [&](const unsigned long long* r) {
+        const double scored = r[1] ? (double)r[1] : wave_chunks;
+        ctx->last_ransac_rescore = (double)r[0] / scored;
+        ctx->last_ransac_scored = scored / wave_chunks;
+    };
     for (int q = 0; q < 2; ++q) event_release(ctx, ev[q]);
     if (status != TDV_OK) return status;
     out->iterations_run = done_iters;
@@ -666,7 +758,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipMemcpyAsync(ctx->pin + pin_b12, d_bad, 160, hipMemcpyDeviceToHost, s));
         TDV_HIP(ctx, hipStreamSynchronize(s));
-        if (want_stats) ctx->last_ransac_rescore = (double)*h_res / wave_chunks;
+        if (want_stats) stats(h_res);
         for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) out->T[c * 4 + r] = h_b12[c * 3 + r];
         out->T[12] = h_b12[9]; out->T[13] = h_b12[10]; out->T[14] = h_b12[11];
         out->fitness = best_fitness;
@@ -679,7 +771,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
             return TDV_ERR_INTERNAL;
         }
     } else if (want_stats) {
-        ctx->last_ransac_rescore = (double)*h_res / wave_chunks;
+        stats(h_res);
     }
     return TDV_OK;
 }

@@ -175,6 +175,7 @@ def main():
     ctx.timing_enable(False)
     icp_search_used = ctx.last_icp_search()   # before the supplementary scan below changes it
     rescore_share = ctx.last_ransac_rescore()  # fast scoring pass: share of (wave, chunk) pairs scored a second time exactly; -1: exact mode
+    scored_share = ctx.last_ransac_scored()    # share of the (hypothesis, point) tests evaluated at all (exact bail-out: DESIGN.md 4)
 
     times = torch.tensor([elapsed, t_icp, t_rs], dtype=torch.float64, device=dev)
     if distributed:
@@ -223,7 +224,7 @@ def main():
         sc_hyps_per_launch = hyps_total / max(sc_launches, 1)
         fast = rescore_share >= 0.0
         ops_per_test = (16.6 + 28.0 * rescore_share) if fast else 28.0
-        sc_tops = ops_per_test * n * hyps_total / max(sc_ms * 1e-3, 1e-12) / 1e12
+        sc_tops = ops_per_test * scored_share * n * hyps_total / max(sc_ms * 1e-3, 1e-12) / 1e12
         sc_bytes = 24.0 * n + 52.0 * sc_hyps_per_launch
         sc_kernel = "k_ransac_score_fast" if fast else "k_ransac_score"
         score = {
@@ -240,6 +241,10 @@ def main():
         }
         if fast:
             score["rescore_share"] = rescore_share
+            score["scored_share"] = scored_share
+            score["note"] = ("%.3f of the hypothesis-point tests were evaluated: a hypothesis whose count over a prefix of the points plus all remaining points "
+                             "cannot exceed the best count of the earlier batches is not scored further (exact: same best hypothesis, count, "
+                             "fitness, rmse); `achieved` counts executed lane-ops only" % scored_share)
             score["reference_arithmetic_equivalent_tops"] = 28.0 * n * hyps_total / max(sc_ms * 1e-3, 1e-12) / 1e12
         # NN search of the timed region.  Algorithmic HBM bytes of one ICP iteration: 12*N_s + 24*N_t + 124
         icp_bytes = 12.0 * n + 24.0 * n + 124

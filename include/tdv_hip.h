@@ -77,6 +77,11 @@ int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode);
 /* Statistics of the last tdv_ransac* call on this ctx: the fraction of (wave, 8-point chunk) pairs the FAST pass scored a
  * second time with the reference arithmetic (-1 if the call ran in EXACT mode or none has run). */
 double tdv_ctx_last_ransac_rescore(tdv_ctx* ctx);
+/* The share of the (hypothesis, point) tests the last tdv_ransac* call on this ctx evaluated.  Below 1 when the call ran without
+ * a per-iteration trace: a hypothesis whose count over a prefix of the points plus ALL remaining points cannot exceed the best
+ * count of the earlier batches is not scored further — the loop of registration.cpp:284-290 only asks whether a count beats the
+ * best so far, so transform, inlier count, fitness, rmse and best iteration are unchanged (env TDV_RANSAC_BAILOUT=0 turns it off). */
+double tdv_ctx_last_ransac_scored(tdv_ctx* ctx);
 /* The search the last tdv_icp* / tdv_icp_correspondences call on this ctx ran (BRUTE, PRUNED or GRID; 0 before any). */
 int tdv_ctx_last_icp_search(tdv_ctx* ctx);
 const char* tdv_status_string(int status);

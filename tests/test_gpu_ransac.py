@@ -311,3 +311,44 @@ def test_ransac_rejects_correspondences_outside_the_target(ctx, tdv, synth):
         with pytest.raises(tdv.TdvError):
             ctx.ransac(src, tgt, corr=c, voxel=0.004, max_iterations=300)
     assert ctx.ransac(src, tgt, corr=corr, voxel=0.004, max_iterations=300).iterations_run == 300   # the ctx is still usable
+
+
+def _same_result(a, ref):
+    assert (a.best_iteration, a.iterations_run, a.inliers) == (ref["best_iter"], ref["iters_run"], int(ref["inliers"][ref["best_iter"]]) if ref["best_iter"] >= 0 else 0), \
+        (a.best_iteration, a.iterations_run, a.inliers, ref["best_iter"], ref["iters_run"])
+    assert a.fitness == ref["fitness"] and abs(float(a.rmse) - float(ref["rmse"])) <= 1e-7
+    assert a.transformation.tobytes() == ref["T"].tobytes()
+
+
+@pytest.mark.parametrize("ns,nt,iters,confidence,good", [
+    (3000, 2000, 70000, 2.0, 0.5),      # a shorter first batch + one long batch + a rest, no early exit
+    (3000, 2000, 70000, 0.35, 0.5),     # early exit
+    (2500, 1500, 140000, 2.0, 0.7),     # three long batches
+    (2500, 1500, 75000, 0.55, 0.7),     # early exit late (or never): the confidence sits near the best fitness
+    (4000, 3000, 66000, 2.0, 0.04),     # hardly any inliers: nothing can be dropped
+    (40, 30, 80000, 2.0, 1.0),          # a tiny cloud: counts tie all the time, the FIRST best has to win; many skipped iterations
+    (257, 200, 70000, 0.9, 1.0),
+])
+def test_ransac_bailout_returns_the_reference_result(ctx, orc, synth, ns, nt, iters, confidence, good):
+    """Without a per-iteration trace the scoring stops early for hypotheses that cannot beat the best count of the earlier
+    batches (RansacPlan, csrc/ransac.hip).  Result, iteration of the best, iterations run and rmse are the oracle's; the
+    traced run (no bail-out) of the same call agrees."""
+    src, tgt, corr, _ = _case(synth, ns, nt, seed=ns, good_frac=good)
+    voxel = 0.004 if ns > 300 else 0.01
+    ref = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence, trace=True)
+    traced = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence, trace=True)
+    assert ctx.last_ransac_scored() == 1.0
+    n = ref["iters_run"]
+    assert np.array_equal(traced.trace_inliers[:n], ref["inliers"][:n])
+    got = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence)
+    scored = ctx.last_ransac_scored()
+    _same_result(got, ref); _same_result(traced, ref)
+    print("ns %d, %d iterations, confidence %g: %.3f of the tests scored, best %d inliers at %d" % (ns, iters, confidence, scored, got.inliers, got.best_iteration))
+    assert 0.0 < scored <= 1.0
+    if ns >= 2500 and good >= 0.5 and confidence > 1.0: assert scored < 0.95      # the scheme does something where it can
+    if iters <= 65536: assert scored == 1.0
+    try:                                  # and the matrix-core variant, which has no bail-out, agrees as well
+        ctx.set_ransac_score("exact")
+        _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence), ref)
+    finally:
+        ctx.set_ransac_score("fast")
