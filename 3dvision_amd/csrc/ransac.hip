@@ -592,9 +592,9 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     static const bool score_mfma_env = getenv("TDV_RANSAC_SCORE") && !strcmp(getenv("TDV_RANSAC_SCORE"), "mfma");
     const bool score_mfma = score_fast && (score_mfma_env || ctx->ransac_score_mode == TDV_RANSAC_SCORE_MATRIX);
     static const bool bailout_env_off = getenv("TDV_RANSAC_BAILOUT") && atoi(getenv("TDV_RANSAC_BAILOUT")) == 0;   // A/B knob
-    // RansacPlan; calls of a single batch have no earlier batch to take a best count from (C4's 10,000 iterations: a short first
-    // batch was tried for them and lost 2 % - their best fitness is 0.1-0.2, so at most a fifth of the points could be left out)
-    const bool bailout = score_fast && !score_mfma && !trace_inliers && !bailout_env_off && max_iterations > 65536;
+    // RansacPlan; short calls run as one batch without it (C4's 10,000 iterations: a short first batch was tried for them and lost
+    // 2 % - their best fitness is 0.1-0.2, so at most a fifth of the points could be left out)
+    const bool bailout = score_fast && !score_mfma && !trace_inliers && !bailout_env_off && max_iterations > 16384;
     int* d_plan = d_bad + 8;
     float* pq2 = nullptr; float* pq3 = nullptr;
     const int n_rec = (ns + 127) / 128;

@@ -328,6 +328,8 @@ def _same_result(a, ref):
     (4000, 3000, 66000, 2.0, 0.04),     # hardly any inliers: nothing can be dropped
     (40, 30, 80000, 2.0, 1.0),          # a tiny cloud: counts tie all the time, the FIRST best has to win; many skipped iterations
     (257, 200, 70000, 0.9, 1.0),
+    (3000, 2000, 20000, 2.0, 0.6),      # a call of two batches below the full batch size (C3's 50,000 hypotheses are of this kind)
+    (3000, 2000, 9000, 2.0, 0.6),       # a short call: one batch, nothing left out
 ])
 def test_ransac_bailout_returns_the_reference_result(ctx, orc, synth, ns, nt, iters, confidence, good):
     """Without a per-iteration trace the scoring stops early for hypotheses that cannot beat the best count of the earlier
@@ -345,10 +347,34 @@ def test_ransac_bailout_returns_the_reference_result(ctx, orc, synth, ns, nt, it
     _same_result(got, ref); _same_result(traced, ref)
     print("ns %d, %d iterations, confidence %g: %.3f of the tests scored, best %d inliers at %d" % (ns, iters, confidence, scored, got.inliers, got.best_iteration))
     assert 0.0 < scored <= 1.0
-    if ns >= 2500 and good >= 0.5 and confidence > 1.0: assert scored < 0.95      # the scheme does something where it can
-    if iters <= 65536: assert scored == 1.0
+    if ns >= 2500 and good >= 0.5 and confidence > 1.0 and iters > 16384: assert scored < 0.95      # the scheme does something where it can
+    if iters <= 16384: assert scored == 1.0
     try:                                  # and the matrix-core variant, which has no bail-out, agrees as well
         ctx.set_ransac_score("exact")
         _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence), ref)
     finally:
         ctx.set_ransac_score("fast")
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ransac_bailout_fuzz(ctx, synth, seed):
+    """Random sizes, inlier shares, thresholds and stopping confidences: the run without a trace (bail-out) returns what the
+    exact kernel returns (which never leaves anything out) — best iteration, iterations run, counts, transform bits, rmse."""
+    rng = np.random.default_rng(100 + seed)
+    ns = int(rng.integers(50, 6000)); nt = int(rng.integers(30, 4000))
+    good = float(rng.choice([0.02, 0.2, 0.5, 0.9, 1.0]))
+    src, tgt, corr, _ = _case(synth, ns, nt, seed=200 + seed, good_frac=good)
+    voxel = float(rng.choice([0.002, 0.004, 0.02]))
+    iters = int(rng.choice([17000, 40000, 66000, 131072, 140000]))
+    confidence = float(rng.choice([2.0, 2.0, 0.9, 0.5, 0.2, 0.05]))
+    try:
+        ctx.set_ransac_score("exact")
+        e = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence)
+        assert ctx.last_ransac_scored() == 1.0
+    finally:
+        ctx.set_ransac_score("fast")
+    f = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence)
+    print("ns %d nt %d good %.2f voxel %g iters %d confidence %g: scored %.3f, best %d @ %d, run %d"
+          % (ns, nt, good, voxel, iters, confidence, ctx.last_ransac_scored(), f.inliers, f.best_iteration, f.iterations_run))
+    assert (f.best_iteration, f.iterations_run, f.inliers, f.fitness, f.rmse) == (e.best_iteration, e.iterations_run, e.inliers, e.fitness, e.rmse)
+    assert f.transformation.tobytes() == e.transformation.tobytes()
