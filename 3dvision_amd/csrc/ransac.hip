@@ -665,9 +665,9 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q], d_pmax, sqrt_tau, counts[q],
                                                                  (score_mfma ? 24.f : 16.f) * 5.9604644775390625e-08f);
         const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
-        {
-            ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
+        {   // TDV_TIMER_RANSAC_SCORE brackets every dispatch of a scoring kernel on its own (with the bail-out: two per batch)
             if (score_mfma) {
+                ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
                 const int groups = (cnt + RM_HPW - 1) / RM_HPW, gblocks = (groups + RM_WAVES - 1) / RM_WAVES;
                 int splits = std::max(1, std::min((16384 + groups - 1) / groups, std::max(1, n_rec / 16)));
                 const int rec_per_split = (n_rec + splits - 1) / splits;
@@ -682,17 +682,26 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                 ps = (n_pchunks + per - 1) / per;
                 if (bailout) {
                     k_ransac_plan<<<1, 1, 0, s>>>(d_plan, ns, n_pchunks);
-                    k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, nullptr, 1);
+                    {
+                        ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
+                        k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, nullptr, 1);
+                    }
                     k_ransac_select<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], ns, d_plan, d_list);
-                    // (phase 2 renumbers its workgroups per XCD: 8 point ranges x the surviving hypothesis blocks at a time, so its grid is padded to whole groups of 8 ranges)
-                    k_ransac_score_fast<<<dim3(hb, (ps + 7) / 8 * 8), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, d_list, 2);
+                    {   // (phase 2 renumbers its workgroups per XCD: 8 point ranges x the surviving hypothesis blocks at a time, so its grid is padded to whole groups of 8 ranges)
+                        ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
+                        k_ransac_score_fast<<<dim3(hb, (ps + 7) / 8 * 8), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, d_list, 2);
+                    }
                     k_ransac_best<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], d_plan);
                 } else {
+                    ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
                     k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, nullptr, nullptr, 0);
                 }
                 wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
             }
-            else k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q]);
+            else {
+                ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
+                k_ransac_score<<<dim3(hb, psplit), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, pchunks_per_split, tau, counts[q]);
+            }
         }
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipMemcpyAsync(h_cnt[q], counts[q], (size_t)cnt * 4, hipMemcpyDeviceToHost, s));

@@ -221,11 +221,17 @@ def main():
         # 48 fma, 12 add - and 13 scalar-f32 ones) + 28 for every (wave, chunk) pair scored again exactly
         # (rescore_share, counted by the kernel).  An FMA is ONE lane-op here, as in the peak (lane-instructions, not flops).
         # Algorithmic HBM bytes per launch: the packed pairs once (24 B per point) + 48 B per hypothesis in, 4 B out.
+        # A "launch" is one dispatch of the scoring kernel (what rocprofv3's kernel statistics average over).  With the exact
+        # bail-out a batch of hypotheses is two dispatches: every hypothesis over a prefix of the points, then the hypotheses that
+        # can still beat the best count of the earlier batches over the rest - together they read the pair array once.
+        # (batching rule of csrc/ransac.hip: batches of 65,536 hypotheses, the first one 8,192 when the bail-out is on)
+        bail = fast_mode_bailout = (os.environ.get("TDV_RANSAC_BAILOUT", "1") != "0") and hyps_total > 16384
+        sc_batches = (1 + -(-(int(hyps_total) - 8192) // 65536)) if bail else max(1, -(-int(hyps_total) // 65536))
         sc_hyps_per_launch = hyps_total / max(sc_launches, 1)
         fast = rescore_share >= 0.0
         ops_per_test = (16.6 + 28.0 * rescore_share) if fast else 28.0
         sc_tops = ops_per_test * scored_share * n * hyps_total / max(sc_ms * 1e-3, 1e-12) / 1e12
-        sc_bytes = 24.0 * n + 52.0 * sc_hyps_per_launch
+        sc_bytes = (24.0 * n * sc_batches + 56.0 * hyps_total) / max(sc_launches, 1)
         sc_kernel = "k_ransac_score_fast" if fast else "k_ransac_score"
         score = {
             "kernel": sc_kernel, "bound": "valu_f32",
@@ -234,7 +240,7 @@ def main():
                      "scored again with the reference arithmetic; same inlier counts as the 28-op reference arithmetic" % (ops_per_test, rescore_share))
                     if fast else "Tops/s (f32 VALU, FMA contraction forbidden by parity; 28 ops per hypothesis-point)",
             "frac": sc_tops / VALU_PEAK_TOPS, "avg_launch_ms": sc_avg_ms, "launches": sc_launches,
-            "hyps_per_launch": sc_hyps_per_launch, "total_ms": sc_ms,
+            "hyps_per_launch": sc_hyps_per_launch, "batches": sc_batches, "total_ms": sc_ms,
             "hbm": {"algorithmic_bytes_per_launch": sc_bytes, "achieved": sc_bytes / max(sc_avg_ms * 1e-3, 1e-12) / 1e9,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sc_bytes / max(sc_avg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBPS},
             "traffic": traffic(sc_kernel),
