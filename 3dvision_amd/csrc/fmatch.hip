@@ -531,12 +531,15 @@ void k_fm_dedupe_insert(const float* __restrict__ f, int n, int* table, unsigned
 }
 
 // first key: p0 of the rows that stay; the others sort behind every real row together with the padding
-__global__ void k_fm_rec_p0(const float* __restrict__ p0, int n, int n_pow2, const int* __restrict__ table, const int* __restrict__ slot_of,
-                            uint4* __restrict__ rec) {
+// Keys of the three sorts of the packing.  The first two are stable radix sorts of (key, row) pairs: rows enter in index order,
+// so equal keys keep the lower row first.
+__global__ void k_fm_key_p0(const float* __restrict__ p0, int n, const int* __restrict__ table, const int* __restrict__ slot_of,
+                            unsigned long long* __restrict__ key, unsigned* __restrict__ row) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pow2) return;
-    const bool keep = i < n && table[slot_of[i]] == i;
-    rec[i] = keep ? make_uint4(sortable_bits(p0[i]), (unsigned)i, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (i >= n) return;
+    const bool keep = table[slot_of[i]] == i;             // a bit-identical copy of an earlier row stays out of the index: it sorts last
+    key[i] = keep ? (unsigned long long)sortable_bits(p0[i]) : (1ull << 32);
+    row[i] = (unsigned)i;
 }
 // number of entries of the ascending array `starts` (m + 1 entries, starts[0] = 0) that are <= r, minus 1
 __device__ __forceinline__ int segment_of(const int* __restrict__ starts, int m, int r) {
@@ -544,22 +547,22 @@ __device__ __forceinline__ int segment_of(const int* __restrict__ starts, int m,
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (starts[mid] <= r) lo = mid; else hi = mid; }
     return lo;
 }
-// after the sort along p0: rank -> slab (equal counts); next key = (slab, p1, row); slab boundary values for locating
-__global__ void k_fm_rec_p1(uint4* __restrict__ rec, int n, const int* __restrict__ slab_start, int S0, const float* __restrict__ p0,
-                            const float* __restrict__ p1, float* __restrict__ b0) {
+// after the sort along p0: rank -> slab (equal counts); next key = (slab, p1); slab boundary values for locating
+__global__ void k_fm_key_p1(const unsigned* __restrict__ row_in, int n, const int* __restrict__ slab_start, int S0, const float* __restrict__ p0,
+                            const float* __restrict__ p1, float* __restrict__ b0, unsigned long long* __restrict__ key) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const unsigned idx = rec[r].y;
+    const unsigned idx = row_in[r];
     const int k = segment_of(slab_start, S0, r);
     if (r == slab_start[k]) b0[k] = p0[idx];
-    rec[r] = make_uint4((unsigned)k, sortable_bits(p1[idx]), idx, 0u);
+    key[r] = ((unsigned long long)(unsigned)k << 32) | sortable_bits(p1[idx]);
 }
-// after the sort along (slab, p1): rank -> column; next key = (column, p2, row)
-__global__ void k_fm_rec_p2(uint4* __restrict__ rec, int n, const int* __restrict__ col_start, int ncol, const float* __restrict__ p1,
-                            const float* __restrict__ p2, float* __restrict__ b1) {
+// after the sort along (slab, p1): rank -> column; last key = (column, p2, row), as 16-byte records for the per-column sort
+__global__ void k_fm_rec_p2(const unsigned* __restrict__ row_in, int n, const int* __restrict__ col_start, int ncol, const float* __restrict__ p1,
+                            const float* __restrict__ p2, float* __restrict__ b1, uint4* __restrict__ rec) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const unsigned idx = rec[r].z;
+    const unsigned idx = row_in[r];
     const int c = segment_of(col_start, ncol, r);
     if (r == col_start[c]) b1[c] = p1[idx];
     rec[r] = make_uint4((unsigned)c, sortable_bits(p2[idx]), idx, 0u);
@@ -1256,6 +1259,11 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &p1));
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &p2));
     TDV_TRY(ws_alloc(ctx, n_pow2, &rec));
+    unsigned long long *key_a, *key_b; unsigned *row_a, *row_b;
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &key_a));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &key_b));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &row_a));
+    TDV_TRY(ws_alloc(ctx, (size_t)nt, &row_b));
     float* prow;
     TDV_TRY(ws_alloc(ctx, rows * PD, &prow));
     char* stage = ctx->pin + 8192;   // the moments occupied the first bytes
@@ -1272,18 +1280,25 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     const unsigned gn = (unsigned)((nt + 255) / 256);
     TDV_HIP(ctx, hipMemsetAsync(ix->amax, 0, 4, s));
     k_fm_project<<<gn, 256, 0, s>>>(d_ft, nt, basis, p0, p1, p2, ix->amax);
-    k_fm_rec_p0<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(p0, nt, (int)n_pow2, table, slot_of, rec);
-    TDV_TRY(sort_records_dev(ctx, rec, n_pow2));
-    const size_t nk_pow2 = sort_pow2((size_t)nk);   // the distinct rows now lead; what follows them up to here is padding
-    k_fm_rec_p1<<<gn, 256, 0, s>>>(rec, nk, d_slab_start, S0, p0, p1, ix->b0);
-    TDV_TRY(sort_records_dev(ctx, rec, nk_pow2));
-    k_fm_rec_p2<<<gn, 256, 0, s>>>(rec, nk, d_col_start, ncol, p1, p2, ix->b1);
+    // slabs along p0, columns along p1: two stable radix sorts of (key, row) pairs (rocPRIM; two bitonic sorts of 16-byte records,
+    // ~30 launches and 0.19 ms each at 150k rows, until the end of round 2)
+    k_fm_key_p0<<<gn, 256, 0, s>>>(p0, nt, table, slot_of, key_a, row_a);
+    TDV_TRY(radix_sort_pairs_dev(ctx, key_a, key_b, row_a, row_b, (size_t)nt, 33));   // the distinct rows lead; the copies follow
+    k_fm_key_p1<<<gn, 256, 0, s>>>(row_b, nk, d_slab_start, S0, p0, p1, ix->b0, key_a);
+    int slab_bits = 1;
+    while ((1 << slab_bits) < S0) ++slab_bits;
+    TDV_TRY(radix_sort_pairs_dev(ctx, key_a, key_b, row_b, row_a, (size_t)nk, 32 + slab_bits));
+    k_fm_rec_p2<<<gn, 256, 0, s>>>(row_a, nk, d_col_start, ncol, p1, p2, ix->b1, rec);
     // the third key only orders the rows INSIDE their column: columns of up to 2,048 rows are sorted by one workgroup each,
-    // all in one launch, instead of a third full sort (~20 launches)
+    // all in one launch, instead of a third full sort
     int max_col = 0;
     for (int c = 0; c < ncol; ++c) max_col = std::max(max_col, col_start[c + 1] - col_start[c]);
     if (max_col <= segment_sort_max_len()) TDV_TRY(segment_sort_records_dev(ctx, rec, d_col_start, ncol));
-    else TDV_TRY(sort_records_dev(ctx, rec, nk_pow2));
+    else {
+        const size_t nk_pow2 = sort_pow2((size_t)nk);
+        if (nk_pow2 > (size_t)nk) TDV_HIP(ctx, hipMemsetAsync(rec + nk, 0xff, (nk_pow2 - (size_t)nk) * sizeof(uint4), s));   // padding sorts last
+        TDV_TRY(sort_records_dev(ctx, rec, nk_pow2));
+    }
     k_fm_fill_rows<<<(unsigned)((rows * FD + 255) / 256), 256, 0, s>>>(ix->T, ix->torig, rows);
     k_fm_place_rows<<<(unsigned)(((size_t)nk * FD + 255) / 256), 256, 0, s>>>(rec, nk, d_col_start, d_col_row0, ncol, d_ft, p0, p1, p2, ix->T, ix->torig, ix->leaf_p2, prow, rows);
     k_fm_leaf_boxes<<<(ngroup * FX_GROUP * (FD + PD) + 255) / 256, 256, 0, s>>>(ix->T, ix->torig, prow, rows, nleaf, ngroup, ix->lbox, ix->pbox);
