@@ -152,3 +152,53 @@ def test_ransac_hypothesis_and_score_against_numpy(orc, synth):
         assert abs(int((err < voxel * 1.5).sum()) - int(r["inliers"][it])) <= near, it
         checked += 1
     assert checked > 250
+
+
+def test_fpfh_against_float64_numpy(orc, synth):
+    """computeFPFH (registration.cpp:133-201) written a second time — vectorised numpy in float64 over scipy's radius
+    neighbourhoods — against the oracle's float32 loops.  A pair whose angle feature falls within rounding distance of a bin
+    edge may land in the neighbouring bin (float32 vs float64), so the comparison is on the descriptors' L1 distance."""
+    pts, _ = synth.sample_object(1500, 9)
+    nrm = orc.estimate_normals(pts, 30)
+    radius = 5.0 * float(synth.mean_spacing(1500))
+    got = orc.compute_fpfh(pts, nrm, radius).astype(np.float64)
+    P = pts.astype(np.float64); N = nrm.astype(np.float64)
+    tree = cKDTree(P)
+    nb = []
+    for i, lst in enumerate(tree.query_ball_point(P, radius * (1 + 1e-9))):   # findRadiusNN: the 100 nearest in (d2, index) order
+        lst = np.array(sorted(lst), int)
+        d2 = ((P[lst] - P[i]) ** 2).sum(1)
+        nb.append(list(lst[np.lexsort((lst, d2))][:100]))
+    spfh = np.zeros((len(P), 33))
+    for i, lst in enumerate(nb):
+        j = np.array([q for q in lst if q != i], int)
+        if len(j) == 0: continue
+        d = P[j] - P[i]; dist = np.linalg.norm(d, axis=1); keep = dist >= 1e-8
+        j, d, dist = j[keep], d[keep] / dist[keep, None], dist[keep]
+        u = N[i]; v = np.cross(u, d); w = np.cross(u, v)
+        alpha = (v * N[j]).sum(1); phi = d @ u; theta = np.arctan2((w * N[j]).sum(1), N[j] @ u)
+        for off, val in ((0, alpha + 1.0), (11, phi + 1.0), (22, theta / np.pi + 1.0)):
+            np.add.at(spfh[i], off + np.clip((val * 5.5).astype(int), 0, 10), 1.0)
+        spfh[i] /= spfh[i].sum()
+    ref = np.zeros_like(spfh)
+    for i, lst in enumerate(nb):
+        j = np.array([q for q in lst if q != i], int)
+        f = spfh[i].copy()
+        if len(j):
+            dist = np.linalg.norm(P[j] - P[i], axis=1); keep = dist >= 1e-8
+            f += (spfh[j[keep]] / dist[keep, None]).sum(0)
+        ref[i] = f / f.sum() if f.sum() > 0 else f
+    l1 = np.abs(got - ref).sum(1)
+    assert np.median(l1) < 1e-5 and (l1 < 2e-2).all() and (l1 < 1e-3).mean() > 0.9, (np.median(l1), l1.max(), (l1 < 1e-3).mean())
+
+
+def test_descriptor_match_against_scipy_kdtree(orc, synth):
+    """ransacRegistration's correspondence step (registration.cpp:216-232: nearest target descriptor by the 33-term float sum,
+    lowest index on ties) against scipy's k-d tree in float64: the same match wherever the two nearest distances differ clearly."""
+    fs = synth.random_features(1200, 5); ft = synth.random_features(900, 6)
+    got = orc.feature_match(fs, ft)
+    d, idx = cKDTree(ft.astype(np.float64)).query(fs.astype(np.float64), 2)
+    clear = (d[:, 1] - d[:, 0]) > 1e-6 * np.maximum(d[:, 1], 1e-12)
+    assert clear.mean() > 0.95 and np.array_equal(got[clear], idx[clear, 0])
+    dd = np.linalg.norm(fs.astype(np.float64) - ft[got].astype(np.float64), axis=1)      # and never worse than the best by more than rounding
+    assert (dd <= d[:, 0] * (1 + 1e-5) + 1e-9).all()
