@@ -315,10 +315,10 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
 // always survives, so the returned transform, inlier count, fitness, rmse and iteration are the reference's.  The running best
 // stays on the device (no host round trip between batches): plan = { chunks in phase 1, survivors, best count so far }.
 // Used only when the caller asked for no per-iteration trace.
-__global__ void k_ransac_plan(int* __restrict__ plan, int ns, int n_pchunks) {
+__global__ void k_ransac_plan(int* __restrict__ plan, int ns, int n_pchunks, int drop_permille) {
     const int best = plan[2];
     int c_split = n_pchunks;
-    const int rest = best - max(best / 10, 1);               // points left to phase 2: a hypothesis with under a tenth of the best count in the prefix is dropped
+    const int rest = best - max((int)((long long)best * drop_permille / 1000), 1);   // points left to phase 2: a hypothesis with under that share of the best count in the prefix is dropped
     if (rest >= ns / 8)                                      // (below an eighth of the points two launches cost more than they save)
         c_split = min(n_pchunks, (ns - rest + RS_PCH - 1) / RS_PCH);
     plan[0] = c_split; plan[1] = 0;
@@ -596,6 +596,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     // 2 % - their best fitness is 0.1-0.2, so at most a fifth of the points could be left out)
     const bool bailout = score_fast && !score_mfma && !trace_inliers && !bailout_env_off && max_iterations > 16384;
     int* d_plan = d_bad + 8;
+    static const int drop_permille = getenv("TDV_RANSAC_DROP_PERMILLE") ? atoi(getenv("TDV_RANSAC_DROP_PERMILLE")) : 100;   // tuning knob
     float* pq2 = nullptr; float* pq3 = nullptr;
     const int n_rec = (ns + 127) / 128;
     if (score_mfma) {
@@ -681,7 +682,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                 const int per = (n_pchunks + ps - 1) / ps;
                 ps = (n_pchunks + per - 1) / per;
                 if (bailout) {
-                    k_ransac_plan<<<1, 1, 0, s>>>(d_plan, ns, n_pchunks);
+                    k_ransac_plan<<<1, 1, 0, s>>>(d_plan, ns, n_pchunks, drop_permille);
                     {
                         ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
                         k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, nullptr, 1);
