@@ -566,15 +566,17 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
     const int vv = threadIdx.x & 31, g = threadIdx.x >> 5;
     {
         // slabs were written by other blocks of this launch: the agent-scope fence above makes them visible to plain loads
+        // sixteen slab rows per thread and round, all loads of a round in flight together (the fold is a chain of round trips:
+        // 196 blocks at 200k points were 7 rounds of 4 loads, now 2 rounds of 16); fixed order, as before
         const double* sl = slabs;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int b2 = g;
-        for (; b2 + 24 < nblocks; b2 += 32) {
-            const double a0 = sl[(size_t)b2 * ACC_NV + vv], a1 = sl[(size_t)(b2 + 8) * ACC_NV + vv];
-            const double a2 = sl[(size_t)(b2 + 16) * ACC_NV + vv], a3 = sl[(size_t)(b2 + 24) * ACC_NV + vv];
-            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        for (int b2 = g; b2 < nblocks; b2 += 128) {
+            double a[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a[j] = b2 + 8 * j < nblocks ? sl[(size_t)(b2 + 8 * j) * ACC_NV + vv] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; j += 4) { s0 += a[j]; s1 += a[j + 1]; s2 += a[j + 2]; s3 += a[j + 3]; }
         }
-        for (; b2 < nblocks; b2 += 8) s0 += sl[(size_t)b2 * ACC_NV + vv];
         red[g][vv] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
