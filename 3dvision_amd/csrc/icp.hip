@@ -556,12 +556,15 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
         slabs[(size_t)blockIdx.x * ACC_NV + threadIdx.x] = s;
     }
     // ---- last block: fold, solve, update -----------------------------------------------------------------------
-    __threadfence();
+    // Release by the wave that wrote the slab (wave 0; thread 0 then moves the ticket), acquire by the block that folds.
+    // __threadfence() by every thread was a write-back AND an invalidate of the XCD's L2 (buffer_wbl2 + buffer_inv) from all
+    // four waves of all 196 blocks - invalidating the target lines the blocks still running were gathering.
+    if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const int nblocks = gridDim.x;
     const int vv = threadIdx.x & 31, g = threadIdx.x >> 5;
     {

@@ -309,13 +309,13 @@ void k_scan_reduce(const int* __restrict__ in, int n, int* __restrict__ sums, in
         int s = 0;
         for (int k = 0; k < 16; ++k) s += w[k];
         sums[blockIdx.x] = s;
-        __threadfence();                                        // the sum is visible device-wide before the ticket moves
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the sum is visible device-wide before the ticket moves (release only: __threadfence() would also invalidate the XCD's L2 under the workgroups still loading)
         is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
         carry_s = 0;
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();                                            // acquire: the other workgroups' sums
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // acquire: the other workgroups' sums
     const int nblocks = gridDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     volatile int* vs = sums;                                    // written by other workgroups of this launch
