@@ -409,10 +409,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // The update of one iteration from the folded sums tot[] (thread 0 of the folding block): registration.cpp:361-411.
+// (iter, prev_rmse, Tcur: the state as the kernel read it at its start - no other launch writes it in between - so that the
+// tail of the iteration does not begin with another round trip to memory)
 template <int MODE>
-__device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_iterations) {
+__device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_iterations, int iter, float prev_rmse, const float* Tcur) {
     const int n_corr = (int)(tot[0] + 0.5);
-    const int iter = st->iter;
     st->iter = iter + 1;
     st->n_corr = n_corr;
     if (n_corr < 3) {  // registration.cpp:361 — break, keeping the previous result
@@ -448,9 +449,8 @@ __device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_it
         delta[12] = tmf[0] - rx; delta[13] = tmf[1] - ry; delta[14] = tmf[2] - rz;
     }
     float Tn[16];
-    dl::mul44(delta, st->T, Tn);
+    dl::mul44(delta, Tcur, Tn);
     for (int i = 0; i < 16; ++i) { st->T[i] = Tn[i]; st->res_T[i] = Tn[i]; }
-    const float prev_rmse = st->rmse;
     const float rmse = sqrtf((float)tot[1] / (float)n_corr);
     st->rmse = rmse;
     st->fitness = (float)n_corr / (float)ns;
@@ -475,6 +475,7 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
                       double* slabs, unsigned* ticket,
                       int* __restrict__ out_corr, float* __restrict__ out_d2, uint8_t* __restrict__ out_acc) {
     if (st->done) return;
+    const int iter0 = st->iter; const float rmse0 = st->rmse;
     double v[ACC_NV];
 #pragma unroll
     for (int k = 0; k < ACC_NV; ++k) v[k] = 0.0;
@@ -483,6 +484,7 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int r = 0; r < 3; ++r) T[c * 3 + r] = st->T[c * 4 + r];
+    const float Tb[4] = {st->T[3], st->T[7], st->T[11], st->T[15]};     // bottom row (0 0 0 1 unless the caller's start pose says otherwise)
 #pragma unroll 1
     for (int q = 0; q < ACC_PPT; ++q) {
         const int i = blockIdx.x * (256 * ACC_PPT) + q * 256 + threadIdx.x;
@@ -589,7 +591,12 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
     if (threadIdx.x != 0) return;
     *ticket = 0u;   // ready for the next launch (stream order)
     if (MODE == 2) st->n_corr = (int)(tot[0] + 0.5);
-    else icp_update<MODE>(tot, ns, st, fixed_iterations);
+    else {
+        float T16[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { T16[c * 4] = T[c * 3]; T16[c * 4 + 1] = T[c * 3 + 1]; T16[c * 4 + 2] = T[c * 3 + 2]; T16[c * 4 + 3] = Tb[c]; }
+        icp_update<MODE>(tot, ns, st, fixed_iterations, iter0, rmse0, T16);
+    }
 }
 
 namespace {
