@@ -363,13 +363,16 @@ class Context:
         return RegistrationResult(transformation=from_colmajor16(res.T), fitness=np.float32(res.fitness), rmse=np.float32(res.rmse),
                                   iterations=res.iterations, n_corr=res.n_corr)
 
-    def ransac_dev(self, d_src, ns, d_tgt, nt, d_fs, d_ft, d_corr, voxel, max_iterations, confidence=0.999, seed=42):
+    def ransac_dev(self, d_src, ns, d_tgt, nt, d_fs, d_ft, d_corr, voxel, max_iterations, confidence=0.999, seed=42, trace=False):
+        """trace=True also returns the per-iteration inlier counts (host array) - and thereby makes the call evaluate every
+        (hypothesis, point) test: the exact bail-out only runs when no trace is asked for."""
         res = RansacResultC()
+        tr = np.full(max_iterations, -2, np.int32) if trace else None
         _check(self._h, lib().tdv_ransac_dev(self._h, _ptr(d_src), ns, _ptr(d_tgt), nt, _ptr(d_fs), _ptr(d_ft), _ptr(d_corr),
                                              C.c_float(voxel), max_iterations, C.c_float(confidence), C.c_uint32(seed),
-                                             C.byref(res), None), "tdv_ransac_dev")
+                                             C.byref(res), _ptr(tr)), "tdv_ransac_dev")
         return RegistrationResult(transformation=from_colmajor16(res.T), fitness=np.float32(res.fitness), rmse=np.float32(res.rmse),
-                                  inliers=res.inliers, best_iteration=res.best_iteration, iterations_run=res.iterations_run)
+                                  inliers=res.inliers, best_iteration=res.best_iteration, iterations_run=res.iterations_run, trace_inliers=tr)
 
     def feature_match_dev(self, d_fs, ns, d_ft, nt, d_corr):
         _check(self._h, lib().tdv_feature_match_dev(self._h, _ptr(d_fs), ns, _ptr(d_ft), nt, _ptr(d_corr)), "tdv_feature_match_dev")

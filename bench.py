@@ -191,6 +191,15 @@ def main():
     ctx.set_icp_search("auto")
     ctx.timing_enable(False)
 
+    # supplementary: RANSAC with EVERY (hypothesis, point) test evaluated (a traced call: the exact bail-out is off), outside `value`
+    full_hyps = 4 * 65536
+    ctx.timing_enable(True); ctx.timing_read(tdv.TIMER_RANSAC_SCORE)
+    torch.cuda.synchronize(); t_f0 = time.perf_counter()
+    r_full = ctx.ransac_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), n, None, None, d_corr.data_ptr(), voxel, full_hyps, 2.0, 42, trace=True)
+    torch.cuda.synchronize(); t_full = time.perf_counter() - t_f0
+    full_ms, full_launches = ctx.timing_read(tdv.TIMER_RANSAC_SCORE); ctx.timing_enable(False)
+    full_rescore = ctx.last_ransac_rescore(); full_scored = ctx.last_ransac_scored()
+
     if rank == 0:
         steps_total = args.steps * world
         pairs = float(n) * float(n)
@@ -245,6 +254,13 @@ def main():
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": sc_bytes / max(sc_avg_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBPS},
             "traffic": traffic(sc_kernel),
         }
+        full_ops = (16.6 + 28.0 * full_rescore) if full_rescore >= 0.0 else 28.0
+        score["every_test_scored"] = {
+            "note": "the same kernel with the bail-out off (a call that asks for the per-iteration trace): %d hypotheses x all %d points, one dispatch per batch" % (full_hyps, n),
+            "hyps_per_s": full_hyps / t_full, "avg_launch_ms": full_ms / max(full_launches, 1), "launches": full_launches,
+            "scored_share": full_scored, "achieved": full_ops * n * full_hyps / max(full_ms * 1e-3, 1e-12) / 1e12, "peak": VALU_PEAK_TOPS,
+            "frac": full_ops * n * full_hyps / max(full_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS,
+            "best_inliers": int(r_full.inliers), "best_iteration": int(r_full.best_iteration)}
         if fast:
             score["rescore_share"] = rescore_share
             score["scored_share"] = scored_share
