@@ -125,6 +125,14 @@ def cloud_ops(ctx, tdv, synth, torch, dev, n, reps=3, want_match=True):
         wall = median_ms(lambda: ctx.feature_match_dev(d_desc.data_ptr(), n, d_mdesc.data_ptr(), n, d_corr.data_ptr()), torch, reps=reps)
         out.append(pruned(dict(op="feature_match", workload="%d x %d FPFH descriptors of the cuboid (GPU chain), index build included" % (n, n), ms=wall),
                           98.0 * n * n, wall, "packed index; flat faces give bit-identical rows, which the index holds once"))
+        if n == 100000:   # config C3's RANSAC half: 50,000 hypotheses over these correspondences, no early exit
+            hyps = 50000
+            f = lambda: ctx.ransac_dev(d_xyz.data_ptr(), n, d_mx.data_ptr(), n, None, None, d_corr.data_ptr(), spacing, hyps, 2.0, 42)
+            wall = median_ms(f, torch, reps=reps)
+            r = f()
+            out.append(dict(op="ransac_c3", workload="C3: %d hypotheses x %d correspondences from the descriptor match above (cuboid), confidence 2.0" % (hyps, n),
+                            ms=wall, hyps_per_s=hyps / (wall * 1e-3), scored_share=ctx.last_ransac_scored(), rescore_share=ctx.last_ransac_rescore(),
+                            best_fitness=float(r.fitness), bound="valu_f32 (k_ransac_score_fast; two batches, the second with the exact bail-out)"))
     return out
 
 
