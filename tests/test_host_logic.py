@@ -330,3 +330,56 @@ def test_ransac_fast_scoring_band_covers_the_two_arithmetics(offset):
     E = 16 * u * (A_kernel + thr)
     near = np.maximum(D_ref, D_fma) <= 2 * thr
     assert (np.abs(D_ref - D_fma)[near] <= E[near]).all()
+
+
+def test_ransac_bailout_scheme_is_exact_on_simulated_counts():
+    """RansacPlan (csrc/ransac.hip) in plain Python on random inlier tables: the host loop fed with PARTIAL counts for the
+    hypotheses the scheme drops returns what the reference's loop (registration.cpp:281-290) returns on the true counts - best
+    iteration, best count, iterations run - for random batch sizes, prefixes, confidences, skipped iterations and heavy ties."""
+    rng = np.random.default_rng(11)
+
+    def reference_loop(true, valid, ns, confidence):
+        best_f, best_it, best_c, run = np.float32(0), -1, 0, 0
+        for it in range(len(true)):
+            run = it + 1
+            if not valid[it]: continue
+            f = np.float32(true[it]) / np.float32(ns)
+            if f > best_f: best_f, best_it, best_c = f, it, int(true[it])
+            if f > np.float32(confidence): break
+        return best_it, best_c, run
+
+    def bailout_loop(inl, valid, ns, confidence, first, batch, drop_permille):
+        # inl[h, i] = 1 if point i is an inlier of hypothesis h; the device keeps `best` = max count seen in EARLIER batches
+        n_h = len(inl); best_dev = 0
+        best_f, best_it, best_c, run = np.float32(0), -1, 0, 0
+        it0 = 0; stop = False
+        while it0 < n_h and not stop:
+            cnt = min(first if it0 == 0 else batch, n_h - it0)
+            rest = best_dev - max(best_dev * drop_permille // 1000, 1)
+            split = ns if rest < ns // 8 else max(0, ns - rest)            # points in phase 1 (k_ransac_plan; chunking left out)
+            counts = inl[it0:it0 + cnt, :split].sum(1)
+            left = ns - split
+            survive = valid[it0:it0 + cnt] & (left > 0) & (counts + left > best_dev)      # k_ransac_select
+            counts = counts + np.where(survive, inl[it0:it0 + cnt, split:].sum(1), 0)     # phase 2
+            for k in range(cnt):                                                         # the host loop of ransac_run_dev
+                run = it0 + k + 1
+                if not valid[it0 + k]: continue
+                f = np.float32(counts[k]) / np.float32(ns)
+                if f > best_f: best_f, best_it, best_c = f, it0 + k, int(counts[k])
+                if f > np.float32(confidence): stop = True; break
+            v = counts[valid[it0:it0 + cnt]]
+            if len(v): best_dev = max(best_dev, int(v.max()))                             # k_ransac_best
+            it0 += cnt
+        return best_it, best_c, run
+
+    for trial in range(300):
+        ns = int(rng.integers(8, 200)); n_h = int(rng.integers(1, 400))
+        quality = rng.choice([0.02, 0.3, 0.6, 0.95], size=n_h, p=[0.6, 0.2, 0.15, 0.05]) * rng.uniform(0.5, 1.0)
+        inl = (rng.random((n_h, ns)) < quality[:, None]).astype(np.int64)
+        if trial % 3 == 0: inl[rng.integers(0, n_h, n_h // 2)] = inl[rng.integers(0, n_h)]    # many exact ties
+        valid = rng.random(n_h) > 0.1
+        confidence = float(rng.choice([2.0, 0.9, 0.6, 0.3, 0.05, -1.0]))
+        true = inl.sum(1)
+        want = reference_loop(true, valid, ns, confidence)
+        got = bailout_loop(inl, valid, ns, confidence, int(rng.integers(1, 40)), int(rng.integers(1, 120)), int(rng.choice([5, 100, 500])))
+        assert got == want, (trial, got, want)
