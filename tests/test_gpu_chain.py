@@ -143,7 +143,8 @@ def test_instances_sharing_frames(ctx, tdv, synth, scene):
                                      d_xyz.data_ptr(), None, cap, n_frames=N_INST, frame_of_instance=np.array([0, 1, 3], np.int32))
 
 
-def test_batched_chain_tie_heavy_terraces(ctx, tdv, synth):
+@pytest.mark.parametrize("k", [30, 120])     # 120 > the radius lists' cap of 100: the batch then runs its stages on the reference-ordered cloud itself
+def test_batched_chain_tie_heavy_terraces(ctx, tdv, synth, k):
     """Terraces of constant depth seen head-on: pixels and voxel means sit on lattices, so nearly every neighbour list holds
     runs of exactly equal distances, whose order is decided by the members' positions in the reference's container order.
     The batch computes normals, descriptors and matches on the first-occurrence order with those positions as tie-break ids
@@ -166,9 +167,9 @@ def test_batched_chain_tie_heavy_terraces(ctx, tdv, synth):
     raw, _ = ctx.depth_to_cloud(md, mm, None, scale, f, f, w / 2.0, h / 2.0, zmax)
     d_raw = torch.from_numpy(raw).to(dev)
     d_mx = torch.empty_like(d_raw); d_mn = torch.empty_like(d_raw); d_mf = torch.empty((len(raw), 33), dtype=torch.float32, device=dev)
-    nm = ctx.prepare_model_dev(d_raw.data_ptr(), len(raw), voxel, 30, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), order=tdv.TDV_VOXEL_ORDER_REFERENCE)
+    nm = ctx.prepare_model_dev(d_raw.data_ptr(), len(raw), voxel, k, 5.0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), order=tdv.TDV_VOXEL_ORDER_REFERENCE)
     mx = d_mx[:nm].cpu().numpy(); mn = d_mn[:nm].cpu().numpy(); mf = d_mf[:nm].cpu().numpy()
-    prm = tdv.batch_params(width=w, height=h, scale_to_meters=scale, zmax=zmax, voxel_size=voxel, ransac_max_iterations=1500,
+    prm = tdv.batch_params(width=w, height=h, scale_to_meters=scale, zmax=zmax, voxel_size=voxel, normals_k=k, ransac_max_iterations=1500,
                            icp_max_iterations=10, voxel_order=tdv.TDV_VOXEL_ORDER_REFERENCE, n_frames=2, **intr)
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev); d_masks = torch.from_numpy(masks).to(dev)
     res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 2, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
@@ -176,7 +177,7 @@ def test_batched_chain_tie_heavy_terraces(ctx, tdv, synth):
     for b, r in enumerate(res):
         xyz, _ = ctx.depth_to_cloud(depth[b], masks[b], None, scale, f, f, w / 2.0, h / 2.0, zmax)
         src, _ = ctx.voxel_downsample(xyz, None, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
-        nrm, knn = ctx.estimate_normals(src, 30, want_knn=True)
+        nrm, knn = ctx.estimate_normals(src, k, want_knn=True)
         d2 = ((src[knn] - src[:, None, :]) ** 2).sum(2)
         tied += int((np.diff(d2, axis=1) == 0).sum())
         fp = ctx.compute_fpfh(src, nrm, voxel * 5.0)
