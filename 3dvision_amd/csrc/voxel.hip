@@ -211,15 +211,10 @@ __global__ void k_voxel_scatter(const uint4* __restrict__ rec_in, int n, unsigne
 // leader (its smallest input index), sums the members in ascending index order and parks the mean at the leader's index.
 // One launch instead of bucket sort + heads + means; the slot of a mean (its first-occurrence rank) comes from the scan of
 // the leader flags, after which k_voxel_compact moves it there.
-__global__ void k_voxel_bucket_emit(uint4* __restrict__ rec, const int* __restrict__ start, const int* __restrict__ hist, int nbuckets,
-                                    int* __restrict__ too_big, const float* __restrict__ xyz, const float* __restrict__ rgb,
-                                    int* __restrict__ leader, float* __restrict__ mean_xyz, float* __restrict__ mean_rgb) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    const int m = hist[b];
-    if (m == 0) return;
-    if (m > VX_MAX_BUCKET) { *too_big = 1; return; }
-    uint4* a = rec + start[b];
+// The bucket's records sorted by (cell, index), its voxels emitted.  `a` points at the bucket's records - in LDS (the normal case:
+// the workgroup's 256 buckets are one contiguous stretch of the record array, staged with coalesced loads) or in global memory.
+__device__ __forceinline__ void voxel_emit_bucket(uint4* a, int m, const float* __restrict__ xyz, const float* __restrict__ rgb,
+                                                  int* __restrict__ leader, float* __restrict__ mean_xyz, float* __restrict__ mean_rgb) {
     for (int e = 1; e < m; ++e) {   // insertion sort by (x, y, z, index)
         const uint4 key = a[e];
         int f = e - 1;
@@ -244,6 +239,28 @@ __global__ void k_voxel_bucket_emit(uint4* __restrict__ rec, const int* __restri
         mean_xyz[3 * l] = ax / fn; mean_xyz[3 * l + 1] = ay / fn; mean_xyz[3 * l + 2] = az / fn;   // :52-53
         if (rgb && mean_rgb) { mean_rgb[3 * l] = cr / fn; mean_rgb[3 * l + 1] = cg / fn; mean_rgb[3 * l + 2] = cb / fn; }
     }
+}
+constexpr int VX_LDS_REC = 1024;   // records of a workgroup's 256 buckets staged in LDS (16 KB); a denser stretch sorts in global memory
+__global__ __launch_bounds__(256)
+void k_voxel_bucket_emit(uint4* __restrict__ rec, const int* __restrict__ start, const int* __restrict__ hist, int nbuckets, int n_rec,
+                         int* __restrict__ too_big, const float* __restrict__ xyz, const float* __restrict__ rgb,
+                         int* __restrict__ leader, float* __restrict__ mean_xyz, float* __restrict__ mean_rgb) {
+    // The insertion sort is a chain of dependent loads and stores: through global memory every step is a round trip of about a
+    // microsecond and the kernel's time was that of its fullest bucket (42 us at 200k points with lanes alive for 3 us on
+    // average); through LDS a step costs a hundred cycles: 25 us.  (Staging the records' points in LDS as well, so that the sums
+    // run over LDS too, changed nothing; nor did a 12-comparator sorting network over registers for buckets of up to 6 records.)
+    __shared__ uint4 s_rec[VX_LDS_REC];
+    const int b0 = blockIdx.x * 256, b = b0 + threadIdx.x;
+    const int base = start[b0];                                           // nbuckets is a multiple of 256
+    const int end = b0 + 256 < nbuckets ? start[b0 + 256] : n_rec;
+    const bool staged = end - base <= VX_LDS_REC;
+    if (staged) for (int i = threadIdx.x; i < end - base; i += 256) s_rec[i] = rec[base + i];
+    __syncthreads();
+    const int m = hist[b];
+    if (m == 0) return;
+    if (m > VX_MAX_BUCKET) { *too_big = 1; return; }
+    if (staged) voxel_emit_bucket(s_rec + (start[b] - base), m, xyz, rgb, leader, mean_xyz, mean_rgb);
+    else voxel_emit_bucket(rec + start[b], m, xyz, rgb, leader, mean_xyz, mean_rgb);
 }
 // out[rank[i]] = mean parked at leader i
 __global__ void k_voxel_compact(const int* __restrict__ leader, const int* __restrict__ rank, int n, const float* __restrict__ mean_xyz,
@@ -525,7 +542,7 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
         k_voxel_hist<<<(n + 255) / 256, 256, 0, s>>>(d_xyz, n, inv, (unsigned)(nb - 1), rec_in, hist);
         TDV_TRY(exclusive_scan_dev(ctx, hist, (int)nb, start, d_tot2));
         k_voxel_scatter<<<(n + 255) / 256, 256, 0, s>>>(rec_in, n, (unsigned)(nb - 1), start, cursor, rec);
-        k_voxel_bucket_emit<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(rec, start, hist, (int)nb, d_too_big, d_xyz, mean_rgb ? d_rgb : nullptr, leader, mean_xyz, mean_rgb);
+        k_voxel_bucket_emit<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(rec, start, hist, (int)nb, n, d_too_big, d_xyz, mean_rgb ? d_rgb : nullptr, leader, mean_xyz, mean_rgb);
     } else {
         TDV_TRY(ws_alloc(ctx, (size_t)n, &leader));
         k_voxel_records<<<(unsigned)((n_pow2 + 255) / 256), 256, 0, s>>>(d_xyz, n, (int)n_pow2, inv, rec);
