@@ -122,10 +122,10 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // lanes: 125 / 184 / 211 / 226 / 252; first-occurrence order 2 / 3 / 4 lanes: 265 / 275 / 260 — and at the end of round
     // 2, with every kernel shorter: reference order 4 / 6 / 8 / 10 lanes 395 / 439 / 466 / 463, first-occurrence order
     // 3 / 4 / 6 lanes 525 / 514 / 532.  Hence 8 resp. 3 lanes by default; TDV_BATCH_LANES overrides (1 = the caller's
-    // thread only, at most 12).
+    // thread only, at most 16).
     static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;
-    const int lanes_default = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 10 : 3;
-    const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 12), n_instances));
+    const int lanes_default = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 12 : 3;   // (10 / 12 / 14 / 16 lanes at the end of round 2: 502-513 / 508-518 / 509-519 / 507-518 instances/s)
+    const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 16), n_instances));
     std::vector<tdv_ctx*> lane_ctx{ctx};
     for (tdv_ctx* c = ctx; (int)lane_ctx.size() < want; c = c->helper) {
         if (!c->helper && tdv_ctx_create(ctx->device, &c->helper) != TDV_OK) { c->helper = nullptr; break; }
