@@ -63,6 +63,28 @@ int prepare(tdv_ctx* ctx, void* comm, int* world, int* rank) {
     return TDV_OK;
 }
 
+// Every rank-local argument is checked BEFORE the first payload collective, and the verdict is made identical on all
+// ranks by one all-gather of a small header (4 ints per rank): a rank that returned on its own between two collectives would
+// leave the others blocked in RCCL for ever.  After the header every rank takes the same branch and returns the same status.
+struct Header { int ok, a, b, c; };
+
+int exchange_header(tdv_ctx* ctx, void* comm, int world, int rank, Header mine, Header** all_out) {
+    hipStream_t s = ctx->stream;
+    Header *d_send, *d_recv;
+    TDV_TRY(tdv::ws_alloc(ctx, 1, &d_send));
+    TDV_TRY(tdv::ws_alloc(ctx, (size_t)world, &d_recv));
+    TDV_TRY(tdv::pin_reserve(ctx, sizeof(Header) * (size_t)(world + 1)));
+    Header* h = reinterpret_cast<Header*>(ctx->pin);
+    h[world] = mine;
+    TDV_HIP(ctx, hipMemcpyAsync(d_send, h + world, sizeof(Header), hipMemcpyHostToDevice, s));
+    TDV_RCCL(ctx, g_rccl.allgather(d_send, d_recv, sizeof(Header), kNcclChar, comm, s), "ncclAllGather(header)");
+    TDV_HIP(ctx, hipMemcpyAsync(h, d_recv, sizeof(Header) * (size_t)world, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    *all_out = h;
+    (void)rank;
+    return TDV_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -70,27 +92,33 @@ extern "C" {
 int tdv_broadcast_model(tdv_ctx* ctx, void* rccl_comm, int root, float* d_xyz, float* d_normals, float* d_fpfh, int capacity, int* n_model) {
     int world = 0, rank = 0;
     TDV_TRY(prepare(ctx, rccl_comm, &world, &rank));
-    if (!n_model || root < 0 || root >= world || capacity < 0) return TDV_ERR_BAD_ARG;
+    // `root` must be the same on every rank (it is an argument of the collective itself, as in ncclBroadcast); everything else
+    // is rank-local and goes through the header.
+    if (root < 0 || root >= world) return TDV_ERR_BAD_ARG;
     TDV_TRY(tdv::ws_reset(ctx));
     hipStream_t s = ctx->stream;
-    // 1. the point count (the other ranks size nothing: their buffers have `capacity`)
-    int* d_n;
-    TDV_TRY(tdv::ws_alloc(ctx, 1, &d_n));
-    TDV_TRY(tdv::pin_reserve(ctx, 64));
-    int* h_n = reinterpret_cast<int*>(ctx->pin);
-    *h_n = (rank == root) ? *n_model : 0;
-    TDV_HIP(ctx, hipMemcpyAsync(d_n, h_n, 4, hipMemcpyHostToDevice, s));
-    TDV_RCCL(ctx, g_rccl.bcast(d_n, d_n, 1, kNcclInt32, root, rccl_comm, s), "ncclBroadcast(count)");
-    TDV_HIP(ctx, hipMemcpyAsync(h_n, d_n, 4, hipMemcpyDeviceToHost, s));
-    TDV_HIP(ctx, hipStreamSynchronize(s));
-    const int n = *h_n;
-    *n_model = n;
-    if (n < 0 || n > capacity) { std::snprintf(ctx->err, sizeof(ctx->err), "model of %d points does not fit capacity %d", n, capacity); return TDV_ERR_BAD_ARG; }
+    Header mine;
+    mine.ok = (n_model && capacity >= 0 && d_xyz && d_fpfh && (rank != root || (*n_model >= 0 && *n_model <= capacity))) ? 1 : 0;
+    mine.a = (rank == root && n_model) ? *n_model : 0;          // the point count travels in the root's header
+    mine.b = capacity;
+    mine.c = d_normals ? 1 : 0;
+    Header* all;
+    TDV_TRY(exchange_header(ctx, rccl_comm, world, rank, mine, &all));
+    const int n = all[root].a;
+    int bad_rank = -1, min_cap = all[0].b, with_normals = 1;
+    for (int r = 0; r < world; ++r) {
+        if (!all[r].ok && bad_rank < 0) bad_rank = r;
+        if (all[r].b < min_cap) min_cap = all[r].b;
+        with_normals &= all[r].c;
+    }
+    if (bad_rank >= 0) { std::snprintf(ctx->err, sizeof(ctx->err), "tdv_broadcast_model: invalid arguments on rank %d (no payload was sent)", bad_rank); return TDV_ERR_BAD_ARG; }
+    if (n_model) *n_model = n;
+    if (n > min_cap) { std::snprintf(ctx->err, sizeof(ctx->err), "model of %d points does not fit the smallest capacity over ranks (%d)", n, min_cap); return TDV_ERR_BAD_ARG; }
     if (n == 0) return TDV_OK;
-    if (!d_xyz || !d_fpfh) return TDV_ERR_BAD_ARG;
-    // 2. the pack, three in-place broadcasts (a model without normals is legal: point-to-point ICP)
+    // the pack, three in-place broadcasts.  Normals travel only when EVERY rank passed a buffer (a model without normals is
+    // legal: point-to-point ICP); a rank that did pass one while another did not keeps its buffer untouched.
     TDV_RCCL(ctx, g_rccl.bcast(d_xyz, d_xyz, (size_t)n * 3, kNcclFloat32, root, rccl_comm, s), "ncclBroadcast(points)");
-    if (d_normals) TDV_RCCL(ctx, g_rccl.bcast(d_normals, d_normals, (size_t)n * 3, kNcclFloat32, root, rccl_comm, s), "ncclBroadcast(normals)");
+    if (with_normals) TDV_RCCL(ctx, g_rccl.bcast(d_normals, d_normals, (size_t)n * 3, kNcclFloat32, root, rccl_comm, s), "ncclBroadcast(normals)");
     TDV_RCCL(ctx, g_rccl.bcast(d_fpfh, d_fpfh, (size_t)n * 33, kNcclFloat32, root, rccl_comm, s), "ncclBroadcast(fpfh)");
     TDV_HIP(ctx, hipStreamSynchronize(s));
     return TDV_OK;
@@ -100,20 +128,28 @@ int tdv_gather_results(tdv_ctx* ctx, void* rccl_comm, const tdv_instance_result*
                        tdv_instance_result* all) {
     int world = 0, rank = 0;
     TDV_TRY(prepare(ctx, rccl_comm, &world, &rank));
-    if (n_local < 0 || slots_per_rank < n_local || !all || (n_local > 0 && !local)) return TDV_ERR_BAD_ARG;
-    if (slots_per_rank == 0) return TDV_OK;
     TDV_TRY(tdv::ws_reset(ctx));
     hipStream_t s = ctx->stream;
-    const size_t rec = sizeof(tdv_instance_result), mine = (size_t)slots_per_rank * rec, total = mine * (size_t)world;
+    Header mine;
+    mine.ok = (n_local >= 0 && slots_per_rank >= n_local && all && (n_local == 0 || local)) ? 1 : 0;
+    mine.a = slots_per_rank; mine.b = n_local; mine.c = 0;
+    Header* hdr;
+    TDV_TRY(exchange_header(ctx, rccl_comm, world, rank, mine, &hdr));
+    for (int r = 0; r < world; ++r) {
+        if (!hdr[r].ok) { std::snprintf(ctx->err, sizeof(ctx->err), "tdv_gather_results: invalid arguments on rank %d (nothing was gathered)", r); return TDV_ERR_BAD_ARG; }
+        if (hdr[r].a != hdr[0].a) { std::snprintf(ctx->err, sizeof(ctx->err), "tdv_gather_results: slots_per_rank differs between ranks (%d on rank 0, %d on rank %d)", hdr[0].a, hdr[r].a, r); return TDV_ERR_BAD_ARG; }
+    }
+    if (slots_per_rank == 0) return TDV_OK;
+    const size_t rec = sizeof(tdv_instance_result), mine_b = (size_t)slots_per_rank * rec, total = mine_b * (size_t)world;
     char *d_send, *d_recv;
-    TDV_TRY(tdv::ws_alloc(ctx, mine, &d_send));
+    TDV_TRY(tdv::ws_alloc(ctx, mine_b, &d_send));
     TDV_TRY(tdv::ws_alloc(ctx, total, &d_recv));
     TDV_TRY(tdv::pin_reserve(ctx, total));
-    std::memset(ctx->pin, 0, mine);
+    std::memset(ctx->pin, 0, mine_b);
     for (int i = n_local; i < slots_per_rank; ++i) reinterpret_cast<tdv_instance_result*>(ctx->pin)[i].status = -1;   // unused slot
     if (n_local) std::memcpy(ctx->pin, local, (size_t)n_local * rec);
-    TDV_HIP(ctx, hipMemcpyAsync(d_send, ctx->pin, mine, hipMemcpyHostToDevice, s));
-    TDV_RCCL(ctx, g_rccl.allgather(d_send, d_recv, mine, kNcclChar, rccl_comm, s), "ncclAllGather(results)");
+    TDV_HIP(ctx, hipMemcpyAsync(d_send, ctx->pin, mine_b, hipMemcpyHostToDevice, s));
+    TDV_RCCL(ctx, g_rccl.allgather(d_send, d_recv, mine_b, kNcclChar, rccl_comm, s), "ncclAllGather(results)");
     TDV_HIP(ctx, hipMemcpyAsync(ctx->pin, d_recv, total, hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
     std::memcpy(all, ctx->pin, total);

@@ -48,7 +48,54 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-operators", action="store_true", help="skip the per-operator block measured after the timed region")
     ap.add_argument("--cpu-budget-s", type=float, default=16.0)
+    ap.add_argument("--min-region-ms", type=float, default=100.0,
+                    help="the timed region is repeated (whole multiples of K steps) until it is at least this long; 0 = exactly K steps once")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="CPU-only rehearsal of the N-rank launch (gloo, no GPU work): the same spawn / barrier / max-over-ranks / one-line skeleton")
     return ap.parse_args()
+
+
+def launch_check(args):
+    """The N > 1 skeleton of this script without a GPU: ranks rendezvous over gloo, rank 0 'broadcasts the model', every rank
+    times K stand-in steps between barriers, the maximum over ranks is taken and rank 0 prints ONE line.  What
+    tests/test_bench_launch.py runs here (no GPU in the build container) to prove that `python bench.py --gpus N` starts N ranks."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = dist.get_world_size() if world > 1 else 1
+    if args.gpus != seen:
+        raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, seen))
+    sharding = importlib.import_module("3dvision_amd.sharding")
+    pack = torch.arange(64 * sharding.MODEL_PACK_WIDTH, dtype=torch.float32).reshape(64, -1) if rank == 0 else None
+    t0 = time.perf_counter()
+    model = sharding.broadcast_model(pack, 64, torch.device("cpu"))
+    bcast_ms = (time.perf_counter() - t0) * 1e3
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    acc = 0.0
+    for _ in range(args.steps):
+        acc += float(model.sum())
+    if world > 1:
+        dist.barrier()
+    times = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    mine = torch.tensor([args.steps / max(float(times[0]), 1e-9), float(rank)], dtype=torch.float64)
+    per_rank = [torch.zeros_like(mine) for _ in range(seen)]
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no GPU work)", "launch_check": True, "n_gpus": seen, "steps": args.steps, "warmup": args.warmup,
+                          "value": args.steps * seen / max(float(times[0]), 1e-9), "unit": "stand-in steps/s", "scaling": "weak",
+                          "model_bcast_ms": bcast_ms, "model_checksum": float(model.sum()),
+                          "per_rank": [{"rank": int(x[1]), "steps_per_s": float(x[0])} for x in per_rank]}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def cpu_baseline(orc, src, tgt, nrm, corr, T0, thr, voxel, budget_s):
@@ -99,19 +146,27 @@ def cpu_baseline(orc, src, tgt, nrm, corr, T0, thr, voxel, budget_s):
 
 def main():
     args = parse()
+    launch = importlib.import_module("3dvision_amd.launch")
+    if args.gpus > 1 and not launch.in_rendezvous():
+        # `python bench.py --gpus N` without a launcher around it: start the N ranks ourselves.  Nothing in this process has
+        # touched HIP yet (torch is not even imported), children are fresh interpreters, rank 0's line is relayed once.
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.launch_check:
+        return launch_check(args)
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    distributed = world > 1
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = env_world > 1
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=torch.device("cuda", local_rank))
+    world = dist.get_world_size() if distributed else 1      # the ranks RCCL actually joined: what n_gpus reports
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but %d rank(s) joined the job" % (args.gpus, world))
 
     tdv = importlib.import_module("3dvision_amd")
     synth = importlib.import_module("3dvision_amd.synth")
@@ -157,19 +212,36 @@ def main():
         c = time.perf_counter()
         return b - a, c - b, r_icp, r_rs
 
+    region_est = None
     if args.warmup > 0:
         run(args.warmup, False)
+        w = run(args.warmup, False)                  # second pass: workspaces sized, clocks up - its wall time sizes the timed region
+        region_est = (w[0] + w[1]) * args.steps / args.warmup
+    # A timed region shorter than ~100 ms is dominated by box noise (and invisible to a 1 Hz utilisation sampler): the K-step
+    # pass is repeated `regions` times inside ONE barrier/sync bracket; every figure below is per step over all K x regions steps.
+    regions = 1
+    if args.min_region_ms > 0 and region_est is not None:
+        regions = max(1, int(np.ceil(args.min_region_ms * 1e-3 / max(region_est, 1e-6))))
+    rg = torch.tensor([regions], dtype=torch.int64, device=dev)
+    if distributed:
+        dist.all_reduce(rg, op=dist.ReduceOp.MAX)      # same count on every rank
+    regions = int(rg.item())
     ctx.timing_enable(True)
     ctx.timing_read(tdv.TIMER_ICP_NN); ctx.timing_read(tdv.TIMER_RANSAC_SCORE)
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    t_icp, t_rs, r_icp, r_rs = run(args.steps, True)
+    t_icp = t_rs = 0.0
+    for _ in range(regions):
+        a_, b_, r_icp, r_rs = run(args.steps, True)
+        t_icp += a_; t_rs += b_
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t_start
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    steps_timed = args.steps * regions
     nn_ms, nn_launches = ctx.timing_read(tdv.TIMER_ICP_NN)
     sc_ms, sc_launches = ctx.timing_read(tdv.TIMER_RANSAC_SCORE)
     ctx.timing_enable(False)
@@ -181,6 +253,16 @@ def main():
     if distributed:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, t_icp, t_rs = [float(x) for x in times.cpu()]
+    # per-rank view (rank 0 prints it at N > 1): own steps/s, the dominant kernel's average dispatch and executed-op fraction
+    ops_mine = ((16.6 + 28.0 * rescore_share) if rescore_share >= 0.0 else 28.0) * scored_share * n * float(steps_timed) * HYPS_PER_STEP
+    mine = torch.tensor([rank, steps_timed / t_local, sc_ms / max(sc_launches, 1), ops_mine / max(sc_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS,
+                         bcast_ms], dtype=torch.float64, device=dev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    if distributed:
+        dist.all_gather(per_rank, mine)
+    else:
+        per_rank = [mine]
+    per_rank = [[float(v) for v in x.cpu()] for x in per_rank]
 
     # supplementary: the brute-force NN scan (the reference kernel's algorithm) on the same inputs, outside `value`
     ctx.timing_enable(True)
@@ -201,18 +283,22 @@ def main():
     full_rescore = ctx.last_ransac_rescore(); full_scored = ctx.last_ransac_scored()
 
     if rank == 0:
-        steps_total = args.steps * world
+        steps_total = steps_timed * world
         pairs = float(n) * float(n)
         nn_avg_ms = nn_ms / max(nn_launches, 1)
         sc_avg_ms = sc_ms / max(sc_launches, 1)
         bf_avg_ms = bf_ms / max(bf_launches, 1)
-        hyps_total = float(args.steps) * HYPS_PER_STEP
+        hyps_total = float(steps_timed) * HYPS_PER_STEP
         pruned_default = icp_search_used in ("pruned", "grid")
         # HBM traffic per launch from the PMC passes (rocprofv3 --pmc cannot run inside this process): taken from the
         # committed summary of the same command when it covers this workload, else null
         pm = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")))
+            for pm_round in ("r3", "r2"):
+                pm_path = os.path.join(ROOT, "profiles", pm_round, "pmc_summary.json")
+                if os.path.exists(pm_path):
+                    break
+            pm = json.load(open(pm_path))
             if not (pm["workload"]["n_src"] == n and pm["workload"]["n_tgt"] == n):
                 pm = None
         except Exception:
@@ -234,8 +320,9 @@ def main():
         # bail-out a batch of hypotheses is two dispatches: every hypothesis over a prefix of the points, then the hypotheses that
         # can still beat the best count of the earlier batches over the rest - together they read the pair array once.
         # (batching rule of csrc/ransac.hip: batches of 65,536 hypotheses, the first one 8,192 when the bail-out is on)
-        bail = fast_mode_bailout = (os.environ.get("TDV_RANSAC_BAILOUT", "1") != "0") and hyps_total > 16384
-        sc_batches = (1 + -(-(int(hyps_total) - 8192) // 65536)) if bail else max(1, -(-int(hyps_total) // 65536))
+        hyps_call = args.steps * HYPS_PER_STEP        # one RANSAC call per region
+        bail = (os.environ.get("TDV_RANSAC_BAILOUT", "1") != "0") and hyps_call > 16384
+        sc_batches = regions * ((1 + -(-(hyps_call - 8192) // 65536)) if bail else max(1, -(-hyps_call // 65536)))
         sc_hyps_per_launch = hyps_total / max(sc_launches, 1)
         fast = rescore_share >= 0.0
         ops_per_test = (16.6 + 28.0 * rescore_share) if fast else 28.0
@@ -300,7 +387,9 @@ def main():
         dominant, other = (score, nn) if sc_ms >= nn_ms else (nn, score)
         roofline = dict(dominant)
         roofline["traffic_unit"] = "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, mean over the dispatches of the same command)"
-        roofline["traffic_source"] = "profiles/r2/pmc_summary.json (separate rocprofv3 --pmc passes)" if roofline.get("traffic") is not None else None
+        roofline["traffic_source"] = ("FROM A COMMITTED PROFILE, not measured by this run: profiles/%s/pmc_summary.json (separate rocprofv3 --pmc FETCH_SIZE / "
+                                      "WRITE_SIZE passes of this command on the builder's box; PMC counters cannot be read from inside the benchmarked process)" % pm_round) \
+            if roofline.get("traffic") is not None else None
         roofline["second_kernel"] = other
         roofline["icp_nn_bruteforce_scan"] = brute
         out = {
@@ -308,16 +397,23 @@ def main():
             "value": steps_total / elapsed,
             "unit": "steps/s (1 step = 1 ICP iteration + %d RANSAC hypotheses, N_s=N_t=%d)" % (HYPS_PER_STEP, n),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "timed_regions": regions, "steps_timed": steps_timed, "timed_region_ms": elapsed * 1e3,
+            "ms_per_step": elapsed / steps_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "icp_iters_per_s": args.steps * world / t_icp,
-            "ransac_hyps_per_s": args.steps * HYPS_PER_STEP * world / t_rs,
+            "icp_iters_per_s": steps_timed * world / t_icp,
+            "ransac_hyps_per_s": steps_timed * HYPS_PER_STEP * world / t_rs,
             "targets": {"icp_iters_per_s": 50, "ransac_hyps_per_s": 1e6},
-            "config": {"workload": "headline: N_s=N_t=%d, point-to-plane ICP (fixed %d iterations, %s correspondence search) + RANSAC scoring (%d hyps), one instance pair per GPU"
-                                   % (n, args.steps, {"grid": "exact hash-grid", "pruned": "exact pruned"}.get(icp_search_used, "brute-force"), args.steps * HYPS_PER_STEP),
+            "config": {"workload": "headline: N_s=N_t=%d, point-to-plane ICP (fixed %d iterations per call, %s correspondence search) + RANSAC scoring (%d hyps per call), "
+                                   "%d call(s) of each in the timed region, one instance pair per GPU"
+                                   % (n, args.steps, {"grid": "exact hash-grid", "pruned": "exact pruned"}.get(icp_search_used, "brute-force"), args.steps * HYPS_PER_STEP, regions),
                        "n_src": n, "n_tgt": n, "hyps_per_step": HYPS_PER_STEP, "parallelism": "instances sharded, %d rank(s)" % world,
+                       "icp_start": "0.3 deg / 0.5 mm from the ground truth (inside the basin of the reference's 0.4-voxel threshold; SURVEY 8d's 3 deg / 5 mm start "
+                                    "lies outside it and every iteration count is fixed, so the start only decides how many correspondences are accepted)",
                        "model_bcast_ms": bcast_ms if distributed else None},
+            "model_bcast_ms": bcast_ms if distributed else None,
+            "per_rank": [{"rank": int(x[0]), "steps_per_s": x[1], "dominant_kernel_avg_ms": x[2], "dominant_kernel_frac": x[3], "model_bcast_ms": x[4] if distributed else None}
+                         for x in per_rank],
             "roofline": roofline,
             "result_check": {"icp_fitness": float(r_icp.fitness), "icp_rmse": float(r_icp.rmse), "ransac_inliers": int(r_rs.inliers),
                              "ransac_iterations_run": int(r_rs.iterations_run)},

@@ -323,8 +323,14 @@ int tdv_prepare_model_dev(tdv_ctx* ctx, const float* d_xyz, int n, float voxel_s
  *
  * tdv_broadcast_model: the prepared model (what tdv_prepare_model_dev / Pipeline::run :291-294 produce) from rank `root`
  * to every rank, in place: on root *n_model is the input count, elsewhere it receives it; buffers hold `capacity` points
- * on every rank (TDV_ERR_BAD_ARG if the model does not fit).  d_normals may be NULL on ALL ranks (no normals: ICP falls
- * back to point-to-point, registration.cpp:343).
+ * on every rank (TDV_ERR_BAD_ARG if the model does not fit).  d_normals may be NULL (no normals: ICP falls back to
+ * point-to-point, registration.cpp:343); normals travel only if EVERY rank passed a buffer.
+ * Rank-local arguments (buffers, capacity, counts) are validated through one all-gather of a 16-byte header before any
+ * payload moves, so every rank takes the same branch and returns the SAME status — a bad argument on one rank makes all
+ * ranks return TDV_ERR_BAD_ARG instead of leaving the others blocked in a collective.  `root` (and slots_per_rank below)
+ * must agree across ranks like the arguments of any collective; a disagreement in slots_per_rank is detected and refused.
+ * STATUS: verified on hardware at world size 1 only (tests/test_gpu_comm.py); world > 1 needs more GPUs than a test box has —
+ * "parity unpinned" for world > 1 until the driver's multi-GPU run.
  * tdv_gather_results: every rank contributes n_local results in slots_per_rank slots (the same number on every rank,
  * >= n_local; unused slots come back with status -1) and receives all ranks' slots, rank-major, in `all`
  * (world_size * slots_per_rank entries).  Both are host arrays. */

@@ -8,8 +8,9 @@ mask), a scan of the part as the model — a chain the reference's algorithm reg
 against its ground truth and the run fails if one is off.
 
     python tools/bench_c5.py --instances-per-gpu 64                                   # one GPU
+    python tools/bench_c5.py --gpus 8 --instances-per-gpu 1024                        # the C5 shape: starts its 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
-        tools/bench_c5.py --instances-per-gpu 1024                                    # the C5 shape
+        tools/bench_c5.py --instances-per-gpu 1024                                    # the same under an outer launcher
 
 Rank 0 prints one JSON line (aggregate instances/s, broadcast and gather times, registration quality)."""
 import argparse
@@ -28,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="ranks to start when no launcher is around this script (0: take WORLD_SIZE, else 1)")
     ap.add_argument("--instances-per-gpu", type=int, default=64)
     ap.add_argument("--frames-per-gpu", type=int, default=64, help="distinct poses rendered per rank; instances cycle through them (bounds the frame memory at 1024 instances)")
     ap.add_argument("--hyps", type=int, default=10000)
@@ -35,9 +37,14 @@ def main():
     ap.add_argument("--voxel-px", type=float, default=1.2)
     ap.add_argument("--max-angle", type=float, default=1e-2)
     args = ap.parse_args()
+    launch = importlib.import_module("3dvision_amd.launch")
+    if args.gpus > 1 and not launch.in_rendezvous():      # same self-launch as bench.py: the parent never touches HIP
+        sys.exit(launch.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus and args.gpus != world:
+        raise SystemExit("--gpus %d but %d rank(s) joined the job" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
