@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
     "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii", "tdv_load_mask_png", "tdv_load_masks_from_dir",
-    "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results",
+    "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results", "tdv_mask_resize_nearest", "tdv_mask_resize_nearest_dev",
 ]
 
 
@@ -68,7 +68,8 @@ class BatchParamsC(C.Structure):
                 ("voxel_size", C.c_float), ("normals_k", C.c_int), ("fpfh_radius_factor", C.c_float),
                 ("ransac_max_iterations", C.c_int), ("ransac_confidence", C.c_float), ("icp_distance_factor", C.c_float),
                 ("icp_max_iterations", C.c_int), ("point_to_plane", C.c_int), ("seed", C.c_uint32),
-                ("voxel_order", C.c_int), ("n_frames", C.c_int), ("frame_of_instance", C.c_void_p)]
+                ("voxel_order", C.c_int), ("n_frames", C.c_int), ("frame_of_instance", C.c_void_p),
+                ("mask_format", C.c_int), ("mask_width", C.c_int), ("mask_height", C.c_int)]
 
 
 class InstanceResultC(C.Structure):
@@ -196,7 +197,7 @@ class Context:
 
     def set_icp_search(self, mode):
         """'auto' (by size and cell occupancy), 'brute' (the reference's scan), 'pruned' (exact box-pruned walk) or 'grid' (hash grid
-        with cells of 1.25 x the threshold; falls back to 'pruned' when the threshold is large against the spacing); same results."""
+        with cells of 2.2 x the threshold; falls back to 'pruned' when the threshold is large against the spacing); same results."""
         _check(self._h, lib().tdv_ctx_set_icp_search(self._h, self.ICP_SEARCH[mode]), "tdv_ctx_set_icp_search")
         self.icp_search_name = mode
 
@@ -261,6 +262,17 @@ class Context:
         _check(self._h, lib().tdv_bilateral_filter(self._h, _ptr(d), w, h, C.c_float(sigma_spatial), C.c_float(sigma_range), _ptr(out)),
                "tdv_bilateral_filter")
         return out
+
+    def mask_resize_nearest(self, masks, dst_width, dst_height):
+        """cv::resize(mask, ..., INTER_NEAREST) of src/pipeline.cpp:38-41; masks: uint8 [h, w] or [B, h, w]."""
+        m = np.ascontiguousarray(masks, np.uint8)
+        single = m.ndim == 2
+        if single:
+            m = m[None]
+        B, sh, sw = m.shape
+        out = np.empty((B, dst_height, dst_width), np.uint8)
+        _check(self._h, lib().tdv_mask_resize_nearest(self._h, _ptr(m), B, sw, sh, dst_width, dst_height, _ptr(out)), "tdv_mask_resize_nearest")
+        return out[0] if single else out
 
     def deproject(self, depth, bgr, fx, fy, cx, cy, zmax, capacity=None):
         depth = _f32(depth)
@@ -402,12 +414,12 @@ class Context:
 def batch_params(width=1280, height=720, scale_to_meters=1000.0, mask_mode=TDV_MASK_THRESHOLD10, fx=900.0, fy=900.0, cx=640.0,
                  cy=360.0, zmax=1.5, voxel_size=0.001, normals_k=30, fpfh_radius_factor=5.0, ransac_max_iterations=100000,
                  ransac_confidence=0.999, icp_distance_factor=0.4, icp_max_iterations=200, point_to_plane=True, seed=42,
-                 voxel_order=TDV_VOXEL_ORDER_REFERENCE, n_frames=1, frame_of_instance=None):
+                 voxel_order=TDV_VOXEL_ORDER_REFERENCE, n_frames=1, frame_of_instance=None, mask_format=0, mask_width=0, mask_height=0):
     """Defaults = include/pipeline_config.hpp + config/pipeline_config.yaml of the reference; voxel_order defaults to the
     reference's container order (the poses of Pipeline::processInstance).  frame_of_instance: int array or None."""
     p = BatchParamsC(width, height, scale_to_meters, mask_mode, fx, fy, cx, cy, zmax, voxel_size, normals_k, fpfh_radius_factor,
                      ransac_max_iterations, ransac_confidence, icp_distance_factor, icp_max_iterations, int(point_to_plane), seed,
-                     voxel_order, n_frames, None)
+                     voxel_order, n_frames, None, mask_format, mask_width, mask_height)
     if frame_of_instance is not None:
         p._frame_map = np.ascontiguousarray(frame_of_instance, np.int32)   # kept alive by the struct object
         p.frame_of_instance = p._frame_map.ctypes.data

@@ -68,6 +68,25 @@ int tdv_bilateral_filter(tdv_ctx* ctx, const float* depth, int width, int height
     return finish(ctx);
 }
 
+int tdv_mask_resize_nearest(tdv_ctx* ctx, const uint8_t* masks, int n_masks, int src_width, int src_height, int dst_width, int dst_height, uint8_t* out) {
+    if (n_masks < 0 || src_width <= 0 || src_height <= 0 || dst_width < 0 || dst_height < 0) return TDV_ERR_BAD_ARG;
+    TDV_TRY(begin(ctx));
+    const size_t ns = (size_t)src_width * src_height * n_masks, nd = (size_t)dst_width * dst_height * n_masks;
+    if (nd == 0) return TDV_OK;
+    if (!masks || !out) return TDV_ERR_BAD_ARG;
+    uint8_t *d_in, *d_out;
+    TDV_TRY(upload(ctx, masks, ns, &d_in));
+    TDV_TRY(ws_alloc(ctx, nd, &d_out));
+    TDV_TRY(mask_resize_nearest_dev(ctx, d_in, n_masks, src_width, src_height, dst_width, dst_height, d_out));
+    TDV_TRY(download(ctx, out, d_out, nd));
+    return finish(ctx);
+}
+
+int tdv_mask_resize_nearest_dev(tdv_ctx* ctx, const uint8_t* d_masks, int n_masks, int src_width, int src_height, int dst_width, int dst_height, uint8_t* d_out) {
+    TDV_TRY(begin(ctx));
+    return mask_resize_nearest_dev(ctx, d_masks, n_masks, src_width, src_height, dst_width, dst_height, d_out);
+}
+
 int tdv_deproject(tdv_ctx* ctx, const float* depth, const uint8_t* bgr, int width, int height,
                   float fx, float fy, float cx, float cy, float zmax,
                   float* out_xyz, float* out_rgb, int capacity, int* n_out) {

@@ -25,18 +25,43 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     if (n_instances == 0) return TDV_OK;
     // all clouds of the frame in two launches (count + emit), back to back in one buffer
     if (prm->voxel_order != TDV_VOXEL_ORDER_FIRST && prm->voxel_order != TDV_VOXEL_ORDER_REFERENCE) return TDV_ERR_BAD_ARG;
+    if (prm->mask_format < 0 || prm->mask_format > 2) return TDV_ERR_BAD_ARG;
+    if (prm->mask_format != 0 && prm->n_frames > 1) return TDV_ERR_BAD_ARG;                     // a label image belongs to one frame
+    if (prm->mask_format == 1 && n_instances > 255) return TDV_ERR_BAD_ARG;                     // u8 labels: instance b is label b + 1
+    if (prm->mask_format == 2 && n_instances > 65535) return TDV_ERR_BAD_ARG;
+    const int layout = prm->mask_format == 0 ? 1 : (prm->mask_format == 1 ? 0 : 2);            // depth.hip's `stacked` argument
+    // masks of another size than the frame: nearest-neighbour resize first (src/pipeline.cpp:38-41)
+    const int mw = prm->mask_width > 0 ? prm->mask_width : prm->width, mh = prm->mask_height > 0 ? prm->mask_height : prm->height;
+    if (mw != prm->width || mh != prm->height) {
+        if (prm->mask_format == 2) return TDV_ERR_BAD_ARG;                                      // (a u16 label image is never resized: no such input in the reference)
+        uint8_t* resized;
+        const int n_masks = prm->mask_format == 0 ? n_instances : 1;
+        TDV_TRY(ws_alloc(ctx, (size_t)n_masks * prm->width * prm->height + 16, &resized));
+        resized = reinterpret_cast<uint8_t*>(align_up(reinterpret_cast<uintptr_t>(resized), 16));
+        TDV_TRY(mask_resize_nearest_dev(ctx, d_masks, n_masks, mw, mh, prm->width, prm->height, resized));
+        d_masks = resized;
+    }
     std::vector<int> off((size_t)n_instances + 1, 0);
     int* d_off = nullptr;
     const int* d_frame_of = nullptr;
     TDV_TRY(frame_map_dev(ctx, n_instances, prm->n_frames, prm->frame_of_instance, &d_frame_of));
-    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_frame_of, d_masks, n_instances, 1, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
+    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_frame_of, d_masks, n_instances, layout, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
                                        prm->zmax, &d_off, off.data()));
     float *all_xyz = nullptr;
     if (off[n_instances] > 0) {
         TDV_TRY(ws_alloc(ctx, (size_t)off[n_instances] * 3, &all_xyz));
-        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_frame_of, d_masks, nullptr, n_instances, 1, prm->width, prm->height, prm->scale_to_meters,
+        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_frame_of, d_masks, nullptr, n_instances, layout, prm->width, prm->height, prm->scale_to_meters,
                                           prm->mask_mode, prm->fx, prm->fy, prm->cx, prm->cy, prm->zmax, d_off, all_xyz, nullptr));
     }
+    // instances without a point: status 1 when the masked depth image holds no non-zero value at all (pipeline.cpp:57-60),
+    // status 2 when it does but nothing survives the z clip (:86-89)
+    std::vector<int> empty_inst, empty_nonzero;
+    for (int b = 0; b < n_instances; ++b) if (off[b + 1] == off[b]) empty_inst.push_back(b);
+    empty_nonzero.assign(empty_inst.size(), 0);
+    TDV_TRY(depth_batch_nonzero_any(ctx, d_raw, d_frame_of, d_masks, layout, prm->width, prm->height, prm->scale_to_meters, prm->mask_mode,
+                                    empty_inst.data(), (int)empty_inst.size(), empty_nonzero.data()));
+    std::vector<int> empty_status((size_t)n_instances, 0);
+    for (size_t e = 0; e < empty_inst.size(); ++e) empty_status[empty_inst[e]] = empty_nonzero[e] ? 2 : 1;
     (void)d_bgr;  // colours do not enter the registration chain (voxelDownsample keeps them, nothing downstream reads them)
     // the model's descriptors are packed once; every instance, on either lane, searches the same read-only index
     FmIndex model_index; bool have_index = false;
@@ -68,7 +93,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         const WsMark mark = ws_mark(c);
         int n = off[b + 1] - off[b];
         r.n_points = n;
-        if (n == 0) { r.status = 2; ws_rewind(c, mark); return TDV_OK; }
+        if (n == 0) { r.status = empty_status[b]; ws_rewind(c, mark); return TDV_OK; }
         float* xyz = all_xyz + (size_t)off[b] * 3;
         float* vx; int v = 0;
         TDV_TRY(ws_alloc(c, (size_t)n * 3, &vx));
@@ -117,14 +142,13 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // Lanes: the calling thread on ctx plus helper threads, each on its own helper ctx (stream + workspace, owned by ctx and
     // chained through ->helper), take the instances in turn, so that one lane's host syncs, its host replay of the voxel
     // order and its small kernels overlap the others' work — the shape of the reference's thread pool
-    // (src/pipeline.cpp:321-327), inside one call.  Results do not depend on the lanes.  Measured on C4 (96 instances,
-    // instances/s): the reference's voxel order, whose container replay is 3 ms of host time per instance, 1 / 2 / 3 / 4 / 6
-    // lanes: 125 / 184 / 211 / 226 / 252; first-occurrence order 2 / 3 / 4 lanes: 265 / 275 / 260 — and at the end of round
-    // 2, with every kernel shorter: reference order 4 / 6 / 8 / 10 lanes 395 / 439 / 466 / 463, first-occurrence order
-    // 3 / 4 / 6 lanes 525 / 514 / 532.  Hence 8 resp. 3 lanes by default; TDV_BATCH_LANES overrides (1 = the caller's
-    // thread only, at most 16).
+    // (src/pipeline.cpp:321-327), inside one call.  Results do not depend on the lanes.  Measured on C4 (instances/s) at the
+    // end of round 2: reference order 4 / 6 / 8 / 10 / 12 / 14 / 16 lanes 395 / 439 / 466 / 463-513 / 508-518 / 509-519 /
+    // 507-518, first-occurrence order 3 / 4 / 6 lanes 525 / 514 / 532.  Hence 12 resp. 3 lanes by default, never more than
+    // the host has hardware threads; TDV_BATCH_LANES overrides (1 = the caller's thread only, at most 16).
     static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;
-    const int lanes_default = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 12 : 3;   // (10 / 12 / 14 / 16 lanes at the end of round 2: 502-513 / 508-518 / 509-519 / 507-518 instances/s)
+    const int hw_threads = std::max(1u, std::thread::hardware_concurrency());
+    const int lanes_default = std::min(prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 12 : 3, hw_threads);
     const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 16), n_instances));
     std::vector<tdv_ctx*> lane_ctx{ctx};
     for (tdv_ctx* c = ctx; (int)lane_ctx.size() < want; c = c->helper) {
@@ -133,8 +157,10 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     }
     const int L = (int)lane_ctx.size();
     if (L == 1) {
-        for (int b = 0; b < n_instances; ++b) TDV_TRY(run_instance(ctx, b));
-        return TDV_OK;
+        int st = TDV_OK;
+        for (int b = 0; b < n_instances && st == TDV_OK; ++b) st = run_instance(ctx, b);
+        if (st != TDV_OK) (void)hipStreamSynchronize(ctx->stream);   // nothing of this call is in flight when it returns
+        return st;
     }
     TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the clouds and the model's index are complete before other streams read them
     std::vector<int> status((size_t)L, TDV_OK);
@@ -147,7 +173,8 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
                 if (hipSetDevice(h->device) != hipSuccess) { status[l] = TDV_ERR_NO_DEVICE; return; }
                 status[l] = ws_reset(h);
                 for (int b = l; b < n_instances && status[l] == TDV_OK; b += L) status[l] = run_instance(h, b);
-                if (status[l] == TDV_OK && hipStreamSynchronize(h->stream) != hipSuccess) status[l] = TDV_ERR_LAUNCH;
+                // on failure too: kernels of this lane may still be reading all_xyz and the workspaces the next call reuses
+                if (hipStreamSynchronize(h->stream) != hipSuccess && status[l] == TDV_OK) status[l] = TDV_ERR_LAUNCH;
             } catch (...) {   // nothing may escape a thread
                 std::snprintf(h->err, sizeof(h->err), "exception in a helper lane");
                 status[l] = TDV_ERR_INTERNAL;
@@ -161,6 +188,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         status[0] = TDV_ERR_INTERNAL;
     }
     for (auto& w : workers) w.join();
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && status[0] == TDV_OK) status[0] = TDV_ERR_LAUNCH;
     if (status[0] != TDV_OK) return status[0];
     for (int l = 1; l < L; ++l)
         if (status[l] != TDV_OK) { std::snprintf(ctx->err, sizeof(ctx->err), "batch lane %d: %s", l + 1, lane_ctx[l]->err); return status[l]; }
@@ -189,7 +217,10 @@ int tdv_depth_to_cloud_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint
                                  float fx, float fy, float cx, float cy, float zmax,
                                  float* d_xyz, float* d_rgb, long long capacity, int* h_offsets) {
     if (!ctx || !d_raw || !d_masks || !h_offsets || n_instances < 0 || width < 0 || height < 0 || capacity < 0) return TDV_ERR_BAD_ARG;
+    if (mask_format < 0 || mask_format > 2) return TDV_ERR_BAD_ARG;
     if (mask_format != 0 && n_frames > 1) return TDV_ERR_BAD_ARG;   // a label image belongs to one frame
+    if ((mask_format == 1 && n_instances > 255) || (mask_format == 2 && n_instances > 65535)) return TDV_ERR_BAD_ARG;   // instance b is label b + 1
+    const int layout = mask_format == 0 ? 1 : (mask_format == 1 ? 0 : 2);
     TDV_HIP(ctx, hipSetDevice(ctx->device));
     ctx->err[0] = 0;
     TDV_TRY(ws_reset(ctx));
@@ -198,10 +229,10 @@ int tdv_depth_to_cloud_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint
     int* d_off = nullptr;
     const int* d_frame_of = nullptr;
     TDV_TRY(frame_map_dev(ctx, n_instances, n_frames, h_frame_of_instance, &d_frame_of));
-    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_frame_of, d_masks, n_instances, mask_format == 0, width, height, scale, mask_mode, zmax, &d_off, h_offsets));
+    TDV_TRY(depth_to_cloud_batch_count(ctx, d_raw, d_frame_of, d_masks, n_instances, layout, width, height, scale, mask_mode, zmax, &d_off, h_offsets));
     if ((long long)h_offsets[n_instances] > capacity || (h_offsets[n_instances] > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
     if (h_offsets[n_instances] > 0)
-        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_frame_of, d_masks, d_bgr, n_instances, mask_format == 0, width, height, scale, mask_mode,
+        TDV_TRY(depth_to_cloud_batch_emit(ctx, d_raw, d_frame_of, d_masks, d_bgr, n_instances, layout, width, height, scale, mask_mode,
                                           fx, fy, cx, cy, zmax, d_off, d_xyz, d_rgb));
     TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TDV_OK;

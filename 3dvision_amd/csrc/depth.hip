@@ -226,21 +226,33 @@ int bilateral_filter_dev(tdv_ctx* ctx, const float* d_in, float* d_out, int w, i
 // B masks (stacked u8 images, or one label image with label = b + 1) of ONE depth/colour frame -> B clouds stored
 // back to back, each in row-major pixel order.  Grid = (pixel blocks, instances); the depth image is re-read from
 // L2 / Infinity Cache by every instance, the masks and the output stream through HBM once.
+// `stacked` carries the mask layout: 1 = one u8 mask per instance (mask_mode applies), 0 = ONE u8 label image (instance b
+// keeps the pixels equal to b + 1), 2 = ONE u16 label image (the same rule, for more than 255 instances).
+__device__ __forceinline__ bool batch_mask_keeps(const uint8_t* __restrict__ masks, size_t n, int b, int layout, size_t i, int mask_mode) {
+    if (layout == 1) return mask_keeps(masks[(size_t)b * n + i], mask_mode);
+    if (layout == 0) return (int)masks[i] == b + 1;
+    return (int)reinterpret_cast<const uint16_t*>(masks)[i] == b + 1;
+}
+__device__ __forceinline__ float batch_pixel_depth(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ masks, size_t n, int b, int layout,
+                                                   size_t i, float inv_scale, int mask_mode) {
+    float v = (float)raw[i] * inv_scale;
+    if (!batch_mask_keeps(masks, n, b, layout, i, mask_mode)) v = 0.f;
+    return v;
+}
+
 __global__ __launch_bounds__(DP_BLOCK)
 void k_valid_count_batch(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, size_t n, int stacked,
                          float inv_scale, int mask_mode, float zmax, int* __restrict__ block_counts) {
     const int b = blockIdx.y;
     const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
     const uint16_t* __restrict__ raw = raw0 + frame * n;
-    const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
-    const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
     const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
     int c = 0;
 #pragma unroll
     for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
         size_t i = base + k * DP_BLOCK + threadIdx.x;
         if (i < n) {
-            float z = scaled_depth(raw, mask, i, inv_scale, mode);
+            float z = batch_pixel_depth(raw, masks, n, b, stacked, i, inv_scale, mask_mode);
             c += !(z <= 0.f || z > zmax);
         }
     }
@@ -261,8 +273,6 @@ void k_emit_batch(const uint16_t* __restrict__ raw0, const int* __restrict__ fra
     const size_t frame = frame_of ? (size_t)frame_of[b] : 0;
     const uint16_t* __restrict__ raw = raw0 + frame * n;
     const uint8_t* __restrict__ bgr = bgr0 ? bgr0 + frame * n * 3 : nullptr;
-    const uint8_t* __restrict__ mask = stacked ? masks + (size_t)b * n : masks;
-    const int mode = stacked ? mask_mode : TDV_MASK_LABEL_BASE + b + 1;
     const size_t base = (size_t)blockIdx.x * DP_PX_PER_BLOCK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ int wcnt[DP_PX_PER_THREAD][DP_BLOCK / 64];
@@ -271,7 +281,7 @@ void k_emit_batch(const uint16_t* __restrict__ raw0, const int* __restrict__ fra
     for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
         size_t i = base + k * DP_BLOCK + threadIdx.x;
         float z = 0.f;
-        if (i < n) z = scaled_depth(raw, mask, i, inv_scale, mode);
+        if (i < n) z = batch_pixel_depth(raw, masks, n, b, stacked, i, inv_scale, mask_mode);
         ok[k] = (i < n) && !(z <= 0.f || z > zmax);
         zs[k] = z;
         unsigned long long bal = __ballot(ok[k]);
@@ -613,7 +623,7 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
     int raw_lo = 1, raw_hi = 0;
-    const bool vec = batch_vectorisable(d_raw, d_masks, n) && depth_valid_range(inv_scale, zmax, &raw_lo, &raw_hi);
+    const bool vec = stacked != 2 && batch_vectorisable(d_raw, d_masks, n) && depth_valid_range(inv_scale, zmax, &raw_lo, &raw_hi);
     const int blocks = vec ? (int)((n + DB_TILE - 1) / DB_TILE) : (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);   // tiles resp. workgroups per instance
     int *counts, *offsets, *d_total, *d_inst;
     TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &counts));
@@ -671,6 +681,77 @@ int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_
                                                                           fx, fy, cx, cy, zmax, d_offsets, d_xyz, d_rgb);
     }
     TDV_CHECK_LAUNCH(ctx);
+    return TDV_OK;
+}
+
+// cv::resize(mask, resized, depth.size(), 0, 0, cv::INTER_NEAREST) of src/pipeline.cpp:38-41 for B stacked masks: a gather
+// through the two index tables of OpenCV's resizeNN (imgproc/src/resize.cpp: x_ofs[x] = min(cvFloor(x * ifx), sw - 1) with
+// ifx = 1. / ((double)dw / sw), likewise for rows), which the host computes in double exactly as OpenCV does.
+__global__ __launch_bounds__(256)
+void k_mask_resize_nn(const uint8_t* __restrict__ src, int sw, int sh, const int* __restrict__ x_ofs, const int* __restrict__ y_ofs,
+                      int dw, int dh, uint8_t* __restrict__ dst) {
+    const size_t b = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)dw * dh) return;
+    const int y = (int)(i / dw), x = (int)(i - (size_t)y * dw);
+    dst[b * (size_t)dw * dh + i] = src[b * (size_t)sw * sh + (size_t)y_ofs[y] * sw + x_ofs[x]];
+}
+
+void resize_nn_tables(int sw, int sh, int dw, int dh, int* x_ofs, int* y_ofs) {
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double ifx = 1. / inv_scale_x, ify = 1. / inv_scale_y;
+    for (int x = 0; x < dw; ++x) x_ofs[x] = std::min((int)std::floor(x * ifx), sw - 1);
+    for (int y = 0; y < dh; ++y) y_ofs[y] = std::min((int)std::floor(y * ify), sh - 1);
+}
+
+int mask_resize_nearest_dev(tdv_ctx* ctx, const uint8_t* d_src, int n_masks, int sw, int sh, int dw, int dh, uint8_t* d_dst) {
+    if (!ctx || n_masks < 0 || sw <= 0 || sh <= 0 || dw < 0 || dh < 0) return TDV_ERR_BAD_ARG;
+    if (n_masks == 0 || (size_t)dw * dh == 0) return TDV_OK;
+    if (!d_src || !d_dst) return TDV_ERR_BAD_ARG;
+    std::vector<int> tab((size_t)dw + dh);
+    resize_nn_tables(sw, sh, dw, dh, tab.data(), tab.data() + dw);
+    int* d_tab;
+    TDV_TRY(ws_alloc(ctx, tab.size(), &d_tab));
+    TDV_HIP(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    const size_t npx = (size_t)dw * dh;
+    k_mask_resize_nn<<<dim3((unsigned)((npx + 255) / 256), n_masks), 256, 0, ctx->stream>>>(d_src, sw, sh, d_tab, d_tab + dw, dw, dh, d_dst);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // tab is a host temporary
+    return TDV_OK;
+}
+
+// Why an instance came out of the batched count pass with no point: does its masked depth image hold ANY non-zero value
+// (cv::countNonZero(scaled_depth) of src/pipeline.cpp:57)?  If not the reference stops at :57-60 ("empty depth after
+// masking"), else at :86-89 ("empty point cloud": every masked pixel lies beyond the z clip).  Run for the empty instances
+// only - rare - so the count pass itself stays as it is.
+__global__ __launch_bounds__(DP_BLOCK)
+void k_masked_nonzero_any(const uint16_t* __restrict__ raw0, const int* __restrict__ frame_of, const uint8_t* __restrict__ masks, size_t n, int layout,
+                          float inv_scale, int mask_mode, const int* __restrict__ inst, int* __restrict__ flags) {
+    const int b = inst[blockIdx.y];
+    const uint16_t* __restrict__ raw = raw0 + (frame_of ? (size_t)frame_of[b] : 0) * n;
+    bool any = false;
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        const size_t i = (size_t)blockIdx.x * DP_PX_PER_BLOCK + k * DP_BLOCK + threadIdx.x;
+        if (i < n) any |= batch_pixel_depth(raw, masks, n, b, layout, i, inv_scale, mask_mode) != 0.f;
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[blockIdx.y], 1);
+}
+
+int depth_batch_nonzero_any(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, int layout, int w, int h, float scale,
+                            int mask_mode, const int* h_inst, int n_list, int* h_flags) {
+    if (n_list <= 0) return TDV_OK;
+    const size_t n = (size_t)w * h;
+    const float inv_scale = (float)(1.0 / (double)scale);
+    int *d_inst, *d_flags;
+    TDV_TRY(ws_alloc(ctx, (size_t)n_list, &d_inst));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_list, &d_flags));
+    TDV_HIP(ctx, hipMemcpyAsync(d_inst, h_inst, (size_t)n_list * 4, hipMemcpyHostToDevice, ctx->stream));
+    TDV_HIP(ctx, hipMemsetAsync(d_flags, 0, (size_t)n_list * 4, ctx->stream));
+    const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
+    k_masked_nonzero_any<<<dim3(blocks, n_list), DP_BLOCK, 0, ctx->stream>>>(d_raw, d_frame_of, d_masks, n, layout, inv_scale, mask_mode, d_inst, d_flags);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_HIP(ctx, hipMemcpyAsync(h_flags, d_flags, (size_t)n_list * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TDV_OK;
 }
 

@@ -162,6 +162,11 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d
 int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, const uint8_t* d_bgr, int n_inst, int stacked,
                               int w, int h, float scale, int mask_mode, float fx, float fy, float cx, float cy, float zmax,
                               const int* d_offsets, float* d_xyz, float* d_rgb);
+// `stacked` above: 1 = one u8 mask per instance, 0 = one u8 label image (label = instance + 1), 2 = one u16 label image
+int mask_resize_nearest_dev(tdv_ctx* ctx, const uint8_t* d_src, int n_masks, int sw, int sh, int dw, int dh, uint8_t* d_dst);
+void resize_nn_tables(int sw, int sh, int dw, int dh, int* x_ofs, int* y_ofs);
+int depth_batch_nonzero_any(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_frame_of, const uint8_t* d_masks, int layout, int w, int h, float scale,
+                            int mask_mode, const int* h_inst, int n_list, int* h_flags);
 int estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* d_normals, int* d_knn);
 int compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
                      float* d_desc, int* d_nbr, int* d_nbr_cnt);

@@ -425,6 +425,12 @@ struct VoxelKeyHash {  // the reference's combiner (registration.cpp:20-27)
     }
 };
 
+// The emulation below is tied to libstdc++'s <bits/hashtable.h> (it instantiates the library's own _Prime_rehash_policy):
+// with any other standard library the real std::unordered_map is used instead (the TDV_VOXEL_REAL_MAP path), which is
+// that library's order by construction.  tests/test_gpu_voxel.py holds the emulation against the real container, so a
+// toolchain bump that changes the node-list manipulation is caught.
+#ifdef __GLIBCXX__
+#define TDV_HAVE_LIBSTDCXX_EMULATION 1
 // Iteration order of a libstdc++ std::unordered_map (unique keys, std::__detail::_Mod_range_hashing, the library's own
 // _Prime_rehash_policy object) after inserting DISTINCT keys in a given sequence — the same node-list manipulation as
 // _Hashtable::_M_insert_unique_node / _M_insert_bucket_begin / _M_rehash_aux(unique) of <bits/hashtable.h>, on index
@@ -478,6 +484,9 @@ private:
     int head_ = NONE;
     std::__detail::_Prime_rehash_policy policy_;
 };
+#else
+#define TDV_HAVE_LIBSTDCXX_EMULATION 0
+#endif
 }  // namespace
 
 // exclusive scan of n ints on the ctx stream; *d_total receives the sum (device pointer)
@@ -590,7 +599,7 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     int* order_pinned = reinterpret_cast<int*>(ctx->pin + pin_order_off);
     TDV_HIP(ctx, hipMemcpyAsync(ctx->pin, d_leaders, (size_t)v * sizeof(int4), hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
-    const bool real_map = getenv("TDV_VOXEL_REAL_MAP") != nullptr;   // A/B knob: a real std::unordered_map instead of the emulation
+    const bool real_map = !TDV_HAVE_LIBSTDCXX_EMULATION || getenv("TDV_VOXEL_REAL_MAP") != nullptr;   // A/B knob: a real std::unordered_map instead of the emulation
     const auto t_host0 = std::chrono::steady_clock::now();
     int n_first = 0;
     struct { int* p; int* n; void push_back(int x) { p[(*n)++] = x; } } order_first{order_pinned, &n_first};
@@ -607,10 +616,12 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
         }
         for (auto& kv : grid) order_first.push_back(kv.second);
     } else {
+#if TDV_HAVE_LIBSTDCXX_EMULATION
         LibstdcxxInsertionOrder order((size_t)v);
         VoxelKeyHash hasher;
         for (int r = 0; r < v; ++r) order.insert(hasher(VoxelKey{leaders[r].x, leaders[r].y, leaders[r].z}));
         order.for_each([&](int r) { order_first.push_back(leaders[r].w); });
+#endif
     }
     if (getenv("TDV_DEBUG")) fprintf(stderr, "[tdv] voxel reference order: %d leaders replayed in %.3f ms (%s)\n", v,
                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), real_map ? "std::unordered_map" : "emulation");

@@ -143,7 +143,7 @@ int tdv_depth_to_cloud(tdv_ctx* ctx, const uint16_t* raw, const uint8_t* mask, c
                        float* out_xyz, float* out_rgb, int capacity, int* n_out);
 
 /* All instances of a scene in two launches: n_instances masks — stacked u8 images
- * (mask_format 0, mask_mode as above) or ONE u8 label image with label b+1 for instance b (mask_format 1; one frame
+ * (mask_format 0, mask_mode as above), ONE u8 label image with label b+1 for instance b (mask_format 1, <= 255 instances) or ONE u16 label image, same rule (mask_format 2, <= 65535 instances; label images: one frame
  * only) — give n_instances clouds stored back to back, each in row-major pixel order.
  * Frames: d_raw (and d_bgr) hold n_frames images back to back (n_frames <= 1: one frame shared by every instance, the
  * reference's case, src/pipeline.cpp:321-327); instance b reads frame h_frame_of_instance[b] (host array), or, when that
@@ -266,8 +266,9 @@ int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rg
  *   icp_distance_factor) -> refined transform.
  * All pointers are device pointers; d_masks holds n_instances full-frame uint8 masks back to back;
  * the model (points, normals, FPFH) is what Pipeline::run prepares once (src/pipeline.cpp:291-294);
- * results is a HOST array of n_instances entries.  Instances whose mask leaves no depth / no points
- * get status 1 / 2 (the reference returns nullopt there, src/pipeline.cpp:57-60, :86-89).
+ * results is a HOST array of n_instances entries.  An instance whose masked depth image holds no non-zero value gets
+ * status 1 (the reference returns nullopt at src/pipeline.cpp:57-60, "empty depth after masking"); one that has depth but
+ * no pixel inside 0 < z <= zmax gets status 2 (:86-89, "empty point cloud").
  * voxel_order: TDV_VOXEL_ORDER_REFERENCE gives, per instance, exactly what the chain of host-buffer operators (and
  * the reference's processInstance) gives — RANSAC's mt19937 index stream picks points by position, so the pose depends
  * on the order of the downsampled cloud; TDV_VOXEL_ORDER_FIRST skips the host replay of the reference's container
@@ -275,7 +276,8 @@ int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rg
  * The RANSAC index stream is seeded per instance exactly as the reference does (mt19937(42) restarted for every
  * ransacRegistration call).  Frames: as tdv_depth_to_cloud_batch_dev (n_frames, frame_of_instance).
  * The call spreads the instances over several lanes (the caller's thread plus helper threads, each with its own stream
- * and workspace owned by the ctx): 6 in the reference's voxel order, 3 otherwise; TDV_BATCH_LANES=n overrides. */
+ * and workspace owned by the ctx): 12 in the reference's voxel order, 3 otherwise, never more than the host has hardware
+ * threads; TDV_BATCH_LANES=n overrides (at most 16). */
 typedef struct tdv_batch_params {
     int width, height;
     float scale_to_meters;      /* depth.scale_to_meters      (include/pipeline_config.hpp:18) */
@@ -293,6 +295,11 @@ typedef struct tdv_batch_params {
     int voxel_order;            /* TDV_VOXEL_ORDER_FIRST / TDV_VOXEL_ORDER_REFERENCE                */
     int n_frames;               /* depth frames stored back to back at d_raw_depth (0 or 1: one)    */
     const int* frame_of_instance; /* HOST array [n_instances] or NULL (b * n_frames / n_instances)   */
+    int mask_format;            /* 0: n_instances stacked u8 masks (mask_mode applies); 1: ONE u8 label image, instance b keeps
+                                   the pixels equal to b + 1 (<= 255 instances); 2: ONE u16 label image, same rule (<= 65535
+                                   instances).  Label images need n_frames <= 1.  SURVEY.md 8f N2                          */
+    int mask_width, mask_height; /* size of the masks when it differs from the frame (0: the frame's): they are resized with
+                                   nearest neighbour first, as cv::resize(..., INTER_NEAREST) in src/pipeline.cpp:38-41   */
 } tdv_batch_params;
 
 typedef struct tdv_instance_result {
@@ -305,6 +312,14 @@ typedef struct tdv_instance_result {
     int n_voxels;           /* after voxelDownsample */
     int status;             /* 0 ok, 1 empty depth after masking, 2 empty cloud */
 } tdv_instance_result;
+
+/* cv::resize(mask, out, dsize, 0, 0, cv::INTER_NEAREST) (src/pipeline.cpp:38-41) for n_masks u8 images stored back to back:
+ * out(y, x) = in(min(floor(y * ify), sh - 1), min(floor(x * ifx), sw - 1)), ifx = 1 / ((double)dw / sw) in double, as OpenCV's
+ * resizeNN computes its index tables.  Host buffers; the _dev form takes device pointers. */
+int tdv_mask_resize_nearest(tdv_ctx* ctx, const uint8_t* masks, int n_masks, int src_width, int src_height,
+                            int dst_width, int dst_height, uint8_t* out);
+int tdv_mask_resize_nearest_dev(tdv_ctx* ctx, const uint8_t* d_masks, int n_masks, int src_width, int src_height,
+                                int dst_width, int dst_height, uint8_t* d_out);
 
 int tdv_register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw_depth, const uint8_t* d_bgr /* may be NULL */,
                            const uint8_t* d_masks, int n_instances, const tdv_batch_params* params,

@@ -130,6 +130,24 @@ void orc_depth_preprocess(const uint16_t* raw, const uint8_t* mask, int width, i
     }
 }
 // pipeline.cpp:57 cv::countNonZero
+// cv::resize(mask, resized_mask, depth.size(), 0, 0, cv::INTER_NEAREST), /root/reference/src/pipeline.cpp:38-41.  OpenCV is an
+// un-vendored, un-pinned dependency (CMakeLists.txt:26); restated from its published resizeNN (modules/imgproc/src/resize.cpp,
+// 4.x): resize() passes inv_scale_x = (double)dsize.width / ssize.width, resizeNN computes ifx = 1. / inv_scale_x and
+// x_ofs[x] = min(cvFloor(x * ifx), ssize.width - 1); rows likewise with sy = min(cvFloor(y * ify), ssize.height - 1).
+// (INTER_NEAREST, not INTER_NEAREST_EXACT: no half-pixel centre.)  Integer index arithmetic on a double product; pure-integer
+// form floor(x * sw / dw) is the cross-check in tests/test_oracle_golden.py wherever the double product is exact.
+void orc_mask_resize_nearest(const uint8_t* src, int sw, int sh, int dw, int dh, uint8_t* dst) {
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double ifx = 1. / inv_scale_x, ify = 1. / inv_scale_y;
+    for (int y = 0; y < dh; ++y) {
+        const int sy = std::min((int)std::floor(y * ify), sh - 1);
+        for (int x = 0; x < dw; ++x) {
+            const int sx = std::min((int)std::floor(x * ifx), sw - 1);
+            dst[(size_t)y * dw + x] = src[(size_t)sy * sw + sx];
+        }
+    }
+}
+
 int orc_count_nonzero(const float* depth, int n) { int c = 0; for (int i = 0; i < n; ++i) c += depth[i] != 0.f; return c; }
 
 // pipeline.cpp:68-83.  bgr may be NULL (rgb.empty()).  Returns the number of points.

@@ -110,6 +110,14 @@ def depth_preprocess(raw, mask, scale):
     return out
 
 
+def mask_resize_nearest(mask, dst_width, dst_height):
+    m = np.ascontiguousarray(mask, np.uint8)
+    sh, sw = m.shape
+    out = np.empty((dst_height, dst_width), np.uint8)
+    lib().orc_mask_resize_nearest(_p(m), sw, sh, dst_width, dst_height, _p(out))
+    return out
+
+
 def count_nonzero(depth):
     d = _f32(depth)
     return lib().orc_count_nonzero(_p(d), int(d.size))

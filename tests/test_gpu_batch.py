@@ -79,7 +79,7 @@ def test_batch_empty_mask(ctx, tdv, synth, orc):
     d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)  # keep alive across the call
     d_masks = torch.from_numpy(masks).to(dev)
     res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), 2, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), 3000)
-    assert res[0]["status"] == 2 and res[0]["n_points"] == 0 and np.array_equal(res[0]["T"], np.eye(4, dtype=np.float32))
+    assert res[0]["status"] == 1 and res[0]["n_points"] == 0 and np.array_equal(res[0]["T"], np.eye(4, dtype=np.float32))   # empty depth after masking (pipeline.cpp:57-60)
     assert res[1]["status"] == 0 and res[1]["n_voxels"] > 100
 
 
@@ -229,3 +229,78 @@ def test_model_prep_small_clouds(ctx, tdv, synth, n, voxel, k):
     en = ctx.estimate_normals(ex, k)
     assert d_mn[:nm].cpu().numpy().tobytes() == en.tobytes()
     assert d_mf[:nm].cpu().numpy().tobytes() == ctx.compute_fpfh(ex, en, voxel * 5.0).tobytes()
+
+
+def test_batch_status_1_vs_2(ctx, tdv, synth, orc):
+    """src/pipeline.cpp:57-60 vs :86-89: an instance whose masked depth holds no non-zero value ends with status 1 ("empty
+    depth after masking"); one that has depth under its mask but nothing inside 0 < z <= zmax ends with status 2 ("empty
+    point cloud").  The oracle's countNonZero / unproject on the same inputs draw the same line."""
+    depth, masks, intr = _scene(synth, orc, n_inst=1)
+    h, w = depth.shape
+    far = depth.copy(); far[:40, :40] = 60000                        # 60 m: beyond zmax = 1.5
+    m_empty = np.zeros((h, w), np.uint8)                             # masks everything away
+    m_zero_depth = np.zeros((h, w), np.uint8); m_zero_depth[h - 8:, w - 8:] = 255   # keeps only pixels whose raw depth is 0
+    assert (far[h - 8:, w - 8:] == 0).all()
+    m_far = np.zeros((h, w), np.uint8); m_far[:40, :40] = 255         # keeps only pixels beyond the clip
+    m_weak = np.where(masks[0] > 0, 10, 0).astype(np.uint8)          # mask value 10 is not > 10: everything rejected
+    allm = np.stack([m_empty, m_zero_depth, m_far, m_weak, masks[0]])
+    want = []
+    for m in allm:
+        sd = orc.depth_preprocess(far, m, 1000.0)
+        if orc.count_nonzero(sd) == 0: want.append(1)
+        elif len(orc.unproject(sd, None, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 1.5)[0]) == 0: want.append(2)
+        else: want.append(0)
+    assert want == [1, 1, 2, 1, 0]
+    dev = torch.device("cuda", 0)
+    model, nrm = synth.sample_object(3000, 7)
+    d_mx = torch.from_numpy(model).to(dev); d_mn = torch.from_numpy(nrm).to(dev)
+    d_mf = torch.from_numpy(synth.random_features(3000, 1)).to(dev)
+    prm = tdv.batch_params(voxel_size=0.006, ransac_max_iterations=500, icp_max_iterations=5, **intr)
+    d_depth = torch.from_numpy(far.view(np.int16)).to(dev)
+    d_masks = torch.from_numpy(allm).to(dev)
+    res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), len(allm), prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), 3000)
+    assert [r["status"] for r in res] == want
+    assert all(r["n_points"] == 0 and np.array_equal(r["T"], np.eye(4, dtype=np.float32)) for r in res[:4])
+
+
+def test_mask_resize_nearest_matches_oracle(ctx, orc):
+    """cv::resize(mask, ..., INTER_NEAREST) of src/pipeline.cpp:38-41: tdv_mask_resize_nearest vs the oracle's restatement of
+    OpenCV's resizeNN, up- and down-scaling, non-integer ratios, 1-pixel sources, several masks per call."""
+    rng = np.random.default_rng(11)
+    for (sh, sw), (dh, dw) in [((480, 640), (720, 1280)), ((720, 1280), (480, 640)), ((37, 53), (720, 1280)), ((1, 1), (9, 7)),
+                               ((200, 300), (200, 300)), ((719, 1279), (720, 1280)), ((3, 1000), (97, 131))]:
+        m = rng.integers(0, 256, (3, sh, sw)).astype(np.uint8)
+        got = ctx.mask_resize_nearest(m, dw, dh)
+        for b in range(3):
+            assert got[b].tobytes() == orc.mask_resize_nearest(m[b], dw, dh).tobytes(), ((sh, sw), (dh, dw))
+
+
+def test_batch_resizes_mismatched_masks_and_takes_u16_labels(ctx, tdv, synth, orc):
+    """Masks of another size than the frame are resized first (pipeline.cpp:38-41): the batch on half-size masks equals the
+    batch on the oracle-resized full-size masks; a u16 label image (mask_format 2) equals the stacked masks it encodes."""
+    depth, masks, intr = _scene(synth, orc, n_inst=3)
+    h, w = depth.shape
+    small = masks[:, ::2, ::2].copy()                                  # 240 x 320 masks for a 480 x 640 frame
+    full = np.stack([orc.mask_resize_nearest(m, w, h) for m in small])
+    label = np.zeros((h, w), np.uint16)
+    for b in range(3):
+        label[(full[b] > 10) & (label == 0)] = b + 1
+    stacked_from_label = np.stack([np.where(label == b + 1, 255, 0).astype(np.uint8) for b in range(3)])
+    dev = torch.device("cuda", 0)
+    model, nrm = synth.sample_object(3000, 7)
+    d_mx = torch.from_numpy(model).to(dev); d_mn = torch.from_numpy(nrm).to(dev)
+    d_mf = torch.from_numpy(synth.random_features(3000, 1)).to(dev)
+    d_depth = torch.from_numpy(depth.view(np.int16)).to(dev)
+    common = dict(voxel_size=0.006, ransac_max_iterations=800, icp_max_iterations=8, **intr)
+
+    def run(m, **kw):
+        d_m = torch.from_numpy(m).to(dev)
+        return ctx.register_batch_dev(d_depth.data_ptr(), None, d_m.data_ptr(), 3, tdv.batch_params(**common, **kw), d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), 3000)
+
+    def same(a, b):
+        return all(x["status"] == y["status"] == 0 and x["n_points"] == y["n_points"] > 500 and x["n_voxels"] == y["n_voxels"] and
+                   x["T"].tobytes() == y["T"].tobytes() and x["coarse_inliers"] == y["coarse_inliers"] for x, y in zip(a, b))
+    assert same(run(small, mask_width=w // 2, mask_height=h // 2), run(full))
+    assert same(run(label.view(np.int16), mask_format=2), run(stacked_from_label))
+    with pytest.raises(tdv.TdvError):
+        run(label.view(np.int16), mask_format=2, mask_width=w // 2, mask_height=h // 2)

@@ -1,9 +1,12 @@
 #!/bin/bash
-# Here (not on the GPU box): copy what tools/run_profiles.sh left under gpurun_out/r2prof into profiles/r2 and fold the PMC
+# Here (not on the GPU box): copy what tools/run_profiles.sh left under gpurun_out/<round>prof into profiles/<round> (TDV_ROUND, default r3) and fold the PMC
 # passes.  gpurun merges new files into old directories, so the newest file of each pass is taken.
-set -e
+set -eu
 cd "$(dirname "$0")/.."
-O=gpurun_out/r2prof; P=profiles/r2
+ROUND="${TDV_ROUND:-r3}"
+O="gpurun_out/${ROUND}prof"; P="profiles/${ROUND}"
+[ -d "$O" ] || { echo "nothing under $O" >&2; exit 1; }
+mkdir -p "$P"
 nf() { ls -t $O/$1/runc/*$2 | head -1; }
 cp $O/bench.json $O/bench_under_rocprof.json $O/bench_ops.jsonl $O/bench_batch_c4_256.jsonl $P/
 cp $(nf kt_bench kernel_stats.csv) $P/kernel_stats_bench.csv

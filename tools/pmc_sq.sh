@@ -1,8 +1,11 @@
 #!/bin/bash
 # GPU box: SQ counters of one python tool, per kernel (own pass, no tracing combined).  usage: tools/pmc_sq.sh <tag> <script.py> [args...]
-tag=$1; shift
-out=$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag
-rm -rf $out
+set -u
+: "${GRAFT_REPO_ROOT:?must be set (gpurun exports it on the GPU box)}"
+tag="${1:?usage: tools/pmc_sq.sh <tag> <script.py> [args...]}"; shift
+[ -n "$tag" ] && [ $# -ge 1 ] || { echo "usage: tools/pmc_sq.sh <tag> <script.py> [args...]" >&2; exit 2; }
+out="$GRAFT_REPO_ROOT/gpurun_out/pmc_$tag"
+rm -rf "$out"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/"$@" > $out.stdout 2> $out.stderr)
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'

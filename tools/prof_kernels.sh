@@ -1,8 +1,11 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel trace of a python tool, top kernels printed.  usage: tools/prof_kernels.sh <tag> <script.py> [args...]
-tag=$1; shift
-out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
-rm -rf $out
+set -u
+: "${GRAFT_REPO_ROOT:?must be set (gpurun exports it on the GPU box)}"
+tag="${1:?usage: tools/prof_kernels.sh <tag> <script.py> [args...]}"; shift
+[ -n "$tag" ] && [ $# -ge 1 ] || { echo "usage: tools/prof_kernels.sh <tag> <script.py> [args...]" >&2; exit 2; }
+out="$GRAFT_REPO_ROOT/gpurun_out/prof_$tag"
+rm -rf "$out"
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/"$@" > $out.stdout 2> $out.stderr)
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'

@@ -1,9 +1,12 @@
 #!/bin/bash
 # One gpurun call: the bench line, the kernel trace of the same command, the PMC passes (FETCH_SIZE, WRITE_SIZE, SQ) for
 # bench.py and for tools/bench_ops.py, and the full C4 batch.  Programs are started directly after `rocprofv3 ... --`.
-set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2prof
-rm -rf $O; mkdir -p $O
+set -eu
+: "${GRAFT_REPO_ROOT:?must be set (gpurun exports it on the GPU box)}"
+ROUND="${TDV_ROUND:-r3}"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/${ROUND}prof"
+[ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }
+rm -rf "$O"; mkdir -p "$O"
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-operators"
