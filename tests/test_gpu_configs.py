@@ -70,19 +70,22 @@ def test_c2_icp_50k_vs_10k(ctx, orc, synth):
 
 # ------------------------------------------------------------------------------------------------------------ C3
 def _score_f32(src, q, T, thr):
-    """Inlier count of one hypothesis as registration.cpp:270-279 evaluates it, in float32 with the same expression
-    tree: R*p + t with Eigen's 3-term products (c0 + (c1 + c2))... evaluated row by row: r0*x + r1*y + r2*z as
-    ((r0*x + r1*y) + r2*z) is NOT the reference's order, so use the column form p.x*R.col(0) + p.y*R.col(1) + ..."""
+    """Inlier count of one hypothesis exactly as the oracle (oracle/oracle.cpp orc_ransac, following registration.cpp:270-279) and
+    the kernels (csrc/ransac.hip) evaluate it, in float32 numpy with the same expression tree: every 3-term sum as
+    c0 + (c1 + c2) (Eigen's fixed-size redux; oracle/small_linalg.hpp sum3), then + t, the squared norm of the difference
+    as d0*d0 + (d1*d1 + d2*d2), its float32 sqrt, strict < threshold.  numpy float32 arithmetic is IEEE round-to-nearest per
+    operation, so this is an independent evaluation of the same roundings: the counts must be EQUAL, not close."""
     R = T[:3, :3].astype(np.float32); t = T[:3, 3].astype(np.float32)
     x, y, z = src[:, 0], src[:, 1], src[:, 2]
     out = np.empty((len(src), 3), np.float32)
     for r in range(3):
-        # Eigen evaluates (R * p)(r) = R(r,0)*p0 + R(r,1)*p1 + R(r,2)*p2 left to right for a 3x3 * 3x1 lazy product
-        out[:, r] = ((R[r, 0] * x + R[r, 1] * y).astype(np.float32) + R[r, 2] * z).astype(np.float32) + t[r]
-    d = (out - q).astype(np.float32)
-    n2 = (d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])).astype(np.float32)
-    err = np.sqrt(n2).astype(np.float32)
-    return int((err < np.float32(thr)).sum()), err
+        out[:, r] = (R[r, 0] * x + (R[r, 1] * y + R[r, 2] * z)) + t[r]
+    assert out.dtype == np.float32
+    d = out - q
+    n2 = d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])
+    err = np.sqrt(n2)
+    assert err.dtype == np.float32
+    return int((err < np.float32(thr)).sum())
 
 
 def test_c3_ransac_50k_hypotheses_at_100k(ctx, orc, synth):
@@ -107,19 +110,42 @@ def test_c3_ransac_50k_hypotheses_at_100k(ctx, orc, synth):
     assert np.array_equal(tr == -1, skipped)
     # the winner is the first iteration with the highest count (strict >, registration.cpp:284)
     assert a.best_iteration == int(np.argmax(tr)) and a.inliers == int(tr.max()) and a.inliers > 0.3 * ns
-    # sampled hypotheses: transform from the oracle's 3-point Kabsch, count from a float32 numpy evaluation; points within
-    # 1e-6 m of the threshold may fall either way in numpy's evaluation order, so the counts must agree up to those
+    # sampled hypotheses: transform from the oracle's 3-point Kabsch, count from the float32 numpy evaluation in the oracle's
+    # expression order - equality, no slack
     thr = np.float32(voxel * 1.5)
-    for it in [int(a.best_iteration)] + [int(i) for i in np.nonzero(~skipped)[0][[0, 17, 4242, -1]]]:
+    for it in [int(a.best_iteration)] + [int(i) for i in np.nonzero(~skipped)[0][[0, 17, 4242, 31337, -1]]]:
         T = orc.hypothesis_from_pairs(src[tri[it].astype(np.int64)], tgt[corr[tri[it].astype(np.int64)]])
-        cnt, err = _score_f32(src, tgt[corr], T, thr)
-        slack = int((np.abs(err - thr) < 1e-6).sum())
-        assert abs(cnt - int(tr[it])) <= slack, (it, cnt, int(tr[it]), slack)
+        assert _score_f32(src, tgt[corr], T, thr) == int(tr[it]), it
     if a.best_iteration >= 0:
         T = orc.hypothesis_from_pairs(src[tri[a.best_iteration].astype(np.int64)], tgt[corr[tri[a.best_iteration].astype(np.int64)]])
         assert T.tobytes() == a.transformation.tobytes()                 # device SVD == CPU restatement, bit for bit
     ang, _ = synth.pose_error(a.transformation, T_gt)
     assert ang < 2e-2
+
+
+def test_headline_size_counts_equal_numpy_float32(ctx, orc, synth):
+    """The same independent check at the headline size: 200,000 points, 5 hypotheses of a traced call (every test evaluated)
+    and the winner of an untraced call (FMA pass + exact bail-out): inlier counts equal the float32 numpy evaluation."""
+    ns = nt = 200000
+    tgt, _ = synth.sample_object(nt, 42)
+    src, T_gt = synth.make_scene(ns, 42)
+    rng = np.random.default_rng(9)
+    corr = rng.integers(0, nt, ns).astype(np.int32)
+    good = np.nonzero(rng.random(ns) < 0.5)[0]
+    corr[good] = ctx.icp_correspondences(src[good], tgt, T_gt, 1.0)["corr"]
+    voxel = float(np.float32(synth.mean_spacing(ns)))
+    thr = np.float32(np.float32(voxel) * np.float32(1.5))
+    a = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=2000, confidence=2.0, trace=True)
+    tri = orc.sample_triples(ns, 2000)
+    ok = np.nonzero(a.trace_inliers >= 0)[0]
+    for it in [int(a.best_iteration)] + [int(i) for i in ok[[0, 3, 777, -1]]]:
+        T = orc.hypothesis_from_pairs(src[tri[it].astype(np.int64)], tgt[corr[tri[it].astype(np.int64)]])
+        assert _score_f32(src, tgt[corr], T, thr) == int(a.trace_inliers[it]), it
+    b = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=40000, confidence=2.0)       # bail-out path, no trace
+    trib = orc.sample_triples(ns, 40000)
+    T = orc.hypothesis_from_pairs(src[trib[b.best_iteration].astype(np.int64)], tgt[corr[trib[b.best_iteration].astype(np.int64)]])
+    assert T.tobytes() == b.transformation.tobytes()
+    assert _score_f32(src, tgt[corr], T, thr) == int(b.inliers)
 
 
 def test_c3_features_at_100k_register(ctx, tdv, synth):
