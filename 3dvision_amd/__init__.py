@@ -42,7 +42,7 @@ DEPTH_BATCH_MASK_PASSES = 1   # the B masks cross HBM once in tdv_depth_to_cloud
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [
-    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_last_icp_search", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_last_icp_search", "tdv_ctx_workspace_bytes", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
@@ -109,6 +109,7 @@ def lib():
             l.tdv_last_error.restype = C.c_char_p
             l.tdv_version.restype = C.c_char_p
             l.tdv_ctx_get_stream.restype = C.c_void_p
+            l.tdv_ctx_workspace_bytes.restype = C.c_ulonglong
             l.tdv_ctx_last_ransac_rescore.restype = C.c_double
             l.tdv_ctx_last_ransac_scored.restype = C.c_double
             _lib = l
@@ -219,6 +220,10 @@ class Context:
         """Name of the search the last ICP / correspondence call ran ('brute', 'pruned', 'grid'; 'auto' before any)."""
         v = lib().tdv_ctx_last_icp_search(self._h)
         return {n: k for k, n in self.ICP_SEARCH.items()}[v]
+
+    def workspace_high_water(self):
+        """Bytes of device memory held by this ctx's workspace arenas (its batch lanes' included): the high-water mark so far."""
+        return int(lib().tdv_ctx_workspace_bytes(self._h))
 
     def close(self):
         if self._h:

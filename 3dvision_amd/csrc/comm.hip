@@ -22,7 +22,7 @@ typedef int (*fn_allgather)(const void*, void*, size_t, int, comm_t, hipStream_t
 typedef int (*fn_count)(const comm_t, int*);
 typedef int (*fn_rank)(const comm_t, int*);
 typedef const char* (*fn_errstr)(int);
-constexpr int kNcclChar = 0, kNcclInt32 = 2, kNcclFloat32 = 7;
+constexpr int kNcclChar = 0, kNcclFloat32 = 7;
 
 struct Rccl {
     fn_bcast bcast = nullptr; fn_allgather allgather = nullptr; fn_count count = nullptr; fn_rank rank = nullptr; fn_errstr errstr = nullptr;

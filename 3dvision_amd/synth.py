@@ -235,3 +235,85 @@ def render_depth_torch(points_t, pose, fx, fy, cx, cy, width, height, scale_to_m
     d = torch.where(hit, torch.round(z * scale_to_meters), torch.zeros_like(z)).to(torch.int32)
     depth = torch.where(d > 32767, d - 65536, d).to(torch.int16)   # uint16 bits in an int16 tensor (torch has no uint16 arithmetic)
     return depth.reshape(height, width), (hit.to(torch.uint8) * 255).reshape(height, width)
+
+
+# --------------------------------------------------------------------------------------------------
+# Tray scene: the workload of config C5 (BASELINE.json configs[4]: "1024-instance batch ... 500k-pt scene" per GPU).
+# ONE depth frame shows a tray of small relief parts, one per grid cell, each at its own pose (any spin about the viewing
+# axis, a tilt, a small shift inside its cell); the instances are cut out of the frame by ONE label image (label = instance
+# + 1, uint16: more than 255 instances).  1,024 parts of ~490 pixels each make a scene cloud of ~500k points.  The model is
+# a scan of the same part at the centre of the image, as Pipeline::run prepares it (src/pipeline.cpp:275-294).
+class DiscPart(ReliefPart):
+    """A round relief part (diameter D): the bumps of ReliefPart over a disc, so that it fits its cell at any spin."""
+
+    def __init__(self, seed, D, feature, density=0.16):
+        ReliefPart.__init__(self, seed, L=D, W=D, feature=feature, density=density)
+        self.D = float(D)
+
+    def surface_points(self, step):
+        p = ReliefPart.surface_points(self, step)
+        return p[p[:, 0] ** 2 + p[:, 1] ** 2 <= (self.D / 2) ** 2]
+
+
+def tray_cells(n_instances, width, height, cell_w, cell_h):
+    """Centres (u, v) in pixels of the first n_instances cells of the grid that fills the frame, row by row."""
+    cols, rows = width // cell_w, height // cell_h
+    assert cols * rows >= n_instances, "frame %dx%d holds %d cells of %dx%d, %d wanted" % (width, height, cols * rows, cell_w, cell_h, n_instances)
+    x0 = (width - cols * cell_w) / 2.0; y0 = (height - rows * cell_h) / 2.0
+    b = np.arange(n_instances)
+    return np.stack([x0 + (b % cols + 0.5) * cell_w, y0 + (b // cols + 0.5) * cell_h], 1)
+
+
+def tray_instance_pose(b, centre_uv, fx, fy, cx, cy, distance, tilt_deg, jitter_px, seed=42):
+    """Pose (part frame -> camera frame) of the part in cell b: top towards the camera, any spin, a tilt of up to tilt_deg,
+    its centre within jitter_px of the cell centre, at distance * (1 +- 1 %).  Deterministic in (b, seed)."""
+    rng = _rng(seed * 104729 + b)
+    a = rng.random() * 2 * np.pi
+    tilt = make_transform([np.cos(a), np.sin(a), 0.0], tilt_deg * rng.random(), (0, 0, 0)).astype(np.float64)
+    spin = make_transform([0.0, 0.0, 1.0], 360.0 * rng.random(), (0, 0, 0)).astype(np.float64)
+    z = distance * (1.0 + 0.02 * (rng.random() - 0.5))
+    u = centre_uv[0] + (rng.random() - 0.5) * 2 * jitter_px; v = centre_uv[1] + (rng.random() - 0.5) * 2 * jitter_px
+    shift = np.eye(4); shift[:3, 3] = [(u - cx) * z / fx, (v - cy) * z / fy, z]
+    M0 = make_transform([1.0, 0.0, 0.0], 180.0, (0, 0, 0)).astype(np.float64)
+    return shift @ spin @ tilt @ M0
+
+
+def render_tray(points, poses, fx, fy, cx, cy, width, height, scale_to_meters):
+    """z-buffer splat of the same dense part samples under every pose into ONE frame: uint16 depth, uint16 label image
+    (0 = background, b + 1 = the instance whose surface is nearest at the pixel).  Numpy."""
+    z = np.full(height * width, np.inf); lab = np.zeros(height * width, np.uint16)
+    idx_all, z_all, b_all = [], [], []
+    for b, pose in enumerate(poses):
+        p = points @ pose[:3, :3].T + pose[:3, 3]
+        u = np.round(p[:, 0] / p[:, 2] * fx + cx).astype(np.int64)
+        v = np.round(p[:, 1] / p[:, 2] * fy + cy).astype(np.int64)
+        ok = (u >= 0) & (u < width) & (v >= 0) & (v < height) & (p[:, 2] > 0)
+        idx_all.append(v[ok] * width + u[ok]); z_all.append(p[ok, 2]); b_all.append(np.full(int(ok.sum()), b + 1, np.uint16))
+    idx = np.concatenate(idx_all); pz = np.concatenate(z_all); pb = np.concatenate(b_all)
+    np.minimum.at(z, idx, pz)
+    first = pz == z[idx]                       # the samples that set their pixel's depth; ties between instances: the lowest label
+    order = np.argsort(-pb[first].astype(np.int64), kind="stable")
+    lab[idx[first][order]] = pb[first][order]
+    hit = np.isfinite(z)
+    depth = np.zeros(height * width, np.uint16)
+    depth[hit] = np.round(z[hit] * scale_to_meters).astype(np.uint16)
+    return depth.reshape(height, width), lab.reshape(height, width)
+
+
+def tray_scene(n_instances, width=1280, height=720, f=1500.0, distance=0.45, part_px=25, cell_w=31, cell_h=28, voxel_px=1.2,
+               tilt_deg=12.0, jitter_px=1.0, scale_to_meters=50000.0, seed=3, feature_voxels=3.5):
+    """The C5 workload: dict(depth u16 [H,W], label u16 [H,W], T_gt list (scene -> model), model_depth, model_mask, voxel,
+    intrinsics).  Defaults: 1,025 cells of 31 x 28 px in a 1280 x 720 frame, parts of 25 px diameter (~490 px)."""
+    cx, cy = width / 2.0, height / 2.0
+    px = distance / f
+    voxel = voxel_px * px
+    part = DiscPart(seed, part_px * px, feature_voxels * voxel)
+    dense = part.surface_points(px / 2.5)
+    M = scan_pose(distance)
+    model_depth, model_mask = render_depth(dense, M, f, f, cx, cy, width, height, scale_to_meters)
+    cells = tray_cells(n_instances, width, height, cell_w, cell_h)
+    poses = [tray_instance_pose(b, cells[b], f, f, cx, cy, distance, tilt_deg, jitter_px, seed) for b in range(n_instances)]
+    depth, label = render_tray(dense, poses, f, f, cx, cy, width, height, scale_to_meters)
+    return dict(depth=depth, label=label, T_gt=[M @ np.linalg.inv(S) for S in poses], model_depth=model_depth, model_mask=model_mask,
+                voxel=float(np.float32(voxel)), fx=f, fy=f, cx=cx, cy=cy, width=width, height=height, scale=scale_to_meters,
+                zmax=1.3, bumps=len(part.bumps))

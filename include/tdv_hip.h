@@ -84,6 +84,9 @@ double tdv_ctx_last_ransac_rescore(tdv_ctx* ctx);
 double tdv_ctx_last_ransac_scored(tdv_ctx* ctx);
 /* The search the last tdv_icp* / tdv_icp_correspondences call on this ctx ran (BRUTE, PRUNED or GRID; 0 before any). */
 int tdv_ctx_last_icp_search(tdv_ctx* ctx);
+/* Device memory this ctx holds in its grow-only workspace arenas, its batch lanes' included: the high-water mark of every
+ * call made on it so far (the arena never shrinks; steady state allocates nothing). */
+unsigned long long tdv_ctx_workspace_bytes(tdv_ctx* ctx);
 const char* tdv_status_string(int status);
 /* Text of the last HIP error seen by this ctx ("" if none). */
 const char* tdv_last_error(tdv_ctx* ctx);

@@ -14,7 +14,7 @@ def test_library_is_built_and_exports_the_abi(tdv):
     assert os.path.exists(tdv.LIB_PATH), "run __graft_entry__.build()"
     lib = tdv.lib()
     header = open(os.path.join(ROOT, "include", "tdv_hip.h")).read()
-    declared = sorted(set(re.findall(r"^(?:int|double|void|void\*|const char\*)\s+(tdv_[a-z0-9_]+)\s*\(", header, re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|double|void|void\*|const char\*|unsigned long long)\s+(tdv_[a-z0-9_]+)\s*\(", header, re.M)))
     assert len(declared) >= 30
     for sym in declared:
         assert hasattr(lib, sym), "header declares %s but the library does not export it" % sym
