@@ -217,42 +217,31 @@ void k_ransac_score(const float* __restrict__ hyp, int h_pad, const float* __res
 // so of the chunks; counts are identical to k_ransac_score's (tests/test_gpu_ransac.py holds the two against each other
 // and against the oracle).
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-// Exact bail-out (RansacPlan, below): with plan != nullptr the kernel scores only a part of the points.  phase 1: every
-// hypothesis of the batch over the first plan[0] chunks; phase 2: the hypotheses listed in `list` (plan[1] of them: those
-// that can still beat the best count of the earlier batches) over the remaining chunks.
-__global__ __launch_bounds__(RS_BLOCK)
-void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq2,
-                         int n_pchunks, int pchunks_per_split, float tau, int* __restrict__ counts, unsigned long long* __restrict__ rescored,
-                         const int* __restrict__ plan, const int* __restrict__ list, int phase) {
-    int split = blockIdx.y, hblock = blockIdx.x;
-    const int c_split = plan ? plan[0] : n_pchunks;
-    int n_list = 0;
-    if (phase == 2) {
-        // Few hypothesis blocks are left, and the points reach the scalar cache through the XCD's L2: a workgroup that walks a
-        // point range alone misses on every chunk (measured 1.2 ms for 5 % of the work).  Workgroups are therefore renumbered so
-        // that an XCD (workgroup id mod 8) runs ALL surviving hypothesis blocks of one point range next to each other, as the
-        // full grid does with its 8 hypothesis blocks per XCD and range.
-        n_list = plan[1];
-        const int n_blk = (n_list + RS_BLOCK - 1) / RS_BLOCK;
-        if (n_blk == 0) return;
-        const int id = blockIdx.x + gridDim.x * blockIdx.y, xcd = id & 7, j = id >> 3;
-        split = c_split / pchunks_per_split + (j / n_blk) * 8 + xcd;
-        hblock = j % n_blk;
-    }
-    int c0 = split * pchunks_per_split;
-    int c1 = min(n_pchunks, c0 + pchunks_per_split);
-    const int slot = hblock * RS_BLOCK + threadIdx.x;
-    int base = slot;
-    if (phase == 1) c1 = min(c1, c_split);
-    else if (phase == 2) { c0 = max(c0, c_split); base = slot < n_list ? list[slot] : -1; }
-    if (c0 >= c1) return;                                    // workgroup-uniform
+// Exact bail-out (RansacPlan, below).  One dispatch carries up to two JOBS, decoded from the workgroup id:
+//   job A (ids below g1): a batch's hypotheses, one block of RS_BLOCK per id, over the first plan[0] chunks of the points
+//                         (plan == nullptr: over all of them) cut EVENLY into a.ps ranges - every workgroup of the job has the
+//                         same amount of work, whatever the prefix (the first version cut the whole point range and let the
+//                         workgroups past the prefix exit: 3,648 busy workgroups on 512 slots, an eighth of the last round idle);
+//   job B (the ids after): phase 2 of the PREVIOUS batch - the hypotheses its selection listed (plan[1] of them: those that
+//                         can still beat the best count known) over the chunks its phase 1 left out, in ranges of plan[3]
+//                         chunks (= what a job-A workgroup of that batch walked, so all workgroups of a dispatch cost the same).
+// Phase 2 used to be a dispatch of its own: a few hypothesis blocks on an otherwise idle chip, 45 % of the lane-op peak
+// against 79 % for a full grid (BENCH_r02: 0.66-0.75 overall).  Riding behind the next batch's phase 1 it fills that grid's tail.
+struct ScoreJob {
+    const float* hyp; int* counts; const int* plan; const int* list;
+    int hb;      // hypothesis blocks (A: of the batch; B: upper bound - the real number comes from plan[1])
+    int ps;      // A: point ranges
+};
+// One block of hypotheses (lane = hypothesis `base`, -1: none) over the chunks [c0, c1) of the point pairs; returns the lane's
+// inlier count, adds the chunks the wave scored twice to n_rescored (wave-uniform).
+__device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, const int h_pad, const int base, const float* __restrict__ pq2,
+                                                const int c0, const int c1, const float tau, unsigned& n_rescored) {
     v2f r[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) { const float t = base >= 0 ? hyp[(size_t)e * h_pad + base] : __builtin_nanf(""); r[e] = (v2f){t, t}; }
     const float mid = base >= 0 ? hyp[(size_t)12 * h_pad + base] : tau, half = base >= 0 ? hyp[(size_t)13 * h_pad + base] : 0.f;   // a lane without a hypothesis has no band
     const v2f nmid = {-mid, -mid};
     int cnt = 0;
-    unsigned n_rescored = 0;     // wave-uniform
     for (int c = c0; c < c1; ++c) {
         const float* __restrict__ g = pq2 + (size_t)c * (6 * RS_PCH);  // RS_PCH points = RS_PCH/2 records of 12 floats, wave-uniform
         float v[6 * RS_PCH];
@@ -294,7 +283,49 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
         }
         cnt += cf;
     }
-    if (base >= 0) atomicAdd(&counts[base], cnt);
+    return cnt;
+}
+
+__global__ __launch_bounds__(RS_BLOCK)
+void k_ransac_score_fast(const ScoreJob a, const ScoreJob b, const int g1, const int h_pad, const float* __restrict__ pq2,
+                         const int n_pchunks, const float tau, unsigned long long* __restrict__ rescored) {
+    const int id = blockIdx.x;
+    unsigned n_rescored = 0;     // wave-uniform
+    unsigned chunks = 0;         // chunks this workgroup walked (workgroup-uniform)
+    if (id < g1) {
+        const int hblock = id % a.hb, split = id / a.hb;          // consecutive ids = the hypothesis blocks of one point range: an XCD (id mod 8) keeps 1/8 of them
+        const int c_split = a.plan ? a.plan[0] : n_pchunks;
+        const int per = (c_split + a.ps - 1) / a.ps;
+        const int c0 = split * per, c1 = min(c_split, c0 + per);
+        if (c0 >= c1) return;                                    // workgroup-uniform (ids past hb * ps, a prefix shorter than ps chunks)
+        const int base = hblock * RS_BLOCK + threadIdx.x;
+        const int cnt = score_range_fast(a.hyp, h_pad, base, pq2, c0, c1, tau, n_rescored);
+        atomicAdd(&a.counts[base], cnt);
+        chunks = (unsigned)(c1 - c0);
+    } else {
+        // Few hypothesis blocks are left, and the points reach the scalar cache through the XCD's L2: a workgroup that walks a
+        // point range alone misses on every chunk (measured 1.2 ms for 5 % of the work).  Items (point range, surviving block)
+        // are therefore dealt so that an XCD (workgroup id mod 8) runs ALL surviving blocks of one range next to each other; a
+        // workgroup takes every (job-B workgroups / 8)-th item of its XCD, so any grid of at least 8 workgroups covers any
+        // number of survivors and any prefix.
+        const int n_list = b.plan[1];
+        const int n_blk = (n_list + RS_BLOCK - 1) / RS_BLOCK;
+        if (n_blk == 0) return;
+        const int j0 = id - g1, xcd = j0 & 7, stride = ((int)gridDim.x - g1) >> 3;
+        const int c_split = b.plan[0], per = max(b.plan[3], 1);
+        const int ranges = (n_pchunks - c_split + per - 1) / per;
+        for (int t = j0 >> 3; ; t += stride) {
+            const int split = (t / n_blk) * 8 + xcd, hblock = t % n_blk;
+            if (split >= ranges) break;                              // workgroup-uniform
+            const int c0 = c_split + split * per, c1 = min(n_pchunks, c0 + per);
+            const int slot = hblock * RS_BLOCK + threadIdx.x;
+            const int base = slot < n_list ? b.list[slot] : -1;
+            const int cnt = score_range_fast(b.hyp, h_pad, base, pq2, c0, c1, tau, n_rescored);
+            if (base >= 0) atomicAdd(&b.counts[base], cnt);
+            chunks += (unsigned)(c1 - c0);
+        }
+        if (!chunks) return;
+    }
     // statistics only (tdv_ctx_last_ransac_rescore / _scored): two atomics per workgroup — (wave, chunk) pairs scored, and scored twice
     __shared__ unsigned s_rescored;
     if (threadIdx.x == 0) s_rescored = 0u;
@@ -303,7 +334,7 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_rescored) atomicAdd(rescored, (unsigned long long)s_rescored);
-        atomicAdd(rescored + 1, (unsigned long long)(RS_BLOCK / 64) * (unsigned long long)(c1 - c0));
+        atomicAdd(rescored + 1, (unsigned long long)(RS_BLOCK / 64) * (unsigned long long)chunks);
     }
 }
 
@@ -315,19 +346,50 @@ void k_ransac_score_fast(const float* __restrict__ hyp, int h_pad, const float* 
 // always survives, so the returned transform, inlier count, fitness, rmse and iteration are the reference's.  The running best
 // stays on the device (no host round trip between batches): plan = { chunks in phase 1, survivors, best count so far }.
 // Used only when the caller asked for no per-iteration trace.
-__global__ void k_ransac_plan(int* __restrict__ plan, int ns, int n_pchunks, int drop_permille) {
-    const int best = plan[2];
+// state[0] = best count known so far (a lower bound of the best count of every batch already enqueued: full counts of the
+// batches that are complete, prefix counts of the one whose phase 2 is still to run).  plan = { chunks in phase 1, survivors,
+// largest PREFIX count of this batch, chunks per workgroup } - one plan per batch buffer, the state shared.
+__global__ void k_ransac_plan(int* __restrict__ state, int* __restrict__ plan, int ns, int n_pchunks, int ps, int drop_permille) {
+    const int best = state[0];
     int c_split = n_pchunks;
     const int rest = best - max((int)((long long)best * drop_permille / 1000), 1);   // points left to phase 2: a hypothesis with under that share of the best count in the prefix is dropped
-    if (rest >= ns / 8)                                      // (below an eighth of the points two launches cost more than they save)
+    if (rest >= ns / 8)                                      // (below an eighth of the points a second phase costs more than it saves)
         c_split = min(n_pchunks, (ns - rest + RS_PCH - 1) / RS_PCH);
-    plan[0] = c_split; plan[1] = 0;
+    plan[0] = c_split; plan[1] = 0; plan[2] = 0; plan[3] = (c_split + ps - 1) / ps;
 }
-__global__ void k_ransac_select(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int ns, int* __restrict__ plan, int* __restrict__ list) {
+// largest count of a batch (prefix counts after phase 1, full counts after phase 2) -> *dst by atomic max
+__global__ void k_ransac_best(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int* __restrict__ dst) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c_split = plan[0], best = plan[2];
+    int c = (h < count && triples[h].w != 0) ? counts[h] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, 64));
+    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(dst, c);
+}
+// Which hypotheses of a batch go on to phase 2.  With rest = the points phase 1 left out, ub = count + rest bounds a
+// hypothesis' full count from above.  It is dropped when it provably is neither the result nor the iteration the loop of
+// registration.cpp:284-290 stops at:
+//   (a) ub <= best of the EARLIER batches.  It cannot be a new best at its iteration (strict >, :284), and the early exit
+//       (:290) can only fire on a new best: had an earlier iteration reached `fitness > confidence` the loop would have ended
+//       there.  Ties with the earlier best lose by the strict comparison, so <= is enough.  [round 2]
+//   (b) ub < L, L = the largest PREFIX count inside this very batch, and float(ub)/ns is not > confidence.  Some hypothesis
+//       h* of the batch has a full count >= L > ub, so this one is not the final result whatever the order of the two (strict
+//       <: with ub == L and h* LATER than it, a tie would go to the earlier iteration, i.e. to the dropped one).  It could
+//       still be a new best at its own iteration when h* comes later, and an exit firing there would return it - hence the
+//       second condition: with no count up to ub passing the confidence test, the exit cannot fire on it.  Conversely an exit
+//       that fires at a kept iteration e returns e itself: anything earlier with at least its count would have ended the loop
+//       before, and every dropped iteration has a count below the confidence bar that e passed.  [round 3]
+// Either way the counts of the dropped hypotheses stay partial and compare as the true ones would: below the result's.
+__global__ void k_ransac_select(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int ns, float confidence,
+                                const int* __restrict__ state, int* __restrict__ plan, int* __restrict__ list) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c_split = plan[0], best = state[0], in_batch = plan[2];
     const int rest = max(0, ns - min(ns, c_split * RS_PCH));     // (the padding past ns is never an inlier)
-    const bool keep = h < count && triples[h].w != 0 && rest > 0 && counts[h] + rest > best;
+    bool keep = h < count && triples[h].w != 0 && rest > 0;
+    if (keep) {
+        const int ub = counts[h] + rest;
+        const bool passes = static_cast<float>(ub) / static_cast<float>((size_t)ns) > confidence;   // registration.cpp:281,290 on the bound
+        keep = ub > best && (ub >= in_batch || passes);
+    }
     const unsigned long long m = __ballot(keep);
     if (!m) return;
     const int lane = threadIdx.x & 63;
@@ -335,13 +397,6 @@ __global__ void k_ransac_select(const int4* __restrict__ triples, int count, con
     if (lane == 0) at = atomicAdd(&plan[1], __popcll(m));
     at = __shfl(at, 0, 64);
     if (keep) list[at + __popcll(m & ((1ull << lane) - 1ull))] = h;
-}
-__global__ void k_ransac_best(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int* __restrict__ plan) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    int c = (h < count && triples[h].w != 0) ? counts[h] : 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, 64));
-    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(&plan[2], c);
 }
 
 // ------------------------------------------------------------------ scoring on the matrix cores (A/B variant, not the default)
@@ -576,7 +631,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     float* pq = nullptr;
     TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 8, &pq));
     // one device block: [0] bad index flag, [1] largest |source coordinate|, [2..3] rescored chunks, [4..5] scored chunks (u64 each),
-    // [8..10] the bail-out plan (phase-1 chunks, survivors, best count so far), [16..27] the winning
+    // [8] the best count known so far, [10..13] and [12+..] the two batch buffers' bail-out plans (4 ints each at [10] and [14]), [16..27] the winning
     // hypothesis, [32..35] its error sum and inlier count (2 doubles): one memset at the start, one copy back at the end
     int* d_bad = nullptr;
     TDV_TRY(ws_alloc(ctx, 40, &d_bad));
@@ -595,7 +650,8 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     // RansacPlan; short calls run as one batch without it (C4's 10,000 iterations: a short first batch was tried for them and lost
     // 2 % - their best fitness is 0.1-0.2, so at most a fifth of the points could be left out)
     const bool bailout = score_fast && !score_mfma && !trace_inliers && !bailout_env_off && max_iterations > 16384;
-    int* d_plan = d_bad + 8;
+    int* d_state = d_bad + 8;                       // [0] best count known so far
+    int* d_plan[2] = {d_bad + 10, d_bad + 28};   // per batch buffer: phase-1 chunks, survivors, largest prefix count, chunks per workgroup
     static const int drop_permille = getenv("TDV_RANSAC_DROP_PERMILLE") ? atoi(getenv("TDV_RANSAC_DROP_PERMILLE")) : 100;   // tuning knob
     float* pq2 = nullptr; float* pq3 = nullptr;
     const int n_rec = (ns + 127) / 128;
@@ -622,13 +678,13 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     // the GPU scores batch k; results are consumed in iteration order, so the outcome is that of the sequential loop
     float* hyp[2] = {nullptr, nullptr}; int* counts[2] = {nullptr, nullptr}; int4* d_tri[2] = {nullptr, nullptr};
     double* slabs = nullptr; double* d_out2 = nullptr; float* d_best12 = nullptr;
-    int* d_list = nullptr;
+    int* d_list[2] = {nullptr, nullptr};
     for (int q = 0; q < 2; ++q) {
         TDV_TRY(ws_alloc(ctx, (size_t)14 * h_pad, &hyp[q]));
         TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &counts[q]));
         TDV_TRY(ws_alloc(ctx, (size_t)batch, &d_tri[q]));
     }
-    if (bailout) TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &d_list));   // one list: phase 2 of a batch has run before the next batch's selection (stream order)
+    if (bailout) for (int q = 0; q < 2; ++q) TDV_TRY(ws_alloc(ctx, (size_t)h_pad, &d_list[q]));   // a batch's list lives until its phase 2 has run, behind the next batch's phase 1
     const int rblocks = (ns + 255) / 256;
     TDV_TRY(ws_alloc(ctx, (size_t)2 * rblocks, &slabs));
     d_best12 = reinterpret_cast<float*>(d_bad + 16);
@@ -661,12 +717,40 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         }
         return cnt;
     };
+    // point ranges of a scoring dispatch with hb hypothesis blocks (counts are accumulated by atomics, so the cut may differ per dispatch)
+    auto ranges_for = [&](int hb) {
+        const int ps = std::max(1, std::min(std::min((RS_WG_TARGET + hb - 1) / hb, std::max(1, n_pchunks / 32)), 512));
+        const int per = (n_pchunks + ps - 1) / ps;
+        return (n_pchunks + per - 1) / per;
+    };
+    int pending = -1, pending_cnt = 0;   // bail-out: the batch buffer whose phase 2 has not been enqueued yet
+    // phase 2 of the pending batch (alone, or riding behind job A of the batch in `a`), then its final counts: best, copy, event
+    auto finish_pending = [&](const ScoreJob* a, int g1) -> int {
+        const int p = pending;
+        const int hbp = (int)(align_up((size_t)pending_cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
+        ScoreJob jb{hyp[p], counts[p], d_plan[p], d_list[p], hbp, 0};
+        // job B's grid: the host knows neither how many hypotheses survived nor how long phase 1 was; its workgroups stride over
+        // the (range, block) items, so any multiple of 8 is enough - a quarter of a full grid covers the usual eighth of
+        // survivors in one pass, surplus workgroups return at once
+        const int g2 = std::max(8, (hbp * ranges_for(hbp) / 4 + 7) / 8 * 8);
+        {
+            ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
+            if (a) k_ransac_score_fast<<<g1 + g2, RS_BLOCK, 0, s>>>(*a, jb, g1, h_pad, pq2, n_pchunks, tau, d_rescored);
+            else k_ransac_score_fast<<<g2, RS_BLOCK, 0, s>>>(jb, jb, 0, h_pad, pq2, n_pchunks, tau, d_rescored);
+        }
+        k_ransac_best<<<(pending_cnt + 255) / 256, 256, 0, s>>>(d_tri[p], pending_cnt, counts[p], d_state);
+        TDV_CHECK_LAUNCH(ctx);
+        TDV_HIP(ctx, hipMemcpyAsync(h_cnt[p], counts[p], (size_t)pending_cnt * 4, hipMemcpyDeviceToHost, s));
+        TDV_HIP(ctx, hipEventRecord(ev[p], s));
+        pending = -1;
+        return TDV_OK;
+    };
     auto enqueue = [&](int q, int cnt) -> int {     // device: hypotheses + scoring + counts back to the host
         TDV_HIP(ctx, hipMemcpyAsync(d_tri[q], h_tri[q], (size_t)cnt * 16, hipMemcpyHostToDevice, s));
         k_ransac_hypotheses<<<(h_pad + 255) / 256, 256, 0, s>>>(pq, d_tri[q], cnt, h_pad, hyp[q], d_pmax, sqrt_tau, counts[q],
                                                                  (score_mfma ? 24.f : 16.f) * 5.9604644775390625e-08f);
         const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
-        {   // TDV_TIMER_RANSAC_SCORE brackets every dispatch of a scoring kernel on its own (with the bail-out: two per batch)
+        {   // TDV_TIMER_RANSAC_SCORE brackets every dispatch of a scoring kernel on its own
             if (score_mfma) {
                 ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
                 const int groups = (cnt + RM_HPW - 1) / RM_HPW, gblocks = (groups + RM_WAVES - 1) / RM_WAVES;
@@ -677,25 +761,32 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                 wave_chunks += (double)gblocks * RM_WAVES * 4.0 * (double)n_rec;
             }
             else if (score_fast) {
-                // point splits for THIS launch's hypothesis blocks (counts are accumulated by atomics, so they may differ per launch)
-                int ps = std::max(1, std::min(std::min((RS_WG_TARGET + hb - 1) / hb, std::max(1, n_pchunks / 32)), 512));
-                const int per = (n_pchunks + ps - 1) / ps;
-                ps = (n_pchunks + per - 1) / per;
+                const int ps = ranges_for(hb);
                 if (bailout) {
-                    k_ransac_plan<<<1, 1, 0, s>>>(d_plan, ns, n_pchunks, drop_permille);
-                    {
+                    // One dispatch per batch: its phase 1 (job A) and, behind it, phase 2 of the batch before (job B).  The plan
+                    // of this batch is made from the best count known now: full counts of the batches whose phase 2 has run,
+                    // the prefix counts of the pending one (a lower bound of its full counts - a bound is all the rule needs).
+                    k_ransac_plan<<<1, 1, 0, s>>>(d_state, d_plan[q], ns, n_pchunks, ps, drop_permille);
+                    ScoreJob ja{hyp[q], counts[q], d_plan[q], nullptr, hb, ps};
+                    const int g1 = (hb * ps + 7) / 8 * 8;     // (job B's XCD numbering starts at a multiple of 8; the few ids past hb * ps walk an empty range)
+                    if (pending >= 0) TDV_TRY(finish_pending(&ja, g1));
+                    else {
                         ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
-                        k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, nullptr, 1);
+                        k_ransac_score_fast<<<g1, RS_BLOCK, 0, s>>>(ja, ja, g1, h_pad, pq2, n_pchunks, tau, d_rescored);
                     }
-                    k_ransac_select<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], ns, d_plan, d_list);
-                    {   // (phase 2 renumbers its workgroups per XCD: 8 point ranges x the surviving hypothesis blocks at a time, so its grid is padded to whole groups of 8 ranges)
-                        ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
-                        k_ransac_score_fast<<<dim3(hb, (ps + 7) / 8 * 8), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, d_plan, d_list, 2);
-                    }
-                    k_ransac_best<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], d_plan);
+                    // survivors of this batch: the in-batch bound first (largest prefix count), then the list; the prefix counts
+                    // also raise the best known for the batches after this one
+                    k_ransac_best<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], d_plan[q] + 2);
+                    k_ransac_select<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], ns, confidence, d_state, d_plan[q], d_list[q]);
+                    k_ransac_best<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], d_state);
+                    pending = q; pending_cnt = cnt;
+                    wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
+                    TDV_CHECK_LAUNCH(ctx);
+                    return TDV_OK;                           // counts and event follow with this batch's phase 2 (finish_pending)
                 } else {
                     ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
-                    k_ransac_score_fast<<<dim3(hb, ps), RS_BLOCK, 0, s>>>(hyp[q], h_pad, pq2, n_pchunks, per, tau, counts[q], d_rescored, nullptr, nullptr, 0);
+                    ScoreJob ja{hyp[q], counts[q], nullptr, nullptr, hb, ps};
+                    k_ransac_score_fast<<<hb * ps, RS_BLOCK, 0, s>>>(ja, ja, hb * ps, h_pad, pq2, n_pchunks, tau, d_rescored);
                 }
                 wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
             }
@@ -722,7 +813,10 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         int cnt_next = 0;
         if (it_next < max_iterations) {             // overlap: prepare and enqueue the next batch behind the current one
             cnt_next = prepare(nxt, it_next);
-            status = enqueue(nxt, cnt_next);
+            status = enqueue(nxt, cnt_next);           // (with the bail-out this also runs phase 2 of `cur` and sends its counts)
+            if (status != TDV_OK) break;
+        } else if (pending == cur) {                  // last batch: its phase 2 runs alone
+            status = finish_pending(nullptr, 0);
             if (status != TDV_OK) break;
         }
         if (hipEventSynchronize(ev[cur]) != hipSuccess) { status = TDV_ERR_LAUNCH; break; }

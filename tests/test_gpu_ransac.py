@@ -378,3 +378,47 @@ def test_ransac_bailout_fuzz(ctx, synth, seed):
           % (ns, nt, good, voxel, iters, confidence, ctx.last_ransac_scored(), f.inliers, f.best_iteration, f.iterations_run))
     assert (f.best_iteration, f.iterations_run, f.inliers, f.fitness, f.rmse) == (e.best_iteration, e.iterations_run, e.inliers, e.fitness, e.rmse)
     assert f.transformation.tobytes() == e.transformation.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ransac_bailout_in_batch_rule_planted_jump(ctx, orc, seed):
+    """Rule (b) of k_ransac_select (a hypothesis is dropped against the largest PREFIX count of its own batch) only acts when a
+    batch holds a hypothesis far better than everything before it.  Such a batch is planted: every correspondence is noisy (a
+    hypothesis from three noisy pairs is a poor pose with a middling count) except the three pairs drawn at ONE chosen iteration
+    of a later batch, which are exact (a pose that collects every pair whose noise is below the threshold).  Stopping
+    confidences sit below, between and above the two levels, so the early exit fires before, at, or never at the planted
+    iteration; in one variant a second exact triple sits EARLIER in the same batch with the same count (the tie must go to the
+    earlier iteration).  The run without a trace equals the exact kernel and the oracle."""
+    rng = np.random.default_rng(700 + seed)
+    ns = int(rng.integers(1500, 5000))
+    iters = int(rng.choice([40000, 75000, 140000]))
+    voxel = 0.004
+    tri = orc.sample_triples(ns, iters).astype(np.int64)
+    ok = np.nonzero((tri[:, 0] != tri[:, 1]) & (tri[:, 1] != tri[:, 2]) & (tri[:, 0] != tri[:, 2]))[0]
+    k_star = int(rng.choice(ok[(ok > 9000) & (ok < iters - 10)]))                 # past the first batch of 8,192
+    src = (rng.random((ns, 3)).astype(np.float32) - 0.5) * np.float32(40 * voxel)  # a cloud 40 voxels wide: noisy triples give poor poses
+    ang = rng.random() * 2.0; ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+    t = rng.normal(size=3) * 0.1
+    d = rng.normal(size=(ns, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    noise = d * (rng.random((ns, 1)) ** (1 / 3)) * (2.2 * 1.5 * voxel)             # uniform in a ball of 2.2 thresholds
+    tgt = (src.astype(np.float64) @ R.T + t + noise).astype(np.float32)
+    planted = [k_star]
+    if seed % 3 == 1:                                                             # a second exact triple earlier in the same batch
+        lo = max(8192, (k_star - 8192) // 65536 * 65536 + 8192)
+        earlier = ok[(ok >= lo) & (ok < k_star)]
+        if len(earlier): planted.append(int(earlier[len(earlier) // 2]))
+    for k in planted:
+        tgt[tri[k]] = (src[tri[k]].astype(np.float64) @ R.T + t).astype(np.float32)
+    corr = np.arange(ns, dtype=np.int32)
+    full = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=2.0, trace=True)
+    top = int(full["inliers"].max()); before = int(full["inliers"][:min(planted)].max())
+    assert top > 1.3 * before, "the planted iteration must stand out (%d vs %d)" % (top, before)
+    for confidence in (2.0, (before + 1) / ns * 0.5, (before + top) / 2 / ns, top / ns * 1.01):
+        ref = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence)), trace=True)
+        got = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence)))
+        scored = ctx.last_ransac_scored()
+        _same_result(got, ref)
+        print("seed %d ns %d iters %d planted %s: level %d -> %d, confidence %.3f: best %d @ %d, run %d, scored %.3f"
+              % (seed, ns, iters, planted, before, top, confidence, got.inliers, got.best_iteration, got.iterations_run, scored))
