@@ -85,6 +85,28 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         }
     }
     static const bool coherent_stages = !(getenv("TDV_BATCH_COHERENT") && atoi(getenv("TDV_BATCH_COHERENT")) == 0);   // A/B knob
+    // voxels of ALL instances in first-occurrence order with one memset + two launches (voxel.hip, hash-table path); a lane then
+    // only finishes its instance's reference order.  A voxel too full for the table's member rows (a very coarse grid) sends the
+    // whole batch back to per-instance calls.
+    static const bool batched_voxel_env = !(getenv("TDV_BATCH_VOXEL") && atoi(getenv("TDV_BATCH_VOXEL")) == 0);          // A/B knob
+    const bool want_ref = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE;
+    std::vector<int> voff((size_t)n_instances + 1, 0);
+    float* vox_first_all = nullptr; int* vox_rank_all = nullptr; int4* vox_leaders_all = nullptr;
+    bool batched_voxel = false;
+    const int total_pts = off[n_instances];
+    if (batched_voxel_env && total_pts > 0 && !getenv("TDV_VOXEL_LEGACY") && !getenv("TDV_VOXEL_SORT")) {
+        TDV_TRY(ws_alloc(ctx, (size_t)total_pts * 3, &vox_first_all));
+        if (want_ref) { TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_rank_all)); TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_leaders_all)); }
+        int* d_off_inst;
+        TDV_TRY(ws_alloc(ctx, (size_t)n_instances + 1, &d_off_inst));
+        TDV_HIP(ctx, hipMemcpyAsync(d_off_inst, off.data(), ((size_t)n_instances + 1) * 4, hipMemcpyHostToDevice, ctx->stream));   // (off outlives the call's sync below)
+        const WsMark vmark = ws_mark(ctx);                   // the table and member rows are scratch: given back after the call
+        int overflowed = 0;
+        TDV_TRY(voxel_downsample_batch_dev(ctx, all_xyz, total_pts, d_off_inst, n_instances, prm->voxel_size, vox_first_all, vox_rank_all, vox_leaders_all,
+                                           voff.data(), &overflowed));
+        ws_rewind(ctx, vmark);
+        batched_voxel = !overflowed;
+    }
     // one instance: voxel -> normals + FPFH -> match -> RANSAC -> ICP on context c (its stream, its workspace)
     auto run_instance = [&](tdv_ctx* c, int b) -> int {
         tdv_instance_result& r = results[b];
@@ -96,21 +118,37 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         if (n == 0) { r.status = empty_status[b]; ws_rewind(c, mark); return TDV_OK; }
         float* xyz = all_xyz + (size_t)off[b] * 3;
         float* vx; int v = 0;
-        TDV_TRY(ws_alloc(c, (size_t)n * 3, &vx));
         // The reference's container order scatters neighbouring voxels over the whole array, which costs the per-point stages
         // (radius search, SPFH / FPFH gathers, descriptor search) their locality.  Those stages are per point: they run on the
         // same voxels in first-occurrence order (image order: coherent), with every neighbour list ordered by the reference
         // POSITIONS of its members — so each point's normal, descriptor and match carry the bits they have in the reference
         // order — and only the correspondences are permuted.  RANSAC (which draws points by position) and ICP (whose sums
         // run over positions) see the cloud in the reference's order.
-        const bool coherent = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE && coherent_stages && prm->normals_k <= 100;
+        const bool coherent = want_ref && coherent_stages && prm->normals_k <= 100;
         VoxelBothOrders both{nullptr, nullptr, nullptr};
-        if (coherent) {
-            TDV_TRY(ws_alloc(c, (size_t)n * 3, &both.first_xyz));
-            TDV_TRY(ws_alloc(c, (size_t)n, &both.ref2first));
-            TDV_TRY(ws_alloc(c, (size_t)n, &both.first2ref));
+        if (batched_voxel) {
+            v = voff[b + 1] - voff[b];
+            float* first = vox_first_all + (size_t)voff[b] * 3;
+            if (!want_ref) vx = first;
+            else {
+                TDV_TRY(ws_alloc(c, (size_t)v * 3, &vx));
+                if (coherent) {
+                    both.first_xyz = first;
+                    TDV_TRY(ws_alloc(c, (size_t)v, &both.ref2first));
+                    TDV_TRY(ws_alloc(c, (size_t)v, &both.first2ref));
+                }
+                TDV_TRY(voxel_reference_order(c, v, n, vox_leaders_all + voff[b], first, nullptr, vox_rank_all + off[b], voff[b], vx, nullptr,
+                                              coherent ? &both : nullptr));
+            }
+        } else {
+            TDV_TRY(ws_alloc(c, (size_t)n * 3, &vx));
+            if (coherent) {
+                TDV_TRY(ws_alloc(c, (size_t)n * 3, &both.first_xyz));
+                TDV_TRY(ws_alloc(c, (size_t)n, &both.ref2first));
+                TDV_TRY(ws_alloc(c, (size_t)n, &both.first2ref));
+            }
+            TDV_TRY(voxel_downsample_dev(c, xyz, nullptr, n, prm->voxel_size, prm->voxel_order, vx, nullptr, n, &v, coherent ? &both : nullptr));
         }
-        TDV_TRY(voxel_downsample_dev(c, xyz, nullptr, n, prm->voxel_size, prm->voxel_order, vx, nullptr, n, &v, coherent ? &both : nullptr));
         r.n_voxels = v;
         float *nrm, *fpfh; int* corr;
         TDV_TRY(ws_alloc(c, (size_t)v * 3, &nrm));

@@ -782,6 +782,8 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                     pending = q; pending_cnt = cnt;
                     wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
                     TDV_CHECK_LAUNCH(ctx);
+                    static const bool merge_off = getenv("TDV_RANSAC_MERGE") && atoi(getenv("TDV_RANSAC_MERGE")) == 0;   // A/B knob: phase 2 as a dispatch of its own (round 2's shape)
+                    if (merge_off) return finish_pending(nullptr, 0);
                     return TDV_OK;                           // counts and event follow with this batch's phase 2 (finish_pending)
                 } else {
                     ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);

@@ -176,6 +176,12 @@ struct VoxelBothOrders { float* first_xyz; int* ref2first; int* first2ref; };
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
                          float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, const VoxelBothOrders* both = nullptr);
 
+// batch: every cloud's voxels in first-occurrence order with one memset + two launches (voxel.hip); the reference order per cloud
+int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, const int* d_seg_off, int n_clouds, float voxel,
+                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed);
+int voxel_reference_order(tdv_ctx* ctx, int v, int n, const int4* d_leaders, const float* tmp_xyz, const float* tmp_rgb, const int* d_rank, int rank_base,
+                          float* d_out_xyz, float* d_out_rgb, const VoxelBothOrders* both);
+
 int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
 // sort.hip: stable radix sort (rocPRIM) of (key, value) pairs on the low end_bit bits of the 64-bit key; any n; scratch from the workspace
 int radix_sort_pairs_dev(tdv_ctx* ctx, const unsigned long long* d_keys_in, unsigned long long* d_keys_out,

@@ -400,15 +400,214 @@ void k_voxel_means(const uint4* __restrict__ rec, int n, const float* __restrict
 }
 
 // out[p] = in[rank[order_first[p]]]
-__global__ void k_voxel_permute(const float* __restrict__ in_xyz, const float* __restrict__ in_rgb, const int* __restrict__ rank,
+__global__ void k_voxel_permute(const float* __restrict__ in_xyz, const float* __restrict__ in_rgb, const int* __restrict__ rank, int rank_base,
                                 const int* __restrict__ order_first, int v, float* __restrict__ out_xyz, float* __restrict__ out_rgb,
                                 int* __restrict__ ref2first, int* __restrict__ first2ref) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= v) return;
-    int s = rank[order_first[p]];
+    int s = rank[order_first[p]] - rank_base;     // (rank_base: the cloud's first voxel when ranks count through several clouds)
     if (ref2first) { ref2first[p] = s; first2ref[s] = p; }
     out_xyz[3 * (size_t)p] = in_xyz[3 * (size_t)s]; out_xyz[3 * (size_t)p + 1] = in_xyz[3 * (size_t)s + 1]; out_xyz[3 * (size_t)p + 2] = in_xyz[3 * (size_t)s + 2];
     if (in_rgb && out_rgb) { out_rgb[3 * (size_t)p] = in_rgb[3 * (size_t)s]; out_rgb[3 * (size_t)p + 1] = in_rgb[3 * (size_t)s + 1]; out_rgb[3 * (size_t)p + 2] = in_rgb[3 * (size_t)s + 2]; }
+}
+
+// ---- grouping through a hash table: memset + 2 kernels for any number of clouds (round 3; the default) -------------------
+// The counting-sort path above is nine dependent launches whose waves wait >= 90 % of their cycles (profiles/r2: 0.10-0.12 ms
+// for a cloud that HBM moves in a microsecond).  This path is three, and takes B clouds stored back to back at once:
+//   memset            one fill (0x7f bytes) of [claim table | per-voxel min | per-voxel count | scan descriptors | ticket]
+//   k_vh_insert       one lane per point: find-or-claim the cell's slot of an open-addressing table (linear probing, 32-bit
+//                     atomics).  The slot permanently holds the CLAIMER - the first point that got there; its index names the
+//                     voxel: vmin[claimer] = atomic min of the members' indices (the leader), vcnt[claimer] counts them down
+//                     from 0x7f7f7f7f, members[claimer][arrival rank] lists them (VH_K per voxel; a fuller voxel raises a
+//                     flag and the call is redone on the counting-sort path).  Which point claims a slot depends on the race;
+//                     nothing that leaves the kernel pair does.
+//   k_vh_finalize     one lane per point, 1,024 points per workgroup: leader flags, workgroup scan, DECOUPLED LOOK-BACK over
+//                     the workgroups' aggregates (single pass: no scan launches) -> the leader's first-occurrence rank; the
+//                     leader sorts its <= VH_K member indices, sums the points in ascending index order (registration.cpp:
+//                     47-50), divides and writes the mean at its rank.  Voxels of cloud b occupy [voff[b], voff[b + 1]).
+// Algorithmic bytes: 12 N in + 12 V out; the table adds 16 B per point of atomics and 4-68 B per voxel of member lists.
+constexpr int VH_K = 16;                       // member slots per voxel (one 64-B row)
+constexpr int VH_EMPTY = 0x7f7f7f7f;           // what the memset leaves; larger than any point index
+constexpr int VH_BLOCK = 256, VH_IPT = 4, VH_ITEMS = VH_BLOCK * VH_IPT;
+constexpr unsigned long long VH_ST_MASK = 3ull << 62, VH_ST_WAIT = 1ull << 62, VH_ST_AGG = 2ull << 62, VH_ST_PREFIX = 3ull << 62;   // 0x7f.. has status 01
+static_assert((0x7f7f7f7f7f7f7f7full & VH_ST_MASK) == VH_ST_WAIT, "the memset pattern must read as 'not ready'");
+
+__device__ __forceinline__ int vh_segment(const int* __restrict__ seg_off, int nseg, int g) {   // largest b with seg_off[b] <= g (b < nseg)
+    int lo = 0, hi = nseg;
+    while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (seg_off[m] <= g) lo = m; else hi = m; }
+    return lo;
+}
+__device__ __forceinline__ void vh_cell(const float* __restrict__ xyz, size_t g, float inv, int& cx, int& cy, int& cz) {
+    cx = (int)floorf(xyz[3 * g] * inv); cy = (int)floorf(xyz[3 * g + 1] * inv); cz = (int)floorf(xyz[3 * g + 2] * inv);   // registration.cpp:33-36
+}
+
+__global__ __launch_bounds__(256)
+void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict__ seg_off, int nseg, float inv, unsigned mask,
+                 int* __restrict__ claim, int* __restrict__ vmin, int* __restrict__ vcnt, int* __restrict__ members,
+                 int* __restrict__ voxel_of, int* __restrict__ overflow) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    int lo = 0, hi = total, b = 0;
+    if (nseg > 1) { b = vh_segment(seg_off, nseg, g); lo = seg_off[b]; hi = seg_off[b + 1]; }
+    int cx, cy, cz;
+    vh_cell(xyz, (size_t)g, inv, cx, cy, cz);
+    unsigned h = voxel_hash((unsigned)cx, (unsigned)cy, (unsigned)cz) + (unsigned)b * 0x9e3779b9u;
+    int j;
+    for (;; ++h) {
+        int* slot = claim + (h & mask);
+        j = *slot;
+        if (j == VH_EMPTY) { const int prev = atomicCAS(slot, VH_EMPTY, g); j = prev == VH_EMPTY ? g : prev; }
+        if (j == g) break;
+        if (j >= lo && j < hi) {                        // the same cloud: same cell?
+            int qx, qy, qz;
+            vh_cell(xyz, (size_t)j, inv, qx, qy, qz);
+            if (qx == cx && qy == cy && qz == cz) break;
+        }
+    }
+    voxel_of[g] = j;
+    atomicMin(&vmin[j], g);
+    const int pos = VH_EMPTY - atomicSub(&vcnt[j], 1);  // arrival rank 0, 1, 2 ...
+    if (pos < VH_K) members[(size_t)j * VH_K + pos] = g;
+    else *overflow = 1;                                 // (any value but the fill pattern)
+}
+
+__global__ __launch_bounds__(VH_BLOCK)
+void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb, int total, const int* __restrict__ seg_off, int nseg, float inv,
+                   const int* __restrict__ voxel_of, const int* __restrict__ vmin, const int* __restrict__ vcnt, const int* __restrict__ members,
+                   unsigned long long* __restrict__ desc, int* __restrict__ ticket, float* __restrict__ out_xyz, float* __restrict__ out_rgb,
+                   int* __restrict__ rank_out /* per point: global first-occurrence rank of leaders */, int4* __restrict__ leaders /* optional */,
+                   int* __restrict__ voff /* nseg + 1 */, int capacity /* voxels that fit out_xyz */) {
+    __shared__ int s_ticket, s_excl, s_wave[VH_BLOCK / 64];
+    if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1) - VH_EMPTY;     // workgroups take their tiles in the order they start
+    __syncthreads();
+    const int t = s_ticket;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g0 = t * VH_ITEMS + threadIdx.x * VH_IPT;
+    int vox[VH_IPT]; bool lead[VH_IPT]; int mine = 0;
+#pragma unroll
+    for (int e = 0; e < VH_IPT; ++e) {
+        const int g = g0 + e;
+        vox[e] = g < total ? voxel_of[g] : 0;
+        lead[e] = g < total && vmin[vox[e]] == g;
+        mine += lead[e] ? 1 : 0;
+    }
+    // workgroup scan of the leader counts
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wbase = 0, agg = 0;
+#pragma unroll
+    for (int w = 0; w < VH_BLOCK / 64; ++w) { if (w < wave) wbase += s_wave[w]; agg += s_wave[w]; }
+    // decoupled look-back (wave 0): publish the aggregate, then add up the predecessors' aggregates back to the nearest
+    // inclusive prefix, 64 tiles per step.  Tiles are numbered by ticket, so every predecessor has started and publishes its
+    // aggregate without waiting for anybody: the wait below always ends.
+    if (wave == 0) {
+        if (lane == 0) __hip_atomic_store(&desc[t], (t == 0 ? VH_ST_PREFIX : VH_ST_AGG) | (unsigned long long)(unsigned)agg, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int excl = 0;
+        for (int look = t - 1; look >= 0; look -= 64) {
+            const int idx = look - lane;
+            unsigned long long d = VH_ST_PREFIX;                                  // tiles before the first: prefix 0
+            if (idx >= 0) {
+                d = __hip_atomic_load(&desc[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                while ((d & VH_ST_MASK) == VH_ST_WAIT) { __builtin_amdgcn_s_sleep(1); d = __hip_atomic_load(&desc[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            const unsigned long long pm = __ballot((d & VH_ST_MASK) == VH_ST_PREFIX);
+            const int first = pm ? __builtin_ctzll(pm) : 64;                       // nearest tile that already holds an inclusive prefix
+            int v = lane <= first ? (int)(unsigned)(d & 0xffffffffull) : 0;
+            v = wave_sum_i32(v);
+            excl += v;
+            if (pm) break;
+        }
+        if (lane == 0) {
+            if (t > 0) __hip_atomic_store(&desc[t], VH_ST_PREFIX | (unsigned long long)(unsigned)(excl + agg), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+        }
+    }
+    __syncthreads();
+    int run = s_excl + wbase + incl - mine;             // global rank of this thread's first leader
+    const bool last_tile = (t + 1) * VH_ITEMS >= total;
+    if (last_tile && threadIdx.x == VH_BLOCK - 1) {      // the grand total, and every cloud that starts at the very end (empty trailing clouds)
+        const int total_v = s_excl + agg;
+        voff[nseg] = total_v;
+        if (nseg > 1) for (int b = nseg - 1; b >= 0 && seg_off[b] >= total; --b) voff[b] = total_v;
+    }
+#pragma unroll
+    for (int e = 0; e < VH_IPT; ++e) {
+        const int g = g0 + e;
+        if (g >= total) break;
+        int lo = 0, b = 0;
+        if (nseg > 1) { b = vh_segment(seg_off, nseg, g); lo = seg_off[b]; }
+        if (g == lo) {                                    // first point of cloud b: its voxels start at this rank; so do the empty clouds right before it
+            voff[b] = run;
+            for (int bb = b - 1; bb >= 0 && seg_off[bb] == g; --bb) voff[bb] = run;
+        }
+        if (!lead[e]) continue;
+        const int j = vox[e];
+        const int cnt = min(VH_EMPTY - vcnt[j], VH_K);    // (an overflowing voxel: the call is redone, whatever is written here is dropped)
+        int m[VH_K];
+        const int4* row = reinterpret_cast<const int4*>(members + (size_t)j * VH_K);
+#pragma unroll
+        for (int q = 0; q < VH_K / 4; ++q) {
+            int4 r = make_int4(VH_EMPTY, VH_EMPTY, VH_EMPTY, VH_EMPTY);
+            if (4 * q < cnt) r = row[q];
+            m[4 * q] = 4 * q < cnt ? r.x : VH_EMPTY; m[4 * q + 1] = 4 * q + 1 < cnt ? r.y : VH_EMPTY;
+            m[4 * q + 2] = 4 * q + 2 < cnt ? r.z : VH_EMPTY; m[4 * q + 3] = 4 * q + 3 < cnt ? r.w : VH_EMPTY;
+        }
+        // ascending index order without moving anything: cnt rounds of "smallest index above the last one"
+        float ax = 0.f, ay = 0.f, az = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        int last = -1;
+        for (int r = 0; r < cnt; ++r) {
+            int nxt = VH_EMPTY;
+#pragma unroll
+            for (int q = 0; q < VH_K; ++q) nxt = (m[q] > last && m[q] < nxt) ? m[q] : nxt;
+            last = nxt;
+            const size_t idx = (size_t)nxt;
+            ax += xyz[3 * idx]; ay += xyz[3 * idx + 1]; az += xyz[3 * idx + 2];        // registration.cpp:47-50, ascending input index
+            if (rgb) { cr += rgb[3 * idx]; cg += rgb[3 * idx + 1]; cb += rgb[3 * idx + 2]; }
+        }
+        const float fn = (float)cnt;
+        const size_t o = (size_t)run;
+        if (rank_out) rank_out[g] = run;
+        if (run >= capacity) { ++run; continue; }          // the caller's buffer is too small: it learns the count and gets an error
+        out_xyz[3 * o] = ax / fn; out_xyz[3 * o + 1] = ay / fn; out_xyz[3 * o + 2] = az / fn;   // :52-53
+        if (rgb && out_rgb) { out_rgb[3 * o] = cr / fn; out_rgb[3 * o + 1] = cg / fn; out_rgb[3 * o + 2] = cb / fn; }
+        if (leaders) { int cx, cy, cz; vh_cell(xyz, (size_t)g, inv, cx, cy, cz); leaders[o] = make_int4(cx, cy, cz, g - lo); }
+        ++run;
+    }
+}
+
+// The hash-table path for B clouds stored back to back (d_seg_off: B + 1 device ints, nullptr for one cloud).  Outputs in
+// first-occurrence order, cloud b at [voff[b], voff[b + 1]) of d_out_xyz (capacity `total` points); d_voff: B + 1 ints.
+// *overflowed = 1: a voxel had more than VH_K members (the outputs are garbage, take the counting-sort path).
+static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int total, const int* d_seg_off, int nseg, float voxel,
+                                  float* d_out_xyz, float* d_out_rgb, int capacity, int* d_rank /* optional, total ints */,
+                                  int4* d_leaders /* optional, capacity entries */, int* d_voff, int** d_overflow_out) {
+    hipStream_t s = ctx->stream;
+    const float inv = 1.0f / voxel;  // registration.cpp:32
+    size_t slots = 4096;
+    while (slots < 2 * (size_t)total) slots <<= 1;
+    const int tiles = (total + VH_ITEMS - 1) / VH_ITEMS;
+    // one fill: claim[slots] | vmin[total] | vcnt[total] | desc[tiles] (u64) | ticket | overflow
+    const size_t desc_at = (slots + 2 * (size_t)total + 1) & ~(size_t)1;
+    const size_t n_fill = desc_at + 2 * (size_t)tiles + 2;
+    int* fill;
+    TDV_TRY(ws_alloc(ctx, n_fill, &fill));
+    int* claim = fill; int* vmin = claim + slots; int* vcnt = vmin + total;
+    unsigned long long* desc = reinterpret_cast<unsigned long long*>(fill + desc_at);
+    int* ticket = reinterpret_cast<int*>(desc + tiles);
+    int* overflow = ticket + 1;
+    int *members, *voxel_of;
+    TDV_TRY(ws_alloc(ctx, (size_t)total * VH_K, &members));
+    TDV_TRY(ws_alloc(ctx, (size_t)total, &voxel_of));
+    TDV_HIP(ctx, hipMemsetAsync(fill, 0x7f, n_fill * 4, s));
+    k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vmin, vcnt, members, voxel_of, overflow);
+    k_vh_finalize<<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vmin, vcnt, members, desc, ticket,
+                                             d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity);
+    TDV_CHECK_LAUNCH(ctx);
+    *d_overflow_out = overflow;                          // still the fill pattern (VH_EMPTY) unless a voxel overflowed its member row
+    return TDV_OK;
 }
 
 namespace {
@@ -509,7 +708,73 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
 
 int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
                          float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, const VoxelBothOrders* both) {
-    return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
+    if (!ctx || !n_out || n < 0 || capacity < 0 || !(voxel > 0.f) || (n > 0 && !d_xyz)) return TDV_ERR_BAD_ARG;
+    if (order != TDV_VOXEL_ORDER_FIRST && order != TDV_VOXEL_ORDER_REFERENCE) return TDV_ERR_BAD_ARG;
+    if (both && (order != TDV_VOXEL_ORDER_REFERENCE || !both->first_xyz || !both->ref2first || !both->first2ref)) return TDV_ERR_BAD_ARG;
+    *n_out = 0;
+    if (n == 0) return TDV_OK;
+    static const bool legacy = getenv("TDV_VOXEL_LEGACY") != nullptr || getenv("TDV_VOXEL_SORT") != nullptr;   // A/B knobs: the counting-sort path / the full sort
+    if (legacy) return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
+    // hash-table path (memset + 2 kernels); first-occurrence order lands in the caller's buffer directly
+    hipStream_t s = ctx->stream;
+    const bool ref = order == TDV_VOXEL_ORDER_REFERENCE;
+    int *d_voff, *d_rank = nullptr, *d_overflow = nullptr; int4* d_leaders = nullptr;
+    float *tmp_xyz = d_out_xyz, *tmp_rgb = d_out_rgb;
+    int cap_first = capacity;
+    TDV_TRY(ws_alloc(ctx, 2, &d_voff));
+    if (ref) {
+        cap_first = n;
+        TDV_TRY(ws_alloc(ctx, (size_t)n, &d_rank));
+        TDV_TRY(ws_alloc(ctx, (size_t)n, &d_leaders));
+        if (both) tmp_xyz = both->first_xyz; else TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &tmp_xyz));
+        tmp_rgb = nullptr;
+        if (d_rgb && d_out_rgb) TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &tmp_rgb));
+    }
+    TDV_TRY(pin_reserve(ctx, 64));
+    int* h = reinterpret_cast<int*>(ctx->pin);
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
+        TDV_TRY(voxel_hash_first_order(ctx, d_xyz, (d_rgb && d_out_rgb) ? d_rgb : nullptr, n, nullptr, 1, voxel, tmp_xyz, tmp_rgb, cap_first, d_rank, d_leaders,
+                                       d_voff, &d_overflow));
+    }
+    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff + 1, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipMemcpyAsync(h + 1, d_overflow, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    if (h[1] != VH_EMPTY)      // a voxel with more than VH_K members (a coarse grid): the counting-sort path takes any count
+        return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
+    const int v = h[0];
+    *n_out = v;
+    if (v > capacity) return TDV_ERR_BAD_ARG;
+    if (!ref) return TDV_OK;
+    return voxel_reference_order(ctx, v, n, d_leaders, tmp_xyz, tmp_rgb, d_rank, 0, d_out_xyz, d_out_rgb, both);
+}
+
+// All clouds of a batch at once (first-occurrence order; the reference order is finished per cloud with
+// voxel_reference_order).  d_seg_off: n_clouds + 1 device offsets into d_xyz.  Voxels of cloud b end up at
+// [h_voff[b], h_voff[b + 1]) of d_first_xyz (room for `total` points); d_rank / d_leaders (optional, `total` entries each) are what
+// voxel_reference_order needs.  *overflowed: a voxel held more than VH_K points - nothing of the output is valid, the caller
+// falls back to per-cloud calls.  Synchronizes the stream once.
+int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, const int* d_seg_off, int n_clouds, float voxel,
+                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed) {
+    if (!ctx || n_clouds < 1 || total < 0 || !(voxel > 0.f) || !h_voff || !overflowed) return TDV_ERR_BAD_ARG;
+    *overflowed = 0;
+    for (int b = 0; b <= n_clouds; ++b) h_voff[b] = 0;
+    if (total == 0) return TDV_OK;
+    hipStream_t s = ctx->stream;
+    int *d_voff, *d_overflow = nullptr;
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 1, &d_voff));
+    TDV_TRY(pin_reserve(ctx, ((size_t)n_clouds + 2) * 4));
+    int* h = reinterpret_cast<int*>(ctx->pin);
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
+        TDV_TRY(voxel_hash_first_order(ctx, d_xyz, nullptr, total, d_seg_off, n_clouds, voxel, d_first_xyz, nullptr, total, d_rank, d_leaders, d_voff, &d_overflow));
+    }
+    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff, ((size_t)n_clouds + 1) * 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipMemcpyAsync(h + n_clouds + 1, d_overflow, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    if (h[n_clouds + 1] != VH_EMPTY) { *overflowed = 1; return TDV_OK; }
+    std::memcpy(h_voff, h, ((size_t)n_clouds + 1) * 4);
+    return TDV_OK;
 }
 
 static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel, int order,
@@ -579,11 +844,10 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
         return TDV_OK;
     }
     // reference order: replay the container on the host to get its iteration order
-    float *tmp_xyz, *tmp_rgb = nullptr; int* d_order;
+    float *tmp_xyz, *tmp_rgb = nullptr;
     if (both) tmp_xyz = both->first_xyz;
     else TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_xyz));
     if (d_rgb && d_out_rgb) TDV_TRY(ws_alloc(ctx, (size_t)v * 3, &tmp_rgb));
-    TDV_TRY(ws_alloc(ctx, (size_t)v, &d_order));
     if (hashed) k_voxel_compact<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, n, mean_xyz, mean_rgb, v, tmp_xyz, tmp_rgb);
     else k_voxel_means<<<(n + 255) / 256, 256, 0, s>>>(rec, n, d_xyz, d_rgb, rank, v, tmp_xyz, tmp_rgb);
     TDV_CHECK_LAUNCH(ctx);
@@ -592,6 +856,17 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     TDV_TRY(ws_alloc(ctx, (size_t)v, &d_leaders));
     k_voxel_leader_list<<<(n + 255) / 256, 256, 0, s>>>(leader, rank, d_xyz, inv, n, d_leaders);
     TDV_CHECK_LAUNCH(ctx);
+    return voxel_reference_order(ctx, v, n, d_leaders, tmp_xyz, tmp_rgb, rank, 0, d_out_xyz, d_out_rgb, both);
+}
+
+// The reference's container order for v voxels held in first-occurrence order (tmp_*): leaders (cell + input index of the first
+// point of every voxel, at its first-occurrence rank) go to the host, which replays the container; d_rank[input index] =
+// first-occurrence rank.  out[p] = tmp[rank[leader index of the p-th voxel of the container]].
+int voxel_reference_order(tdv_ctx* ctx, int v, int n, const int4* d_leaders, const float* tmp_xyz, const float* tmp_rgb, const int* d_rank, int rank_base,
+                          float* d_out_xyz, float* d_out_rgb, const VoxelBothOrders* both) {
+    hipStream_t s = ctx->stream;
+    int* d_order;
+    TDV_TRY(ws_alloc(ctx, (size_t)v, &d_order));
     // through pinned memory both ways (a pageable std::vector made these two copies staged ones: 2.3 MB + 0.6 MB per C4 instance)
     const size_t pin_order_off = align_up((size_t)v * sizeof(int4), 64);
     TDV_TRY(pin_reserve(ctx, pin_order_off + (size_t)v * 4));
@@ -627,7 +902,7 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
                                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count(), real_map ? "std::unordered_map" : "emulation");
     if (n_first != v) { snprintf(ctx->err, sizeof(ctx->err), "voxel: host replay listed %d voxels, device %d", n_first, v); return TDV_ERR_INTERNAL; }
     TDV_HIP(ctx, hipMemcpyAsync(d_order, order_pinned, (size_t)v * 4, hipMemcpyHostToDevice, s));
-    k_voxel_permute<<<(v + 255) / 256, 256, 0, s>>>(tmp_xyz, tmp_rgb, rank, d_order, v, d_out_xyz, d_out_rgb,
+    k_voxel_permute<<<(v + 255) / 256, 256, 0, s>>>(tmp_xyz, tmp_rgb, d_rank, rank_base, d_order, v, d_out_xyz, d_out_rgb,
                                                     both ? both->ref2first : nullptr, both ? both->first2ref : nullptr);
     TDV_CHECK_LAUNCH(ctx);
     TDV_HIP(ctx, hipStreamSynchronize(s));  // the pinned staging is reused by the next call

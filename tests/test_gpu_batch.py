@@ -243,14 +243,14 @@ def test_batch_status_1_vs_2(ctx, tdv, synth, orc):
     assert (far[h - 8:, w - 8:] == 0).all()
     m_far = np.zeros((h, w), np.uint8); m_far[:40, :40] = 255         # keeps only pixels beyond the clip
     m_weak = np.where(masks[0] > 0, 10, 0).astype(np.uint8)          # mask value 10 is not > 10: everything rejected
-    allm = np.stack([m_empty, m_zero_depth, m_far, m_weak, masks[0]])
+    allm = np.stack([m_empty, m_zero_depth, masks[0], m_far, m_weak])    # empty instances before AND after a real one (offsets of empty clouds)
     want = []
     for m in allm:
         sd = orc.depth_preprocess(far, m, 1000.0)
         if orc.count_nonzero(sd) == 0: want.append(1)
         elif len(orc.unproject(sd, None, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 1.5)[0]) == 0: want.append(2)
         else: want.append(0)
-    assert want == [1, 1, 2, 1, 0]
+    assert want == [1, 1, 0, 2, 1]
     dev = torch.device("cuda", 0)
     model, nrm = synth.sample_object(3000, 7)
     d_mx = torch.from_numpy(model).to(dev); d_mn = torch.from_numpy(nrm).to(dev)
@@ -260,7 +260,8 @@ def test_batch_status_1_vs_2(ctx, tdv, synth, orc):
     d_masks = torch.from_numpy(allm).to(dev)
     res = ctx.register_batch_dev(d_depth.data_ptr(), None, d_masks.data_ptr(), len(allm), prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), 3000)
     assert [r["status"] for r in res] == want
-    assert all(r["n_points"] == 0 and np.array_equal(r["T"], np.eye(4, dtype=np.float32)) for r in res[:4])
+    assert all(r["n_points"] == 0 and np.array_equal(r["T"], np.eye(4, dtype=np.float32)) for i, r in enumerate(res) if i != 2)
+    assert res[2]["n_voxels"] > 100
 
 
 def test_mask_resize_nearest_matches_oracle(ctx, orc):

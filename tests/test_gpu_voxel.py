@@ -83,3 +83,27 @@ def test_reference_order_emulation_at_size(ctx, orc, synth, tdv, n, voxel):
     got_xyz, _ = ctx.voxel_downsample(pts, None, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
     assert len(got_xyz) == len(ref_xyz)
     assert got_xyz.tobytes() == ref_xyz.tobytes()
+
+
+@pytest.mark.parametrize("kmax", [15, 16, 17, 40])
+def test_member_counts_around_the_hash_path_row_size(ctx, orc, tdv, kmax):
+    """The hash-table path keeps up to 16 member indices per voxel and hands a call with a fuller voxel to the counting-sort
+    path: voxels holding exactly 1 .. kmax points (shuffled input order, colours, negative cells) straddle that limit; means
+    (sums in ascending input index) and both orders are the oracle's either way."""
+    rng = np.random.default_rng(kmax)
+    voxel = np.float32(0.01)
+    cells = rng.permutation(np.arange(-60, 60))[:kmax * 3].reshape(-1, 3)[:kmax]          # distinct cells
+    pts = []
+    for k, c in enumerate(cells):
+        for rep in range(1 + (k % 3 == 0)):                                              # some counts appear twice (in other cells)
+            cell = c + np.array([rep * 200, 0, 0])
+            pts.append((cell + 0.05 + 0.9 * rng.random((k + 1, 3))) * float(voxel))
+    pts = np.concatenate(pts).astype(np.float32)
+    perm = rng.permutation(len(pts)); pts = pts[perm]
+    rgb = rng.random((len(pts), 3)).astype(np.float32)
+    ref_xyz, ref_rgb, first = orc.voxel_downsample(pts, rgb, float(voxel))
+    got_xyz, got_rgb = ctx.voxel_downsample(pts, rgb, float(voxel), tdv.TDV_VOXEL_ORDER_REFERENCE)
+    assert got_xyz.tobytes() == ref_xyz.tobytes() and got_rgb.tobytes() == ref_rgb.tobytes()
+    order = np.argsort(first, kind="stable")
+    f_xyz, f_rgb = ctx.voxel_downsample(pts, rgb, float(voxel), tdv.TDV_VOXEL_ORDER_FIRST)
+    assert f_xyz.tobytes() == ref_xyz[order].tobytes() and f_rgb.tobytes() == ref_rgb[order].tobytes()
