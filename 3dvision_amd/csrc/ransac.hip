@@ -225,8 +225,8 @@ __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elem
 //   job B (the ids after): phase 2 of the PREVIOUS batch - the hypotheses its selection listed (plan[1] of them: those that
 //                         can still beat the best count known) over the chunks its phase 1 left out, in ranges of plan[3]
 //                         chunks (= what a job-A workgroup of that batch walked, so all workgroups of a dispatch cost the same).
-// Phase 2 used to be a dispatch of its own: a few hypothesis blocks on an otherwise idle chip, 45 % of the lane-op peak
-// against 79 % for a full grid (BENCH_r02: 0.66-0.75 overall).  Riding behind the next batch's phase 1 it fills that grid's tail.
+// By default the two jobs are dispatched one after the other (job B alone, see ransac_run_dev); with TDV_RANSAC_MERGE=1 job B
+// rides behind the NEXT batch's job A.
 struct ScoreJob {
     const float* hyp; int* counts; const int* plan; const int* list;
     int hb;      // hypothesis blocks (A: of the batch; B: upper bound - the real number comes from plan[1])
@@ -782,8 +782,14 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                     pending = q; pending_cnt = cnt;
                     wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
                     TDV_CHECK_LAUNCH(ctx);
-                    static const bool merge_off = getenv("TDV_RANSAC_MERGE") && atoi(getenv("TDV_RANSAC_MERGE")) == 0;   // A/B knob: phase 2 as a dispatch of its own (round 2's shape)
-                    if (merge_off) return finish_pending(nullptr, 0);
+                    // Phase 2 runs as a dispatch of its own right away.  Letting it ride behind the NEXT batch's phase 1 (TDV_RANSAC_MERGE=1:
+                    // one scoring dispatch per batch, job B of k_ransac_score_fast) was built and measured: the dispatches gain a point
+                    // of lane-op utilisation (0.667 vs 0.660 of the peak on the same box) but a batch's counts then reach the host one
+                    // dispatch later, the host prepares the next index batch with nothing queued behind it, and the call loses 11 %
+                    // end to end (19.0 vs 21.7 M hypotheses/s; profiles/r3/history/ransac_merged_dispatch.md).  Two batches in flight
+                    // (three buffer sets) would hide that for one point of utilisation - not built.
+                    const bool merge_on = getenv("TDV_RANSAC_MERGE") && atoi(getenv("TDV_RANSAC_MERGE")) == 1;     // (read per call: the tests switch it)
+                    if (!merge_on) return finish_pending(nullptr, 0);
                     return TDV_OK;                           // counts and event follow with this batch's phase 2 (finish_pending)
                 } else {
                     ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);

@@ -1,6 +1,8 @@
 """R5 parity: feature matching, hypothesis generation, inlier scoring and selection through the
 C ABI vs the CPU oracle (reference src/registration.cpp:204-295).
 Bar: correspondences exact; per-iteration inlier counts bit-exact; winner identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -345,6 +347,12 @@ def test_ransac_bailout_returns_the_reference_result(ctx, orc, synth, ns, nt, it
     got = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence)
     scored = ctx.last_ransac_scored()
     _same_result(got, ref); _same_result(traced, ref)
+    try:                                  # phase 2 riding behind the next batch's phase 1 (one dispatch per batch): same result
+        os.environ["TDV_RANSAC_MERGE"] = "1"
+        _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence), ref)
+        assert abs(ctx.last_ransac_scored() - scored) < 1e-9 or confidence < 1.0
+    finally:
+        os.environ.pop("TDV_RANSAC_MERGE", None)
     print("ns %d, %d iterations, confidence %g: %.3f of the tests scored, best %d inliers at %d" % (ns, iters, confidence, scored, got.inliers, got.best_iteration))
     assert 0.0 < scored <= 1.0
     if ns >= 2500 and good >= 0.5 and confidence > 1.0 and iters > 16384: assert scored < 0.95      # the scheme does something where it can
@@ -419,11 +427,16 @@ def test_ransac_bailout_in_batch_rule_planted_jump(ctx, orc, seed):
     corr = np.arange(ns, dtype=np.int32)
     full = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=2.0, trace=True)
     top = int(full["inliers"].max()); before = int(full["inliers"][:min(planted)].max())
-    assert top > 1.2 * before and before > ns // 5, "the planted iteration must stand out over a level that already splits the points (%d vs %d of %d)" % (top, before, ns)
+    assert top > 1.1 * before and before > ns // 5, "the planted iteration must stand out over a level that already splits the points (%d vs %d of %d)" % (top, before, ns)
     for confidence in (2.0, (before + 1) / ns * 0.5, (before + top) / 2 / ns, top / ns * 1.01):
         ref = orc.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence)), trace=True)
         got = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence)))
         scored = ctx.last_ransac_scored()
         _same_result(got, ref)
+        try:
+            os.environ["TDV_RANSAC_MERGE"] = "1"
+            _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence))), ref)
+        finally:
+            os.environ.pop("TDV_RANSAC_MERGE", None)
         print("seed %d ns %d iters %d planted %s: level %d -> %d, confidence %.3f: best %d @ %d, run %d, scored %.3f"
               % (seed, ns, iters, planted, before, top, confidence, got.inliers, got.best_iteration, got.iterations_run, scored))
