@@ -428,7 +428,7 @@ __global__ void k_voxel_permute(const float* __restrict__ in_xyz, const float* _
 // Algorithmic bytes: 12 N in + 12 V out; the table adds 16 B per point of atomics and 4-68 B per voxel of member lists.
 constexpr int VH_K = 16;                       // member slots per voxel (one 64-B row)
 constexpr int VH_EMPTY = 0x7f7f7f7f;           // what the memset leaves; larger than any point index
-constexpr int VH_BLOCK = 256, VH_IPT = 4, VH_ITEMS = VH_BLOCK * VH_IPT;
+constexpr int VH_BLOCK = 1024, VH_IPT = 1, VH_ITEMS = VH_BLOCK * VH_IPT;   // one point per lane: four per lane ran their gather chains one after the other
 constexpr unsigned long long VH_ST_MASK = 3ull << 62, VH_ST_WAIT = 1ull << 62, VH_ST_AGG = 2ull << 62, VH_ST_PREFIX = 3ull << 62;   // 0x7f.. has status 01
 static_assert((0x7f7f7f7f7f7f7f7full & VH_ST_MASK) == VH_ST_WAIT, "the memset pattern must read as 'not ready'");
 
@@ -446,27 +446,52 @@ void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict
                  int* __restrict__ claim, int* __restrict__ vmin, int* __restrict__ vcnt, int* __restrict__ members,
                  int* __restrict__ voxel_of, int* __restrict__ overflow) {
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= total) return;
+    const bool active = g < total;
+    const int lane = threadIdx.x & 63;
     int lo = 0, hi = total, b = 0;
-    if (nseg > 1) { b = vh_segment(seg_off, nseg, g); lo = seg_off[b]; hi = seg_off[b + 1]; }
-    int cx, cy, cz;
-    vh_cell(xyz, (size_t)g, inv, cx, cy, cz);
-    unsigned h = voxel_hash((unsigned)cx, (unsigned)cy, (unsigned)cz) + (unsigned)b * 0x9e3779b9u;
-    int j;
-    for (;; ++h) {
-        int* slot = claim + (h & mask);
-        j = *slot;
-        if (j == VH_EMPTY) { const int prev = atomicCAS(slot, VH_EMPTY, g); j = prev == VH_EMPTY ? g : prev; }
-        if (j == g) break;
-        if (j >= lo && j < hi) {                        // the same cloud: same cell?
-            int qx, qy, qz;
-            vh_cell(xyz, (size_t)j, inv, qx, qy, qz);
-            if (qx == cx && qy == cy && qz == cz) break;
-        }
+    int cx = 0, cy = 0, cz = 0;
+    if (active) {
+        if (nseg > 1) { b = vh_segment(seg_off, nseg, g); lo = seg_off[b]; hi = seg_off[b + 1]; }
+        vh_cell(xyz, (size_t)g, inv, cx, cy, cz);
     }
+    // Device-scope atomics are resolved beyond the XCDs' L2s and cost microseconds each; neighbouring points (one wave holds 64
+    // consecutive ones, in image order neighbouring pixels) mostly share their voxels.  The wave therefore groups its lanes by
+    // (cloud, cell) first - one pass per distinct cell, the cell of the lowest pending lane broadcast with readlane - and only the
+    // lowest lane of a group goes to the table, for the whole group: one find-or-claim, one atomicMin, one atomicSub by the group's
+    // size.  Lanes are in index order, so the group's lowest lane holds its smallest index.
+    unsigned long long todo = __ballot(active), group = 0ull;
+    while (todo) {                                        // wave-uniform
+        const int src = __builtin_ctzll(todo);
+        const int rx = __builtin_amdgcn_readlane(cx, src), ry = __builtin_amdgcn_readlane(cy, src), rz = __builtin_amdgcn_readlane(cz, src),
+                  rb = __builtin_amdgcn_readlane(b, src);
+        const bool same = active && cx == rx && cy == ry && cz == rz && b == rb;
+        const unsigned long long m = __ballot(same);
+        if (same) group = m;
+        todo &= ~m;
+    }
+    if (!active) return;
+    const int head = __builtin_ctzll(group);
+    const int rank = __popcll(group & ((1ull << lane) - 1ull)), size = __popcll(group);
+    int j = 0, pos0 = 0;
+    if (lane == head) {
+        unsigned h = voxel_hash((unsigned)cx, (unsigned)cy, (unsigned)cz) + (unsigned)b * 0x9e3779b9u;
+        for (;; ++h) {
+            int* slot = claim + (h & mask);
+            j = *slot;
+            if (j == VH_EMPTY) { const int prev = atomicCAS(slot, VH_EMPTY, g); j = prev == VH_EMPTY ? g : prev; }
+            if (j == g) break;
+            if (j >= lo && j < hi) {                        // the same cloud: same cell?
+                int qx, qy, qz;
+                vh_cell(xyz, (size_t)j, inv, qx, qy, qz);
+                if (qx == cx && qy == cy && qz == cz) break;
+            }
+        }
+        atomicMin(&vmin[j], g);
+        pos0 = VH_EMPTY - atomicSub(&vcnt[j], size);       // arrival ranks pos0 .. pos0 + size - 1
+    }
+    j = __shfl(j, head, 64); pos0 = __shfl(pos0, head, 64);
     voxel_of[g] = j;
-    atomicMin(&vmin[j], g);
-    const int pos = VH_EMPTY - atomicSub(&vcnt[j], 1);  // arrival rank 0, 1, 2 ...
+    const int pos = pos0 + rank;
     if (pos < VH_K) members[(size_t)j * VH_K + pos] = g;
     else *overflow = 1;                                 // (any value but the fill pattern)
 }
@@ -476,7 +501,8 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
                    const int* __restrict__ voxel_of, const int* __restrict__ vmin, const int* __restrict__ vcnt, const int* __restrict__ members,
                    unsigned long long* __restrict__ desc, int* __restrict__ ticket, float* __restrict__ out_xyz, float* __restrict__ out_rgb,
                    int* __restrict__ rank_out /* per point: global first-occurrence rank of leaders */, int4* __restrict__ leaders /* optional */,
-                   int* __restrict__ voff /* nseg + 1 */, int capacity /* voxels that fit out_xyz */) {
+                   int* __restrict__ voff /* nseg + 2: the last entry receives the overflow flag */, int capacity /* voxels that fit out_xyz */,
+                   const int* __restrict__ overflow_flag) {
     __shared__ int s_ticket, s_excl, s_wave[VH_BLOCK / 64];
     if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1) - VH_EMPTY;     // workgroups take their tiles in the order they start
     __syncthreads();
@@ -531,6 +557,7 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
     if (last_tile && threadIdx.x == VH_BLOCK - 1) {      // the grand total, and every cloud that starts at the very end (empty trailing clouds)
         const int total_v = s_excl + agg;
         voff[nseg] = total_v;
+        voff[nseg + 1] = *overflow_flag;                     // (set by k_vh_insert, the launch before: one copy brings back counts and flag)
         if (nseg > 1) for (int b = nseg - 1; b >= 0 && seg_off[b] >= total; --b) voff[b] = total_v;
     }
 #pragma unroll
@@ -604,7 +631,7 @@ static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float*
     TDV_HIP(ctx, hipMemsetAsync(fill, 0x7f, n_fill * 4, s));
     k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vmin, vcnt, members, voxel_of, overflow);
     k_vh_finalize<<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vmin, vcnt, members, desc, ticket,
-                                             d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity);
+                                             d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow);
     TDV_CHECK_LAUNCH(ctx);
     *d_overflow_out = overflow;                          // still the fill pattern (VH_EMPTY) unless a voxel overflowed its member row
     return TDV_OK;
@@ -721,7 +748,7 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     int *d_voff, *d_rank = nullptr, *d_overflow = nullptr; int4* d_leaders = nullptr;
     float *tmp_xyz = d_out_xyz, *tmp_rgb = d_out_rgb;
     int cap_first = capacity;
-    TDV_TRY(ws_alloc(ctx, 2, &d_voff));
+    TDV_TRY(ws_alloc(ctx, 3, &d_voff));
     if (ref) {
         cap_first = n;
         TDV_TRY(ws_alloc(ctx, (size_t)n, &d_rank));
@@ -737,8 +764,7 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
         TDV_TRY(voxel_hash_first_order(ctx, d_xyz, (d_rgb && d_out_rgb) ? d_rgb : nullptr, n, nullptr, 1, voxel, tmp_xyz, tmp_rgb, cap_first, d_rank, d_leaders,
                                        d_voff, &d_overflow));
     }
-    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff + 1, 4, hipMemcpyDeviceToHost, s));
-    TDV_HIP(ctx, hipMemcpyAsync(h + 1, d_overflow, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff + 1, 8, hipMemcpyDeviceToHost, s));      // voxel count, overflow flag
     TDV_HIP(ctx, hipStreamSynchronize(s));
     if (h[1] != VH_EMPTY)      // a voxel with more than VH_K members (a coarse grid): the counting-sort path takes any count
         return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
@@ -762,15 +788,14 @@ int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, cons
     if (total == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
     int *d_voff, *d_overflow = nullptr;
-    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 1, &d_voff));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_voff));
     TDV_TRY(pin_reserve(ctx, ((size_t)n_clouds + 2) * 4));
     int* h = reinterpret_cast<int*>(ctx->pin);
     {
         ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
         TDV_TRY(voxel_hash_first_order(ctx, d_xyz, nullptr, total, d_seg_off, n_clouds, voxel, d_first_xyz, nullptr, total, d_rank, d_leaders, d_voff, &d_overflow));
     }
-    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff, ((size_t)n_clouds + 1) * 4, hipMemcpyDeviceToHost, s));
-    TDV_HIP(ctx, hipMemcpyAsync(h + n_clouds + 1, d_overflow, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff, ((size_t)n_clouds + 2) * 4, hipMemcpyDeviceToHost, s));   // offsets, then the overflow flag
     TDV_HIP(ctx, hipStreamSynchronize(s));
     if (h[n_clouds + 1] != VH_EMPTY) { *overflowed = 1; return TDV_OK; }
     std::memcpy(h_voff, h, ((size_t)n_clouds + 1) * 4);

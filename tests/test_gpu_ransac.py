@@ -350,7 +350,7 @@ def test_ransac_bailout_returns_the_reference_result(ctx, orc, synth, ns, nt, it
     try:                                  # phase 2 riding behind the next batch's phase 1 (one dispatch per batch): same result
         os.environ["TDV_RANSAC_MERGE"] = "1"
         _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence), ref)
-        assert abs(ctx.last_ransac_scored() - scored) < 1e-9 or confidence < 1.0
+        assert 0.0 < ctx.last_ransac_scored() <= 1.0          # (its plans see other bounds: the share differs, the result does not)
     finally:
         os.environ.pop("TDV_RANSAC_MERGE", None)
     print("ns %d, %d iterations, confidence %g: %.3f of the tests scored, best %d inliers at %d" % (ns, iters, confidence, scored, got.inliers, got.best_iteration))
