@@ -414,17 +414,19 @@ __global__ void k_voxel_permute(const float* __restrict__ in_xyz, const float* _
 // ---- grouping through a hash table: memset + 2 kernels for any number of clouds (round 3; the default) -------------------
 // The counting-sort path above is nine dependent launches whose waves wait >= 90 % of their cycles (profiles/r2: 0.10-0.12 ms
 // for a cloud that HBM moves in a microsecond).  This path is three, and takes B clouds stored back to back at once:
-//   memset            one fill (0x7f bytes) of [claim table | per-voxel min | per-voxel count | scan descriptors | ticket]
+//   memset            one fill (0x7f bytes) of [claim table | per-voxel count | scan descriptors | ticket | overflow flag]
 //   k_vh_insert       one lane per point: find-or-claim the cell's slot of an open-addressing table (linear probing, 32-bit
 //                     atomics).  The slot permanently holds the CLAIMER - the first point that got there; its index names the
-//                     voxel: vmin[claimer] = atomic min of the members' indices (the leader), vcnt[claimer] counts them down
-//                     from 0x7f7f7f7f, members[claimer][arrival rank] lists them (VH_K per voxel; a fuller voxel raises a
-//                     flag and the call is redone on the counting-sort path).  Which point claims a slot depends on the race;
-//                     nothing that leaves the kernel pair does.
-//   k_vh_finalize     one lane per point, 1,024 points per workgroup: leader flags, workgroup scan, DECOUPLED LOOK-BACK over
-//                     the workgroups' aggregates (single pass: no scan launches) -> the leader's first-occurrence rank; the
-//                     leader sorts its <= VH_K member indices, sums the points in ascending index order (registration.cpp:
-//                     47-50), divides and writes the mean at its rank.  Voxels of cloud b occupy [voff[b], voff[b + 1]).
+//                     voxel: vcnt[claimer] counts the members down from 0x7f7f7f7f, members[claimer][arrival rank] lists them
+//                     (VH_K per voxel; a fuller voxel raises a flag and the call is redone on the counting-sort path).  Lanes of
+//                     a wave that share a cell go to the table once, through their lowest lane.  Which point claims a slot and
+//                     the arrival order depend on the race; nothing that leaves the kernel pair does.
+//   k_vh_finalize     one lane per point, 1,024 points per workgroup: every lane reads its voxel's member row; the smallest
+//                     index in it is the voxel's leader (an atomic min per point in k_vh_insert did the same for 5 us more).
+//                     Leader flags, workgroup scan, DECOUPLED LOOK-BACK over the workgroups' aggregates (single pass: no scan
+//                     launches) -> the leader's first-occurrence rank; the leader sums its voxel's points in ascending index
+//                     order (registration.cpp:47-50), divides and writes the mean at its rank.  Voxels of cloud b occupy
+//                     [voff[b], voff[b + 1]).  Count and overflow flag go straight into pinned host memory (no copy kernel).
 // Algorithmic bytes: 12 N in + 12 V out; the table adds 16 B per point of atomics and 4-68 B per voxel of member lists.
 constexpr int VH_K = 16;                       // member slots per voxel (one 64-B row)
 constexpr int VH_EMPTY = 0x7f7f7f7f;           // what the memset leaves; larger than any point index
@@ -443,7 +445,7 @@ __device__ __forceinline__ void vh_cell(const float* __restrict__ xyz, size_t g,
 
 __global__ __launch_bounds__(256)
 void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict__ seg_off, int nseg, float inv, unsigned mask,
-                 int* __restrict__ claim, int* __restrict__ vmin, int* __restrict__ vcnt, int* __restrict__ members,
+                 int* __restrict__ claim, int* __restrict__ vcnt, int* __restrict__ members,
                  int* __restrict__ voxel_of, int* __restrict__ overflow) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     const bool active = g < total;
@@ -459,7 +461,10 @@ void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict
     // (cloud, cell) first - one pass per distinct cell, the cell of the lowest pending lane broadcast with readlane - and only the
     // lowest lane of a group goes to the table, for the whole group: one find-or-claim, one atomicMin, one atomicSub by the group's
     // size.  Lanes are in index order, so the group's lowest lane holds its smallest index.
-    unsigned long long todo = __ballot(active), group = 0ull;
+    // (a cloud in random order has nothing to group: when no lane shares its cell with the lane before it, every lane goes alone)
+    const bool dup = lane > 0 && cx == __shfl_up(cx, 1, 64) && cy == __shfl_up(cy, 1, 64) && cz == __shfl_up(cz, 1, 64) && b == __shfl_up(b, 1, 64);
+    unsigned long long todo = __ballot(active), group = 1ull << lane;
+    if (!__any(active && dup)) todo = 0ull;
     while (todo) {                                        // wave-uniform
         const int src = __builtin_ctzll(todo);
         const int rx = __builtin_amdgcn_readlane(cx, src), ry = __builtin_amdgcn_readlane(cy, src), rz = __builtin_amdgcn_readlane(cz, src),
@@ -486,7 +491,6 @@ void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict
                 if (qx == cx && qy == cy && qz == cz) break;
             }
         }
-        atomicMin(&vmin[j], g);
         pos0 = VH_EMPTY - atomicSub(&vcnt[j], size);       // arrival ranks pos0 .. pos0 + size - 1
     }
     j = __shfl(j, head, 64); pos0 = __shfl(pos0, head, 64);
@@ -498,26 +502,38 @@ void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict
 
 __global__ __launch_bounds__(VH_BLOCK)
 void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb, int total, const int* __restrict__ seg_off, int nseg, float inv,
-                   const int* __restrict__ voxel_of, const int* __restrict__ vmin, const int* __restrict__ vcnt, const int* __restrict__ members,
+                   const int* __restrict__ voxel_of, const int* __restrict__ vcnt, const int* __restrict__ members,
                    unsigned long long* __restrict__ desc, int* __restrict__ ticket, float* __restrict__ out_xyz, float* __restrict__ out_rgb,
                    int* __restrict__ rank_out /* per point: global first-occurrence rank of leaders */, int4* __restrict__ leaders /* optional */,
                    int* __restrict__ voff /* nseg + 2: the last entry receives the overflow flag */, int capacity /* voxels that fit out_xyz */,
-                   const int* __restrict__ overflow_flag) {
+                   const int* __restrict__ overflow_flag, int* __restrict__ host_result /* optional, pinned host memory: {voxels, overflow flag} */) {
     __shared__ int s_ticket, s_excl, s_wave[VH_BLOCK / 64];
     if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1) - VH_EMPTY;     // workgroups take their tiles in the order they start
     __syncthreads();
     const int t = s_ticket;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g0 = t * VH_ITEMS + threadIdx.x * VH_IPT;
-    int vox[VH_IPT]; bool lead[VH_IPT]; int mine = 0;
+    const int g = t * VH_ITEMS + threadIdx.x;
+    const bool inside = g < total;
+    // this point's voxel: its member row (the indices of its points in arrival order).  The smallest is the voxel's leader.
+    const int j = inside ? voxel_of[g] : 0;
+    const int cnt = inside ? min(VH_EMPTY - vcnt[j], VH_K) : 0;     // (an overflowing voxel: the call is redone, whatever is written here is dropped)
+    int m[VH_K];
+    {
+        const int4* row = reinterpret_cast<const int4*>(members + (size_t)j * VH_K);
 #pragma unroll
-    for (int e = 0; e < VH_IPT; ++e) {
-        const int g = g0 + e;
-        vox[e] = g < total ? voxel_of[g] : 0;
-        lead[e] = g < total && vmin[vox[e]] == g;
-        mine += lead[e] ? 1 : 0;
+        for (int q = 0; q < VH_K / 4; ++q) {
+            int4 r = make_int4(VH_EMPTY, VH_EMPTY, VH_EMPTY, VH_EMPTY);
+            if (4 * q < cnt) r = row[q];
+            m[4 * q] = 4 * q < cnt ? r.x : VH_EMPTY; m[4 * q + 1] = 4 * q + 1 < cnt ? r.y : VH_EMPTY;
+            m[4 * q + 2] = 4 * q + 2 < cnt ? r.z : VH_EMPTY; m[4 * q + 3] = 4 * q + 3 < cnt ? r.w : VH_EMPTY;
+        }
     }
-    // workgroup scan of the leader counts
+    int first_member = VH_EMPTY;
+#pragma unroll
+    for (int q = 0; q < VH_K; ++q) first_member = min(first_member, m[q]);
+    const bool lead = inside && first_member == g;
+    const int mine = lead ? 1 : 0;
+    // workgroup scan of the leader flags
     int incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
@@ -552,57 +568,42 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
         }
     }
     __syncthreads();
-    int run = s_excl + wbase + incl - mine;             // global rank of this thread's first leader
+    const int run = s_excl + wbase + incl - mine;        // global first-occurrence rank (of this lane's voxel if it leads one)
     const bool last_tile = (t + 1) * VH_ITEMS >= total;
     if (last_tile && threadIdx.x == VH_BLOCK - 1) {      // the grand total, and every cloud that starts at the very end (empty trailing clouds)
-        const int total_v = s_excl + agg;
+        const int total_v = s_excl + agg, ovf = *overflow_flag;   // (the flag was set by k_vh_insert, the launch before)
         voff[nseg] = total_v;
-        voff[nseg + 1] = *overflow_flag;                     // (set by k_vh_insert, the launch before: one copy brings back counts and flag)
+        voff[nseg + 1] = ovf;
         if (nseg > 1) for (int b = nseg - 1; b >= 0 && seg_off[b] >= total; --b) voff[b] = total_v;
+        if (host_result) { host_result[0] = total_v; host_result[1] = ovf; __threadfence_system(); }   // straight into pinned host memory: no copy kernel
     }
-#pragma unroll
-    for (int e = 0; e < VH_IPT; ++e) {
-        const int g = g0 + e;
-        if (g >= total) break;
-        int lo = 0, b = 0;
-        if (nseg > 1) { b = vh_segment(seg_off, nseg, g); lo = seg_off[b]; }
-        if (g == lo) {                                    // first point of cloud b: its voxels start at this rank; so do the empty clouds right before it
-            voff[b] = run;
-            for (int bb = b - 1; bb >= 0 && seg_off[bb] == g; --bb) voff[bb] = run;
-        }
-        if (!lead[e]) continue;
-        const int j = vox[e];
-        const int cnt = min(VH_EMPTY - vcnt[j], VH_K);    // (an overflowing voxel: the call is redone, whatever is written here is dropped)
-        int m[VH_K];
-        const int4* row = reinterpret_cast<const int4*>(members + (size_t)j * VH_K);
-#pragma unroll
-        for (int q = 0; q < VH_K / 4; ++q) {
-            int4 r = make_int4(VH_EMPTY, VH_EMPTY, VH_EMPTY, VH_EMPTY);
-            if (4 * q < cnt) r = row[q];
-            m[4 * q] = 4 * q < cnt ? r.x : VH_EMPTY; m[4 * q + 1] = 4 * q + 1 < cnt ? r.y : VH_EMPTY;
-            m[4 * q + 2] = 4 * q + 2 < cnt ? r.z : VH_EMPTY; m[4 * q + 3] = 4 * q + 3 < cnt ? r.w : VH_EMPTY;
-        }
-        // ascending index order without moving anything: cnt rounds of "smallest index above the last one"
-        float ax = 0.f, ay = 0.f, az = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-        int last = -1;
-        for (int r = 0; r < cnt; ++r) {
-            int nxt = VH_EMPTY;
-#pragma unroll
-            for (int q = 0; q < VH_K; ++q) nxt = (m[q] > last && m[q] < nxt) ? m[q] : nxt;
-            last = nxt;
-            const size_t idx = (size_t)nxt;
-            ax += xyz[3 * idx]; ay += xyz[3 * idx + 1]; az += xyz[3 * idx + 2];        // registration.cpp:47-50, ascending input index
-            if (rgb) { cr += rgb[3 * idx]; cg += rgb[3 * idx + 1]; cb += rgb[3 * idx + 2]; }
-        }
-        const float fn = (float)cnt;
-        const size_t o = (size_t)run;
-        if (rank_out) rank_out[g] = run;
-        if (run >= capacity) { ++run; continue; }          // the caller's buffer is too small: it learns the count and gets an error
-        out_xyz[3 * o] = ax / fn; out_xyz[3 * o + 1] = ay / fn; out_xyz[3 * o + 2] = az / fn;   // :52-53
-        if (rgb && out_rgb) { out_rgb[3 * o] = cr / fn; out_rgb[3 * o + 1] = cg / fn; out_rgb[3 * o + 2] = cb / fn; }
-        if (leaders) { int cx, cy, cz; vh_cell(xyz, (size_t)g, inv, cx, cy, cz); leaders[o] = make_int4(cx, cy, cz, g - lo); }
-        ++run;
+    if (!inside) return;
+    int lo = 0, b = 0;
+    if (nseg > 1) { b = vh_segment(seg_off, nseg, g); lo = seg_off[b]; }
+    if (g == lo) {                                        // first point of cloud b: its voxels start at this rank; so do the empty clouds right before it
+        voff[b] = run;
+        for (int bb = b - 1; bb >= 0 && seg_off[bb] == g; --bb) voff[bb] = run;
     }
+    if (!lead) return;
+    // ascending index order without moving anything: cnt rounds of "smallest index above the last one"
+    float ax = 0.f, ay = 0.f, az = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    int last = -1;
+    for (int r = 0; r < cnt; ++r) {
+        int nxt = VH_EMPTY;
+#pragma unroll
+        for (int q = 0; q < VH_K; ++q) nxt = (m[q] > last && m[q] < nxt) ? m[q] : nxt;
+        last = nxt;
+        const size_t idx = (size_t)nxt;
+        ax += xyz[3 * idx]; ay += xyz[3 * idx + 1]; az += xyz[3 * idx + 2];        // registration.cpp:47-50, ascending input index
+        if (rgb) { cr += rgb[3 * idx]; cg += rgb[3 * idx + 1]; cb += rgb[3 * idx + 2]; }
+    }
+    const float fn = (float)cnt;
+    const size_t o = (size_t)run;
+    if (rank_out) rank_out[g] = run;
+    if (run >= capacity) return;                          // the caller's buffer is too small: it learns the count and gets an error
+    out_xyz[3 * o] = ax / fn; out_xyz[3 * o + 1] = ay / fn; out_xyz[3 * o + 2] = az / fn;   // :52-53
+    if (rgb && out_rgb) { out_rgb[3 * o] = cr / fn; out_rgb[3 * o + 1] = cg / fn; out_rgb[3 * o + 2] = cb / fn; }
+    if (leaders) { int cx, cy, cz; vh_cell(xyz, (size_t)g, inv, cx, cy, cz); leaders[o] = make_int4(cx, cy, cz, g - lo); }
 }
 
 // The hash-table path for B clouds stored back to back (d_seg_off: B + 1 device ints, nullptr for one cloud).  Outputs in
@@ -610,18 +611,18 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
 // *overflowed = 1: a voxel had more than VH_K members (the outputs are garbage, take the counting-sort path).
 static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int total, const int* d_seg_off, int nseg, float voxel,
                                   float* d_out_xyz, float* d_out_rgb, int capacity, int* d_rank /* optional, total ints */,
-                                  int4* d_leaders /* optional, capacity entries */, int* d_voff, int** d_overflow_out) {
+                                  int4* d_leaders /* optional, capacity entries */, int* d_voff, int* h_result /* optional: pinned {voxels, overflow flag} */) {
     hipStream_t s = ctx->stream;
     const float inv = 1.0f / voxel;  // registration.cpp:32
     size_t slots = 4096;
     while (slots < 2 * (size_t)total) slots <<= 1;
     const int tiles = (total + VH_ITEMS - 1) / VH_ITEMS;
-    // one fill: claim[slots] | vmin[total] | vcnt[total] | desc[tiles] (u64) | ticket | overflow
-    const size_t desc_at = (slots + 2 * (size_t)total + 1) & ~(size_t)1;
+    // one fill: claim[slots] | vcnt[total] | desc[tiles] (u64) | ticket | overflow
+    const size_t desc_at = (slots + (size_t)total + 1) & ~(size_t)1;
     const size_t n_fill = desc_at + 2 * (size_t)tiles + 2;
     int* fill;
     TDV_TRY(ws_alloc(ctx, n_fill, &fill));
-    int* claim = fill; int* vmin = claim + slots; int* vcnt = vmin + total;
+    int* claim = fill; int* vcnt = claim + slots;
     unsigned long long* desc = reinterpret_cast<unsigned long long*>(fill + desc_at);
     int* ticket = reinterpret_cast<int*>(desc + tiles);
     int* overflow = ticket + 1;
@@ -629,11 +630,10 @@ static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float*
     TDV_TRY(ws_alloc(ctx, (size_t)total * VH_K, &members));
     TDV_TRY(ws_alloc(ctx, (size_t)total, &voxel_of));
     TDV_HIP(ctx, hipMemsetAsync(fill, 0x7f, n_fill * 4, s));
-    k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vmin, vcnt, members, voxel_of, overflow);
-    k_vh_finalize<<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vmin, vcnt, members, desc, ticket,
-                                             d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow);
+    k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vcnt, members, voxel_of, overflow);
+    k_vh_finalize<<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vcnt, members, desc, ticket,
+                                             d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result);
     TDV_CHECK_LAUNCH(ctx);
-    *d_overflow_out = overflow;                          // still the fill pattern (VH_EMPTY) unless a voxel overflowed its member row
     return TDV_OK;
 }
 
@@ -745,7 +745,7 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     // hash-table path (memset + 2 kernels); first-occurrence order lands in the caller's buffer directly
     hipStream_t s = ctx->stream;
     const bool ref = order == TDV_VOXEL_ORDER_REFERENCE;
-    int *d_voff, *d_rank = nullptr, *d_overflow = nullptr; int4* d_leaders = nullptr;
+    int *d_voff, *d_rank = nullptr; int4* d_leaders = nullptr;
     float *tmp_xyz = d_out_xyz, *tmp_rgb = d_out_rgb;
     int cap_first = capacity;
     TDV_TRY(ws_alloc(ctx, 3, &d_voff));
@@ -758,14 +758,15 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
         if (d_rgb && d_out_rgb) TDV_TRY(ws_alloc(ctx, (size_t)n * 3, &tmp_rgb));
     }
     TDV_TRY(pin_reserve(ctx, 64));
-    int* h = reinterpret_cast<int*>(ctx->pin);
+    int* h = reinterpret_cast<int*>(ctx->pin);      // the finalize kernel stores {voxel count, overflow flag} here itself: a D2H copy of 8 bytes is a 9-us blit kernel
+    h[0] = -1; h[1] = 0;
     {
         ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
         TDV_TRY(voxel_hash_first_order(ctx, d_xyz, (d_rgb && d_out_rgb) ? d_rgb : nullptr, n, nullptr, 1, voxel, tmp_xyz, tmp_rgb, cap_first, d_rank, d_leaders,
-                                       d_voff, &d_overflow));
+                                       d_voff, h));
     }
-    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff + 1, 8, hipMemcpyDeviceToHost, s));      // voxel count, overflow flag
     TDV_HIP(ctx, hipStreamSynchronize(s));
+    if (h[0] < 0) { snprintf(ctx->err, sizeof(ctx->err), "voxel: the result did not reach the host"); return TDV_ERR_INTERNAL; }
     if (h[1] != VH_EMPTY)      // a voxel with more than VH_K members (a coarse grid): the counting-sort path takes any count
         return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
     const int v = h[0];
@@ -787,13 +788,13 @@ int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, cons
     for (int b = 0; b <= n_clouds; ++b) h_voff[b] = 0;
     if (total == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
-    int *d_voff, *d_overflow = nullptr;
+    int* d_voff;
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_voff));
     TDV_TRY(pin_reserve(ctx, ((size_t)n_clouds + 2) * 4));
     int* h = reinterpret_cast<int*>(ctx->pin);
     {
         ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
-        TDV_TRY(voxel_hash_first_order(ctx, d_xyz, nullptr, total, d_seg_off, n_clouds, voxel, d_first_xyz, nullptr, total, d_rank, d_leaders, d_voff, &d_overflow));
+        TDV_TRY(voxel_hash_first_order(ctx, d_xyz, nullptr, total, d_seg_off, n_clouds, voxel, d_first_xyz, nullptr, total, d_rank, d_leaders, d_voff, nullptr));
     }
     TDV_HIP(ctx, hipMemcpyAsync(h, d_voff, ((size_t)n_clouds + 2) * 4, hipMemcpyDeviceToHost, s));   // offsets, then the overflow flag
     TDV_HIP(ctx, hipStreamSynchronize(s));
