@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
     "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii", "tdv_load_mask_png", "tdv_load_masks_from_dir",
-    "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results", "tdv_mask_resize_nearest", "tdv_mask_resize_nearest_dev",
+    "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results", "tdv_mask_resize_nearest", "tdv_mask_resize_nearest_dev", "tdv_voxel_downsample_batch_dev",
 ]
 
 
@@ -416,6 +416,15 @@ class Context:
         return m.value
 
 
+def _voxel_downsample_batch_dev(self, d_xyz, cloud_offsets, voxel, d_out_xyz):
+    """All clouds' voxels (first-occurrence order) in one set of launches; returns the voxel offsets (int32 [n_clouds + 1])."""
+    off = np.ascontiguousarray(cloud_offsets, np.int32)
+    voff = np.zeros(len(off), np.int32)
+    _check(self._h, lib().tdv_voxel_downsample_batch_dev(self._h, _ptr(d_xyz), _ptr(off), len(off) - 1, C.c_float(voxel), _ptr(d_out_xyz), _ptr(voff)),
+           "tdv_voxel_downsample_batch_dev")
+    return voff
+
+
 def batch_params(width=1280, height=720, scale_to_meters=1000.0, mask_mode=TDV_MASK_THRESHOLD10, fx=900.0, fy=900.0, cx=640.0,
                  cy=360.0, zmax=1.5, voxel_size=0.001, normals_k=30, fpfh_radius_factor=5.0, ransac_max_iterations=100000,
                  ransac_confidence=0.999, icp_distance_factor=0.4, icp_max_iterations=200, point_to_plane=True, seed=42,
@@ -485,6 +494,7 @@ Context.depth_to_cloud_batch_dev = _depth_to_cloud_batch_dev
 Context.broadcast_model = _broadcast_model
 Context.gather_results = _gather_results
 Context.register_batch_dev = _register_batch_dev
+Context.voxel_downsample_batch_dev = _voxel_downsample_batch_dev
 Context.prepare_model_dev = _prepare_model_dev
 
 

@@ -68,6 +68,35 @@ int tdv_bilateral_filter(tdv_ctx* ctx, const float* depth, int width, int height
     return finish(ctx);
 }
 
+int tdv_voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size,
+                                   float* d_out_xyz, int* h_voxel_offsets) {
+    if (!h_cloud_offsets || !h_voxel_offsets || n_clouds < 0) return TDV_ERR_BAD_ARG;
+    TDV_TRY(begin(ctx));
+    h_voxel_offsets[0] = 0;
+    if (n_clouds == 0) return TDV_OK;
+    for (int b = 0; b < n_clouds; ++b) if (h_cloud_offsets[b] > h_cloud_offsets[b + 1] || h_cloud_offsets[b] < 0) return TDV_ERR_BAD_ARG;
+    const int total = h_cloud_offsets[n_clouds];
+    if (h_cloud_offsets[0] != 0 || (total > 0 && (!d_xyz || !d_out_xyz))) return TDV_ERR_BAD_ARG;
+    int* d_off;
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 1, &d_off));
+    TDV_HIP(ctx, hipMemcpyAsync(d_off, h_cloud_offsets, ((size_t)n_clouds + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    int overflowed = 0;
+    TDV_TRY(voxel_downsample_batch_dev(ctx, d_xyz, total, d_off, n_clouds, voxel_size, d_out_xyz, nullptr, nullptr, h_voxel_offsets, &overflowed));
+    if (!overflowed) return TDV_OK;
+    // a voxel with more points than the table's member rows hold (a coarse grid): cloud by cloud on the path without that limit
+    int at = 0;
+    for (int b = 0; b < n_clouds; ++b) {
+        const int n = h_cloud_offsets[b + 1] - h_cloud_offsets[b];
+        int v = 0;
+        h_voxel_offsets[b] = at;
+        if (n > 0) TDV_TRY(voxel_downsample_dev(ctx, d_xyz + (size_t)h_cloud_offsets[b] * 3, nullptr, n, voxel_size, TDV_VOXEL_ORDER_FIRST, d_out_xyz + (size_t)at * 3, nullptr, n, &v));
+        at += v;
+    }
+    h_voxel_offsets[n_clouds] = at;
+    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TDV_OK;
+}
+
 int tdv_mask_resize_nearest(tdv_ctx* ctx, const uint8_t* masks, int n_masks, int src_width, int src_height, int dst_width, int dst_height, uint8_t* out) {
     if (n_masks < 0 || src_width <= 0 || src_height <= 0 || dst_width < 0 || dst_height < 0) return TDV_ERR_BAD_ARG;
     TDV_TRY(begin(ctx));

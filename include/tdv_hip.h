@@ -260,6 +260,14 @@ int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d
 int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int n, float voxel_size, int order,
                              float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out /* host */);
 
+/* Registration::voxelDownsample (src/registration.cpp:29-60) for n_clouds clouds stored back to back at d_xyz (cloud b =
+ * points [h_cloud_offsets[b], h_cloud_offsets[b+1]); host array of n_clouds + 1 entries starting at 0), in ONE set of launches:
+ * cloud b's voxels, in first-occurrence order (TDV_VOXEL_ORDER_FIRST), come back at [h_voxel_offsets[b], h_voxel_offsets[b+1])
+ * of d_out_xyz, which has room for as many points as d_xyz holds.  Means are the reference's (f32 sums in ascending input
+ * index).  What tdv_register_batch_dev runs for its instances. */
+int tdv_voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size,
+                                   float* d_out_xyz, int* h_voxel_offsets);
+
 /* ---- batched, device-resident Pipeline::processInstance ------------------------
  * One call runs the whole per-instance chain of src/pipeline.cpp:25-150 for n_instances masks that
  * share one depth/colour frame and one prepared reference model, without returning to the host

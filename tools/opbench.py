@@ -109,8 +109,8 @@ def cloud_ops(ctx, tdv, synth, torch, dev, n, reps=3, want_match=True):
     def f():
         m[0] = ctx.voxel_downsample_dev(d_xyz.data_ptr(), None, n, spacing * 1.5, d_out.data_ptr(), None, n)
     wall = median_ms(f, torch, reps=reps)
-    out.append(hbm(dict(op="voxel_downsample", workload="%d points -> %d voxels (first-occurrence order)" % (n, m[0]), ms=wall,
-                        note="12N in + 12V out; the grouping itself moves 16-B records twice more"), 12 * n + 12 * m[0], wall))
+    out.append(hbm(dict(op="voxel_downsample", workload="%d points in RANDOM order -> %d voxels (first-occurrence order)" % (n, m[0]), ms=wall,
+                        note="hash-table grouping: memset + 2 kernels; 12 N in + 12 V out; frac from the wall time of the call"), 12 * n + 12 * m[0], wall))
     d_nrm = torch.empty_like(d_xyz)
     wall = median_ms(lambda: ctx.estimate_normals_dev(d_xyz.data_ptr(), n, 30, d_nrm.data_ptr()), torch, reps=reps)
     out.append(pruned(dict(op="estimate_normals_k30", workload="%d points" % n, ms=wall), 9.0 * n * n, wall, "kNN, one wave per query"))
@@ -173,33 +173,90 @@ def icp_c2(ctx, tdv, synth, torch, dev, reps=3):
     return out
 
 
-def c4_batch(ctx, tdv, synth, torch, dev, instances=16, voxel_px=1.2, hyps=10000):
+def voxel_image_order(ctx, tdv, synth, torch, dev, reps=5):
+    """voxelDownsample as processInstance meets it (src/pipeline.cpp:92): the cloud of a masked depth frame in row-major pixel order
+    (neighbouring points share voxels), one instance and 256 instances in one set of launches."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     bb = importlib.import_module("bench_batch")
-    order = tdv.TDV_VOXEL_ORDER_REFERENCE
-    wl = bb.build_workload(tdv, synth, ctx, instances, voxel_px, 448, 3, order, dev)
-    d_mx, d_mn, d_mf, nm = wl["model"]
-    prm = tdv.batch_params(width=bb.W, height=bb.H, scale_to_meters=bb.SCALE, fx=bb.F, fy=bb.F, cx=bb.CX, cy=bb.CY, zmax=bb.ZMAX, voxel_size=wl["voxel"],
-                           ransac_max_iterations=hyps, icp_max_iterations=50, voxel_order=order, n_frames=instances)
-    res = [None]
+    B = 256
+    px = bb.DIST / bb.F
+    part = synth.ReliefPart(3, L=448 * px, W=448 * px, feature=6.0 * 1.2 * px, density=0.09)
+    dense = torch.from_numpy(part.surface_points(px / 2.5)).to(dev)
+    d_depth, d_mask = synth.render_depth_torch(dense, synth.instance_pose(0, bb.DIST, 30.0), bb.F, bb.F, bb.CX, bb.CY, bb.W, bb.H, bb.SCALE)
+    n_px = int((d_mask > 0).sum())
+    d_one = torch.empty((n_px, 3), dtype=torch.float32, device=dev)
+    n = ctx.depth_to_cloud_dev(d_depth.data_ptr(), d_mask.data_ptr(), None, bb.W, bb.H, bb.SCALE, bb.F, bb.F, bb.CX, bb.CY, bb.ZMAX, d_one.data_ptr(), None, n_px)
+    voxel = 1.2 * px
+    d_out = torch.empty_like(d_one)
+    m = [0]
 
     def f():
-        res[0] = ctx.register_batch_dev(wl["depth"].data_ptr(), None, wl["masks"].data_ptr(), instances, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
-    wall = median_ms(f, torch, reps=3)
-    ang = max(synth.pose_error(r["T"], T)[0] for r, T in zip(res[0], wl["T_gt"]))
-    return [dict(op="register_batch", workload="C4 sample: %d distinct instances (~%d px masks, %d voxels) vs a %d-point model, %d hypotheses + ICP each, reference voxel order"
-                 % (instances, int(np.mean(wl["mask_px"])), int(np.mean([r["n_voxels"] for r in res[0]])), nm, hyps),
-                 ms=wall, instances_per_s=instances / (wall * 1e-3), ms_per_instance=wall / instances, max_angle_to_ground_truth_rad=ang,
-                 icp_iterations_per_instance=float(np.mean([r["icp_iterations"] for r in res[0]])), bound="chain of the operators above")]
+        m[0] = ctx.voxel_downsample_dev(d_one.data_ptr(), None, n, voxel, d_out.data_ptr(), None, n)
+    wall, kms, _ = kernel_ms(ctx, tdv.TIMER_VOXEL, f, torch, reps=reps, warm=2)
+    out = [hbm(dict(op="voxel_downsample", workload="one instance cloud in pixel order: %d points -> %d voxels (first-occurrence order)" % (n, m[0]), ms=wall, kernels_ms=kms,
+                    note="hash-table grouping: memset + 2 kernels; algorithmic bytes 12 N in + 12 V out; frac from the kernels' time"), 12 * n + 12 * m[0], kms)]
+    d_all = d_one[:n].repeat(B, 1).contiguous()                # 256 instance clouds back to back (the same cloud: the table sees them as 256 clouds)
+    d_allout = torch.empty_like(d_all)
+    off = np.arange(B + 1, dtype=np.int32) * n
+    voff = [None]
+
+    def g():
+        voff[0] = ctx.voxel_downsample_batch_dev(d_all.data_ptr(), off, voxel, d_allout.data_ptr())
+    wall, kms, _ = kernel_ms(ctx, tdv.TIMER_VOXEL, g, torch, reps=3, warm=2)
+    v = int(voff[0][-1])
+    assert v == B * m[0], (v, B, m[0])
+    out.append(hbm(dict(op="voxel_downsample_batch", workload="%d instance clouds of %d points in ONE set of launches -> %d voxels" % (B, n, v), ms=wall, kernels_ms=kms,
+                        us_per_instance=wall * 1e3 / B, note="what tdv_register_batch_dev runs for its instances; frac from the kernels' time"),
+                   12.0 * B * n + 12.0 * v, kms))
+    return out
+
+
+def c4_batch(ctx, tdv, synth, torch, dev, instances=256, voxel_px=1.2, hyps=10000, reps=2):
+    """Config C4 at its own size: `instances` DISTINCT instances (own pose, own frame, own ~190k-pixel mask) through ONE
+    tdv_register_batch_dev call, in the reference's voxel order and in first-occurrence order."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    bb = importlib.import_module("bench_batch")
+    out = []
+    wl = None
+    for order, name in ((tdv.TDV_VOXEL_ORDER_REFERENCE, "reference"), (tdv.TDV_VOXEL_ORDER_FIRST, "first-occurrence")):
+        if wl is None:
+            wl = bb.build_workload(tdv, synth, ctx, instances, voxel_px, 448, 3, order, dev)
+        else:                                                   # same frames; the model in the other voxel order
+            wl = dict(wl, model=bb.build_workload(tdv, synth, ctx, 1, voxel_px, 448, 3, order, dev)["model"])
+        d_mx, d_mn, d_mf, nm = wl["model"]
+        prm = tdv.batch_params(width=bb.W, height=bb.H, scale_to_meters=bb.SCALE, fx=bb.F, fy=bb.F, cx=bb.CX, cy=bb.CY, zmax=bb.ZMAX, voxel_size=wl["voxel"],
+                               ransac_max_iterations=hyps, icp_max_iterations=50, voxel_order=order, n_frames=instances)
+        res = [None]
+
+        def f():
+            res[0] = ctx.register_batch_dev(wl["depth"].data_ptr(), None, wl["masks"].data_ptr(), instances, prm, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), nm)
+        wall = median_ms(f, torch, reps=reps, warm=1)
+        ang = max(synth.pose_error(r["T"], T)[0] for r, T in zip(res[0], wl["T_gt"]))
+        out.append(dict(op="register_batch", workload="C4: %d distinct instances (~%d px masks, %d voxels) vs a %d-point model, %d hypotheses + ICP each, %s voxel order"
+                        % (instances, int(np.mean(wl["mask_px"])), int(np.mean([r["n_voxels"] for r in res[0]])), nm, hyps, name),
+                        ms=wall, instances_per_s=instances / (wall * 1e-3), ms_per_instance=wall / instances, max_angle_to_ground_truth_rad=ang,
+                        icp_iterations_per_instance=float(np.mean([r["icp_iterations"] for r in res[0]])),
+                        workspace_high_water_MiB=ctx.workspace_high_water() / 2 ** 20, bound="chain of the operators above"))
+    return out
+
+
+def c5_batch(ctx, tdv, synth, torch, dev, instances=1024):
+    """Config C5, one rank's share: 1,024 instances cut by one uint16 label image from one frame (tools/c5_tray.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    c5 = importlib.import_module("c5_tray")
+    out, _, _ = c5.measure(tdv, synth, ctx, torch, dev, instances, reps=2)
+    return [out]
 
 
 def measure_all(ctx, tdv, synth, torch, dev, quick=False):
     out = []
     out += depth_ops(ctx, tdv, torch, dev)
+    out += voxel_image_order(ctx, tdv, synth, torch, dev)
     for n in ([100000] if quick else [100000, 200000]):
         out += cloud_ops(ctx, tdv, synth, torch, dev, n)
     out += relief_match(ctx, tdv, synth, torch, dev, 1.45)   # C3's size (~110k x 110k)
     out += relief_match(ctx, tdv, synth, torch, dev, 1.2)    # C4's size (~143k x 151k)
     out += icp_c2(ctx, tdv, synth, torch, dev)
-    out += c4_batch(ctx, tdv, synth, torch, dev, instances=8 if quick else 16)
+    out += c4_batch(ctx, tdv, synth, torch, dev, instances=16 if quick else 256)
+    out += c5_batch(ctx, tdv, synth, torch, dev, instances=128 if quick else 1024)
     return out
