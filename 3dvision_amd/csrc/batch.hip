@@ -92,20 +92,33 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     const bool want_ref = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE;
     std::vector<int> voff((size_t)n_instances + 1, 0);
     float* vox_first_all = nullptr; int* vox_rank_all = nullptr; int4* vox_leaders_all = nullptr;
+    float* vox_ref_all = nullptr; int *vox_r2f_all = nullptr, *vox_f2r_all = nullptr;
+    std::vector<int> ref_failed((size_t)n_instances, 1);        // 1: this instance's reference order is (still) to be made by the host replay
     bool batched_voxel = false;
     const int total_pts = off[n_instances];
     if (batched_voxel_env && total_pts > 0 && !getenv("TDV_VOXEL_LEGACY") && !getenv("TDV_VOXEL_SORT")) {
         TDV_TRY(ws_alloc(ctx, (size_t)total_pts * 3, &vox_first_all));
         if (want_ref) { TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_rank_all)); TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_leaders_all)); }
-        int* d_off_inst;
+        int *d_off_inst, *d_voff;
         TDV_TRY(ws_alloc(ctx, (size_t)n_instances + 1, &d_off_inst));
+        TDV_TRY(ws_alloc(ctx, (size_t)n_instances + 2, &d_voff));
         TDV_HIP(ctx, hipMemcpyAsync(d_off_inst, off.data(), ((size_t)n_instances + 1) * 4, hipMemcpyHostToDevice, ctx->stream));   // (off outlives the call's sync below)
         const WsMark vmark = ws_mark(ctx);                   // the table and member rows are scratch: given back after the call
         int overflowed = 0;
         TDV_TRY(voxel_downsample_batch_dev(ctx, all_xyz, total_pts, d_off_inst, n_instances, prm->voxel_size, vox_first_all, vox_rank_all, vox_leaders_all,
-                                           voff.data(), &overflowed));
+                                           voff.data(), &overflowed, d_voff));
         ws_rewind(ctx, vmark);
         batched_voxel = !overflowed;
+        // ... and their reference order, on the device too (the host replay stays as the fall-back of a cloud whose hash degenerates)
+        static const bool device_order_env = !(getenv("TDV_VOXEL_DEVICE_ORDER") && atoi(getenv("TDV_VOXEL_DEVICE_ORDER")) == 0);   // A/B knob
+        if (batched_voxel && want_ref && device_order_env && voff[n_instances] > 0) {
+            const size_t tv = (size_t)voff[n_instances];
+            TDV_TRY(ws_alloc(ctx, tv * 3, &vox_ref_all));
+            TDV_TRY(ws_alloc(ctx, tv, &vox_r2f_all));
+            TDV_TRY(ws_alloc(ctx, tv, &vox_f2r_all));
+            TDV_TRY(voxel_reference_order_batch_dev(ctx, n_instances, voff.data(), d_voff, vox_leaders_all, vox_first_all, vox_ref_all, vox_r2f_all, vox_f2r_all,
+                                                    ref_failed.data()));
+        }
     }
     // one instance: voxel -> normals + FPFH -> match -> RANSAC -> ICP on context c (its stream, its workspace)
     auto run_instance = [&](tdv_ctx* c, int b) -> int {
@@ -130,7 +143,10 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
             v = voff[b + 1] - voff[b];
             float* first = vox_first_all + (size_t)voff[b] * 3;
             if (!want_ref) vx = first;
-            else {
+            else if (vox_ref_all && !ref_failed[b]) {           // ordered on the device with the rest of the batch
+                vx = vox_ref_all + (size_t)voff[b] * 3;
+                if (coherent) both = VoxelBothOrders{first, vox_r2f_all + voff[b], vox_f2r_all + voff[b]};
+            } else {
                 TDV_TRY(ws_alloc(c, (size_t)v * 3, &vx));
                 if (coherent) {
                     both.first_xyz = first;

@@ -178,7 +178,10 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
 
 // batch: every cloud's voxels in first-occurrence order with one memset + two launches (voxel.hip); the reference order per cloud
 int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, const int* d_seg_off, int n_clouds, float voxel,
-                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed);
+                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed, int* d_voff_keep = nullptr);
+// the reference's container order of every cloud of a batch, computed on the device (voxel.hip); h_failed[b] != 0: finish cloud b with voxel_reference_order
+int voxel_reference_order_batch_dev(tdv_ctx* ctx, int n_clouds, const int* h_voff, const int* d_voff, const int4* d_leaders, const float* d_first_xyz,
+                                    float* d_out_xyz, int* d_ref2first, int* d_first2ref, int* h_failed);
 int voxel_reference_order(tdv_ctx* ctx, int v, int n, const int4* d_leaders, const float* tmp_xyz, const float* tmp_rgb, const int* d_rank, int rank_base,
                           float* d_out_xyz, float* d_out_rgb, const VoxelBothOrders* both);
 

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 #include <algorithm>
@@ -776,20 +777,166 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     return voxel_reference_order(ctx, v, n, d_leaders, tmp_xyz, tmp_rgb, d_rank, 0, d_out_xyz, d_out_rgb, both);
 }
 
+// ---- the reference's container order ON THE DEVICE, for all clouds of a batch (round 3) ---------------------------------
+// What the host replay above computes node by node has a closed form per rehash period.  Between two rehashes libstdc++ puts a
+// new node at the FRONT of its bucket's run, and a bucket that was empty at the FRONT of the whole list (_M_insert_bucket_begin);
+// a rehash walks the list front to back and re-inserts every node by the same rule (_M_rehash_aux).  So after a period with
+// bucket count B the list is the REVERSE of: the period's insertion sequence - the previous list front to back, then the new
+// keys in input order - grouped stably by bucket (code mod B), groups in order of first appearance.  With s(e) = position of
+// element e in that sequence (its previous rank, or its own index if it is new: the previous list holds exactly the elements
+// before it), first(b) = smallest s in bucket b, and F = the bucket sizes written at their first positions:
+//     rank(e) = m - 1 - ( exclusive_scan(F)[first(bucket(e))] + #{x in bucket(e) : s(x) < s(e)} ),        m = elements so far
+// One period = one memset + 3 small kernels + a scan over ALL clouds of the batch; ~17 periods reach 170k voxels (the bucket
+// counts 13, 29, 59, 127 ... are libstdc++'s, taken from its own _Prime_rehash_policy on the host: they depend on the element
+// count only).  Buckets hold their members' s in rows of RO_K; a fuller bucket (a degenerate hash) flags its cloud, which is then
+// finished by the host replay.  No leader leaves the device, the lanes of the batch never wait for the host.
+constexpr int RO_K = 16;
+__global__ void k_ro_codes(const int4* __restrict__ leaders, int total_v, unsigned long long* __restrict__ code) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total_v) return;
+    const int4 l = leaders[p];
+    // VoxelKeyHash (registration.cpp:20-27) with std::hash<int> = the value converted to size_t
+    unsigned long long h = (unsigned long long)(long long)l.x;
+    h ^= (unsigned long long)(long long)l.y + 0x9e3779b9ull + (h << 6) + (h >> 2);
+    h ^= (unsigned long long)(long long)l.z + 0x9e3779b9ull + (h << 6) + (h >> 2);
+    code[p] = h;
+}
+// grid (ceil(n_next / 256), clouds).  A cloud takes part in the period while it has elements past n_k; m = its elements so far.
+__global__ __launch_bounds__(256)
+void k_ro_insert(const unsigned long long* __restrict__ code, const int* __restrict__ rank, const int* __restrict__ voff, int n_k, int n_next, unsigned nb,
+                 int* __restrict__ fmax, int* __restrict__ cnt, int* __restrict__ rows, int* __restrict__ overflow) {
+    const int b = blockIdx.y, v0 = voff[b], v = voff[b + 1] - v0;
+    if (v <= n_k) return;
+    const int m = min(v, n_next), e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m) return;
+    const size_t P = (size_t)v0 + e;
+    const int s = e < n_k ? rank[P] : e;
+    const size_t slot = (size_t)b * nb + (size_t)(code[P] % (unsigned long long)nb);
+    atomicMax(&fmax[slot], 0x7fffffff - s);                // first(b) = 0x7fffffff - fmax: a zero fill initialises it
+    const int pos = atomicAdd(&cnt[slot], 1);
+    if (pos < RO_K) rows[slot * RO_K + pos] = s; else overflow[b] = 1;
+}
+__global__ __launch_bounds__(256)
+void k_ro_first_sizes(const int* __restrict__ voff, int n_k, int n_next, unsigned nb, const int* __restrict__ fmax, const int* __restrict__ cnt, int* __restrict__ F) {
+    const int b = blockIdx.y;
+    if (voff[b + 1] - voff[b] <= n_k) return;
+    const unsigned k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nb) return;
+    const size_t slot = (size_t)b * nb + k;
+    const int c = cnt[slot];
+    if (c) F[(size_t)b * n_next + (0x7fffffff - fmax[slot])] = c;
+}
+__global__ __launch_bounds__(256)
+void k_ro_rank(const unsigned long long* __restrict__ code, int* __restrict__ rank, const int* __restrict__ voff, int n_k, int n_next, unsigned nb,
+               const int* __restrict__ fmax, const int* __restrict__ cnt, const int* __restrict__ rows, const int* __restrict__ S) {
+    const int b = blockIdx.y, v0 = voff[b], v = voff[b + 1] - v0;
+    if (v <= n_k) return;
+    const int m = min(v, n_next), e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m) return;
+    const size_t P = (size_t)v0 + e;
+    const int s = e < n_k ? rank[P] : e;
+    const size_t slot = (size_t)b * nb + (size_t)(code[P] % (unsigned long long)nb);
+    const int first = 0x7fffffff - fmax[slot], c = min(cnt[slot], RO_K);
+    int before = S[(size_t)b * n_next + first] - S[(size_t)b * n_next];
+    const int* row = rows + slot * RO_K;
+    for (int q = 0; q < c; ++q) before += row[q] < s ? 1 : 0;
+    rank[P] = m - 1 - before;                                // in place: a lane reads and writes only its own element's rank
+}
+// out[voff[b] + rank] = first-order voxel; the permutation both ways (positions local to the cloud)
+__global__ __launch_bounds__(256)
+void k_ro_permute(const float* __restrict__ first_xyz, const int* __restrict__ rank, const int* __restrict__ voff, const int* __restrict__ skip,
+                  float* __restrict__ out_xyz, int* __restrict__ ref2first, int* __restrict__ first2ref) {
+    const int b = blockIdx.y, v0 = voff[b], v = voff[b + 1] - v0, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= v || skip[b]) return;
+    const size_t P = (size_t)v0 + e, O = (size_t)v0 + rank[P];
+    out_xyz[3 * O] = first_xyz[3 * P]; out_xyz[3 * O + 1] = first_xyz[3 * P + 1]; out_xyz[3 * O + 2] = first_xyz[3 * P + 2];
+    if (ref2first) { ref2first[O] = e; first2ref[P] = (int)(O - v0); }
+}
+
+#if TDV_HAVE_LIBSTDCXX_EMULATION
+// (first element index, bucket count) of every rehash period a container of up to n_max elements goes through, from the
+// library's own policy object
+static void rehash_schedule(int n_max, std::vector<std::pair<int, unsigned>>& out) {
+    static std::mutex mu; static std::vector<std::pair<int, unsigned>> cache; static int cached_to = 0;
+    static std::__detail::_Prime_rehash_policy policy; static size_t buckets = 1;
+    std::lock_guard<std::mutex> lock(mu);
+    for (; cached_to < n_max; ++cached_to) {
+        const auto rh = policy._M_need_rehash(buckets, (size_t)cached_to, 1);
+        if (rh.first) { buckets = rh.second; cache.emplace_back(cached_to, (unsigned)buckets); }
+    }
+    out.clear();
+    for (auto& p : cache) if (p.first < n_max) out.push_back(p);
+}
+#endif
+
+// Reference order of every cloud of a batch on the device.  d_leaders / d_first_xyz / outputs are indexed by global first-
+// occurrence position (cloud b at [h_voff[b], h_voff[b + 1])); d_voff: the same offsets on the device.  h_failed[b] = 1: a
+// bucket of cloud b overflowed its row (or this build has no libstdc++): its slice of the outputs is untouched, the caller
+// finishes it with voxel_reference_order.
+int voxel_reference_order_batch_dev(tdv_ctx* ctx, int n_clouds, const int* h_voff, const int* d_voff, const int4* d_leaders, const float* d_first_xyz,
+                                    float* d_out_xyz, int* d_ref2first, int* d_first2ref, int* h_failed) {
+    for (int b = 0; b < n_clouds; ++b) h_failed[b] = TDV_HAVE_LIBSTDCXX_EMULATION ? 0 : 1;
+#if TDV_HAVE_LIBSTDCXX_EMULATION
+    const int total_v = h_voff[n_clouds];
+    if (total_v == 0) return TDV_OK;
+    int v_max = 0;
+    for (int b = 0; b < n_clouds; ++b) v_max = std::max(v_max, h_voff[b + 1] - h_voff[b]);
+    std::vector<std::pair<int, unsigned>> sched;
+    rehash_schedule(v_max, sched);
+    hipStream_t s = ctx->stream;
+    unsigned long long* code; int *rank, *d_overflow;
+    TDV_TRY(ws_alloc(ctx, (size_t)total_v, &code));
+    TDV_TRY(ws_alloc(ctx, (size_t)total_v, &rank));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds, &d_overflow));
+    TDV_HIP(ctx, hipMemsetAsync(d_overflow, 0, (size_t)n_clouds * 4, s));
+    k_ro_codes<<<(total_v + 255) / 256, 256, 0, s>>>(d_leaders, total_v, code);
+    const WsMark mark = ws_mark(ctx);
+    ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
+    for (size_t k = 0; k < sched.size(); ++k) {
+        const int n_k = sched[k].first, n_next = std::min(k + 1 < sched.size() ? sched[k + 1].first : v_max, v_max);
+        const unsigned nb = sched[k].second;
+        ws_rewind(ctx, mark);                                  // every period reuses the same scratch (stream order keeps them apart)
+        const size_t n_tab = (size_t)n_clouds * nb, n_F = (size_t)n_clouds * n_next;
+        if (n_F + 1 > 0x7fffffffull) { for (int b = 0; b < n_clouds; ++b) h_failed[b] = 1; return TDV_OK; }   // (beyond the 32-bit scan: host replay)
+        int *zero, *rows, *S, *d_tot;
+        TDV_TRY(ws_alloc(ctx, 2 * n_tab + n_F, &zero));       // fmax | cnt | F: one fill
+        TDV_TRY(ws_alloc(ctx, n_tab * RO_K, &rows));
+        TDV_TRY(ws_alloc(ctx, n_F, &S));
+        TDV_TRY(ws_alloc(ctx, 1, &d_tot));
+        int *fmax = zero, *cnt = zero + n_tab, *F = zero + 2 * n_tab;
+        TDV_HIP(ctx, hipMemsetAsync(zero, 0, (2 * n_tab + n_F) * 4, s));
+        const dim3 ge((n_next + 255) / 256, n_clouds), gb((nb + 255) / 256, n_clouds);
+        k_ro_insert<<<ge, 256, 0, s>>>(code, rank, d_voff, n_k, n_next, nb, fmax, cnt, rows, d_overflow);
+        k_ro_first_sizes<<<gb, 256, 0, s>>>(d_voff, n_k, n_next, nb, fmax, cnt, F);
+        TDV_TRY(exclusive_scan_dev(ctx, F, (int)n_F, S, d_tot));
+        k_ro_rank<<<ge, 256, 0, s>>>(code, rank, d_voff, n_k, n_next, nb, fmax, cnt, rows, S);
+        TDV_CHECK_LAUNCH(ctx);
+    }
+    k_ro_permute<<<dim3((v_max + 255) / 256, n_clouds), 256, 0, s>>>(d_first_xyz, rank, d_voff, d_overflow, d_out_xyz, d_ref2first, d_first2ref);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_TRY(pin_reserve(ctx, (size_t)n_clouds * 4));
+    TDV_HIP(ctx, hipMemcpyAsync(ctx->pin, d_overflow, (size_t)n_clouds * 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    std::memcpy(h_failed, ctx->pin, (size_t)n_clouds * 4);
+    ws_rewind(ctx, mark);
+#endif
+    return TDV_OK;
+}
+
 // All clouds of a batch at once (first-occurrence order; the reference order is finished per cloud with
 // voxel_reference_order).  d_seg_off: n_clouds + 1 device offsets into d_xyz.  Voxels of cloud b end up at
 // [h_voff[b], h_voff[b + 1]) of d_first_xyz (room for `total` points); d_rank / d_leaders (optional, `total` entries each) are what
 // voxel_reference_order needs.  *overflowed: a voxel held more than VH_K points - nothing of the output is valid, the caller
-// falls back to per-cloud calls.  Synchronizes the stream once.
+// falls back to per-cloud calls.  d_voff_keep (optional): n_clouds + 2 device ints that receive the voxel offsets.  Synchronizes once.
 int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, const int* d_seg_off, int n_clouds, float voxel,
-                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed) {
+                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed, int* d_voff_keep) {
     if (!ctx || n_clouds < 1 || total < 0 || !(voxel > 0.f) || !h_voff || !overflowed) return TDV_ERR_BAD_ARG;
     *overflowed = 0;
     for (int b = 0; b <= n_clouds; ++b) h_voff[b] = 0;
     if (total == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
-    int* d_voff;
-    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_voff));
+    int* d_voff = d_voff_keep;                               // (n_clouds + 2 ints; the caller's when it wants the offsets on the device afterwards)
+    if (!d_voff) TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_voff));
     TDV_TRY(pin_reserve(ctx, ((size_t)n_clouds + 2) * 4));
     int* h = reinterpret_cast<int*>(ctx->pin);
     {
