@@ -4,6 +4,7 @@
 // the host only reads three scalars (point count, voxel count, results).  SURVEY.md 8f N1.
 #include "tdv_internal.hpp"
 #include <algorithm>
+#include <functional>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -194,15 +195,15 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         return TDV_OK;
     };
     // Lanes: the calling thread on ctx plus helper threads, each on its own helper ctx (stream + workspace, owned by ctx and
-    // chained through ->helper), take the instances in turn, so that one lane's host syncs, its host replay of the voxel
-    // order and its small kernels overlap the others' work — the shape of the reference's thread pool
-    // (src/pipeline.cpp:321-327), inside one call.  Results do not depend on the lanes.  Measured on C4 (instances/s) at the
-    // end of round 2: reference order 4 / 6 / 8 / 10 / 12 / 14 / 16 lanes 395 / 439 / 466 / 463-513 / 508-518 / 509-519 /
-    // 507-518, first-occurrence order 3 / 4 / 6 lanes 525 / 514 / 532.  Hence 12 resp. 3 lanes by default, never more than
-    // the host has hardware threads; TDV_BATCH_LANES overrides (1 = the caller's thread only, at most 16).
+    // chained through ->helper), take the instances in turn, so that one lane's host syncs and its small kernels overlap the
+    // others' work — the shape of the reference's thread pool (src/pipeline.cpp:321-327), inside one call.  Results do not
+    // depend on the lanes.  Round 2 needed 12 lanes in the reference's voxel order to hide 3 ms of host replay per instance
+    // (395 / 466 / 513 instances/s of C4 with 4 / 8 / 12 lanes); with the order made on the device the lane count hardly
+    // matters any more (round 3, 128 instances: 513 / 497 / 505 with 2 / 4 / 8).  4 lanes by default, never more than the host
+    // has hardware threads; TDV_BATCH_LANES overrides (1 = the caller's thread only, at most 16).
     static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;
     const int hw_threads = std::max(1u, std::thread::hardware_concurrency());
-    const int lanes_default = std::min(prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE ? 12 : 3, hw_threads);
+    const int lanes_default = std::min(4, hw_threads);
     const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 16), n_instances));
     std::vector<tdv_ctx*> lane_ctx{ctx};
     for (tdv_ctx* c = ctx; (int)lane_ctx.size() < want; c = c->helper) {
@@ -210,43 +211,116 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         lane_ctx.push_back(c->helper);
     }
     const int L = (int)lane_ctx.size();
-    if (L == 1) {
-        int st = TDV_OK;
-        for (int b = 0; b < n_instances && st == TDV_OK; ++b) st = run_instance(ctx, b);
-        if (st != TDV_OK) (void)hipStreamSynchronize(ctx->stream);   // nothing of this call is in flight when it returns
-        return st;
-    }
-    TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the clouds and the model's index are complete before other streams read them
-    std::vector<int> status((size_t)L, TDV_OK);
-    std::vector<std::thread> workers;
-    for (int l = 1; l < L; ++l) {
-        tdv_ctx* h = lane_ctx[l];
-        h->timing = ctx->timing; h->icp_search = ctx->icp_search; h->ransac_score_mode = ctx->ransac_score_mode; h->err[0] = 0;
-        workers.emplace_back([&, h, l]() {
-            try {
-                if (hipSetDevice(h->device) != hipSuccess) { status[l] = TDV_ERR_NO_DEVICE; return; }
-                status[l] = ws_reset(h);
-                for (int b = l; b < n_instances && status[l] == TDV_OK; b += L) status[l] = run_instance(h, b);
-                // on failure too: kernels of this lane may still be reading all_xyz and the workspaces the next call reuses
-                if (hipStreamSynchronize(h->stream) != hipSuccess && status[l] == TDV_OK) status[l] = TDV_ERR_LAUNCH;
-            } catch (...) {   // nothing may escape a thread
-                std::snprintf(h->err, sizeof(h->err), "exception in a helper lane");
-                status[l] = TDV_ERR_INTERNAL;
-            }
-        });
-    }
-    try {
-        for (int b = 0; b < n_instances && status[0] == TDV_OK; b += L) status[0] = run_instance(ctx, b);
-    } catch (...) {   // the workers must be joined whatever happens here
-        std::snprintf(ctx->err, sizeof(ctx->err), "exception in the batch lane");
-        status[0] = TDV_ERR_INTERNAL;
-    }
-    for (auto& w : workers) w.join();
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && status[0] == TDV_OK) status[0] = TDV_ERR_LAUNCH;
-    if (status[0] != TDV_OK) return status[0];
-    for (int l = 1; l < L; ++l)
-        if (status[l] != TDV_OK) { std::snprintf(ctx->err, sizeof(ctx->err), "batch lane %d: %s", l + 1, lane_ctx[l]->err); return status[l]; }
-    return TDV_OK;
+    // fn(lane ctx, instance) over all instances, dealt to the lanes in turn; returns when every lane's stream has drained
+    auto for_all_instances = [&](const std::function<int(tdv_ctx*, int)>& fn) -> int {
+        if (L == 1) {
+            int st = TDV_OK;
+            for (int b = 0; b < n_instances && st == TDV_OK; ++b) st = fn(ctx, b);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess && st == TDV_OK) st = TDV_ERR_LAUNCH;   // nothing of this pass is in flight when it returns
+            return st;
+        }
+        TDV_HIP(ctx, hipStreamSynchronize(ctx->stream));   // what the pass reads is complete before other streams read it
+        std::vector<int> status((size_t)L, TDV_OK);
+        std::vector<std::thread> workers;
+        for (int l = 1; l < L; ++l) {
+            tdv_ctx* h = lane_ctx[l];
+            h->timing = ctx->timing; h->icp_search = ctx->icp_search; h->ransac_score_mode = ctx->ransac_score_mode; h->err[0] = 0;
+            workers.emplace_back([&, h, l]() {
+                try {
+                    if (hipSetDevice(h->device) != hipSuccess) { status[l] = TDV_ERR_NO_DEVICE; return; }
+                    status[l] = ws_reset(h);
+                    for (int b = l; b < n_instances && status[l] == TDV_OK; b += L) status[l] = fn(h, b);
+                    // on failure too: kernels of this lane may still be reading all_xyz and the workspaces the next call reuses
+                    if (hipStreamSynchronize(h->stream) != hipSuccess && status[l] == TDV_OK) status[l] = TDV_ERR_LAUNCH;
+                } catch (...) {   // nothing may escape a thread
+                    std::snprintf(h->err, sizeof(h->err), "exception in a helper lane");
+                    status[l] = TDV_ERR_INTERNAL;
+                }
+            });
+        }
+        try {
+            for (int b = 0; b < n_instances && status[0] == TDV_OK; b += L) status[0] = fn(ctx, b);
+        } catch (...) {   // the workers must be joined whatever happens here
+            std::snprintf(ctx->err, sizeof(ctx->err), "exception in the batch lane");
+            status[0] = TDV_ERR_INTERNAL;
+        }
+        for (auto& w : workers) w.join();
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess && status[0] == TDV_OK) status[0] = TDV_ERR_LAUNCH;
+        if (status[0] != TDV_OK) return status[0];
+        for (int l = 1; l < L; ++l)
+            if (status[l] != TDV_OK) { std::snprintf(ctx->err, sizeof(ctx->err), "batch lane %d: %s", l + 1, lane_ctx[l]->err); return status[l]; }
+        return TDV_OK;
+    };
+
+    // STAGED batch (the default whenever every instance's voxels sit in the batch's own arrays): instead of walking each instance
+    // through the whole chain, the stages that do not depend on an instance's size run ONCE for all instances:
+    //   voxels + reference order (above)  ->  [lanes] normals + FPFH per instance, descriptors into one array
+    //   ->  ONE descriptor match for all instances' points against the model  ->  [lanes] RANSAC + ICP per instance.
+    // Every point's nearest model descriptor is the same whoever else is in the call (an exact search), so the results are those
+    // of the instance-by-instance chain, bit for bit (tests/test_gpu_chain.py, test_gpu_configs.py, test_gpu_c5.py).  For C5's
+    // 1,024 small instances the per-instance match was the largest item of an instance (2 launches, 167 us of 600 us of kernels).
+    static const bool staged_env = !(getenv("TDV_BATCH_STAGED") && atoi(getenv("TDV_BATCH_STAGED")) == 0);   // A/B knob
+    bool staged = staged_env && batched_voxel && voff[n_instances] > 0;
+    if (staged && want_ref) { if (!vox_ref_all) staged = false; else for (int b = 0; b < n_instances; ++b) if (ref_failed[b] && off[b + 1] > off[b]) staged = false; }
+    if (!staged) return for_all_instances(run_instance);
+
+    const size_t tv = (size_t)voff[n_instances];
+    const bool coherent = want_ref && coherent_stages && prm->normals_k <= 100;
+    float* fpfh_all; int* corr_all;
+    TDV_TRY(ws_alloc(ctx, tv * 33, &fpfh_all));
+    TDV_TRY(ws_alloc(ctx, tv, &corr_all));
+    auto instance_clouds = [&](int b, float*& vx, const float*& stage_xyz) {
+        float* first = vox_first_all + (size_t)voff[b] * 3;
+        vx = want_ref ? vox_ref_all + (size_t)voff[b] * 3 : first;
+        stage_xyz = coherent ? first : vx;
+    };
+    auto stage_features = [&](tdv_ctx* c, int b) -> int {
+        tdv_instance_result& r = results[b];
+        std::memset(&r, 0, sizeof(r));
+        for (int i = 0; i < 16; ++i) r.T[i] = (i % 5 == 0) ? 1.f : 0.f;
+        const int n = off[b + 1] - off[b], v = voff[b + 1] - voff[b];
+        r.n_points = n; r.n_voxels = v;
+        if (n == 0) { r.status = empty_status[b]; return TDV_OK; }
+        const WsMark mark = ws_mark(c);
+        float* vx; const float* stage_xyz;
+        instance_clouds(b, vx, stage_xyz);
+        float* nrm;
+        TDV_TRY(ws_alloc(c, (size_t)v * 3, &nrm));
+        TDV_TRY(normals_fpfh_dev(c, stage_xyz, v, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor, nrm, fpfh_all + (size_t)voff[b] * 33,
+                                 coherent ? vox_f2r_all + voff[b] : nullptr, coherent ? vox_r2f_all + voff[b] : nullptr));
+        ws_rewind(c, mark);
+        return TDV_OK;
+    };
+    TDV_TRY(for_all_instances(stage_features));
+    if (have_index && tv >= 4096) TDV_TRY(feature_match_indexed_dev(ctx, fpfh_all, (int)tv, model_index, corr_all));
+    else TDV_TRY(feature_match_dev(ctx, fpfh_all, (int)tv, d_model_fpfh, n_model, corr_all));
+    auto stage_register = [&](tdv_ctx* c, int b) -> int {
+        tdv_instance_result& r = results[b];
+        const int v = voff[b + 1] - voff[b];
+        if (off[b + 1] == off[b]) return TDV_OK;
+        const WsMark mark = ws_mark(c);
+        float* vx; const float* stage_xyz;
+        instance_clouds(b, vx, stage_xyz);
+        int* corr = corr_all + voff[b];
+        if (coherent) {                                        // the match ran on the coherent ordering: bring it to reference positions
+            TDV_TRY(ws_alloc(c, (size_t)v, &corr));
+            k_gather_i32<<<(v + 255) / 256, 256, 0, c->stream>>>(corr_all + voff[b], vox_r2f_all + voff[b], v, corr);
+            TDV_CHECK_LAUNCH(c);
+        }
+        tdv_ransac_result coarse;
+        TDV_TRY(ransac_run_dev(c, vx, v, d_model_xyz, n_model, nullptr, nullptr, corr, prm->voxel_size, prm->ransac_max_iterations,
+                               prm->ransac_confidence, prm->seed, &coarse, nullptr));
+        r.coarse_fitness = coarse.fitness; r.coarse_inliers = coarse.inliers;
+        tdv_icp_result fine;
+        TDV_TRY(icp_run_dev(c, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, icp_thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine,
+                            have_sorted ? &model_sorted : nullptr, have_grid ? &model_grid : nullptr));
+        std::memcpy(r.T, fine.T, 64);
+        r.fitness = fine.fitness; r.rmse = fine.rmse; r.icp_iterations = fine.iterations;
+        r.status = 0;
+        ws_rewind(c, mark);
+        return TDV_OK;
+    };
+    return for_all_instances(stage_register);
 }
 
 }  // namespace tdv

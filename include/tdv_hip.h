@@ -282,13 +282,14 @@ int tdv_voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* 
  * no pixel inside 0 < z <= zmax gets status 2 (:86-89, "empty point cloud").
  * voxel_order: TDV_VOXEL_ORDER_REFERENCE gives, per instance, exactly what the chain of host-buffer operators (and
  * the reference's processInstance) gives — RANSAC's mt19937 index stream picks points by position, so the pose depends
- * on the order of the downsampled cloud; TDV_VOXEL_ORDER_FIRST skips the host replay of the reference's container
- * (16 B per voxel over PCIe + ~15 ns per voxel of host time) and yields a different, equally valid, coarse pose.
+ * on the order of the downsampled cloud; TDV_VOXEL_ORDER_FIRST skips the computation of the reference's container order
+ * (done on the device, ~17 small passes per batch) and yields a different, equally valid, coarse pose.
  * The RANSAC index stream is seeded per instance exactly as the reference does (mt19937(42) restarted for every
  * ransacRegistration call).  Frames: as tdv_depth_to_cloud_batch_dev (n_frames, frame_of_instance).
  * The call spreads the instances over several lanes (the caller's thread plus helper threads, each with its own stream
- * and workspace owned by the ctx): 12 in the reference's voxel order, 3 otherwise, never more than the host has hardware
- * threads; TDV_BATCH_LANES=n overrides (at most 16). */
+ * and workspace owned by the ctx): 4, never more than the host has hardware threads; TDV_BATCH_LANES=n overrides (at most 16).
+ * Stages that do not depend on an instance run once for the whole batch: the clouds (2 launches), the voxels and their
+ * reference order (on the device: no leader leaves it), the descriptor match of all instances' points against the model. */
 typedef struct tdv_batch_params {
     int width, height;
     float scale_to_meters;      /* depth.scale_to_meters      (include/pipeline_config.hpp:18) */
