@@ -198,12 +198,15 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // chained through ->helper), take the instances in turn, so that one lane's host syncs and its small kernels overlap the
     // others' work — the shape of the reference's thread pool (src/pipeline.cpp:321-327), inside one call.  Results do not
     // depend on the lanes.  Round 2 needed 12 lanes in the reference's voxel order to hide 3 ms of host replay per instance
-    // (395 / 466 / 513 instances/s of C4 with 4 / 8 / 12 lanes); with the order made on the device the lane count hardly
-    // matters any more (round 3, 128 instances: 513 / 497 / 505 with 2 / 4 / 8).  4 lanes by default, never more than the host
-    // has hardware threads; TDV_BATCH_LANES overrides (1 = the caller's thread only, at most 16).
+    // (395 / 466 / 513 instances/s of C4 with 4 / 8 / 12 lanes); with the order made on the device large instances no longer
+    // care (round 3, C4, 128 instances: 497 / 503 / 500 with 4 / 8 / 12 lanes) and take 4.  Small instances are chains of
+    // launch-bound kernels and host read-backs and still gain from more lanes (C5, 1,024 instances of ~400 voxels:
+    // 5,650 / 6,550 / 6,790 instances/s with 8 / 12 / 16): they take 12.  Never more than the host has hardware threads;
+    // TDV_BATCH_LANES overrides (1 = the caller's thread only, at most 16).
     static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;
     const int hw_threads = std::max(1u, std::thread::hardware_concurrency());
-    const int lanes_default = std::min(4, hw_threads);
+    const bool small_instances = off[n_instances] / std::max(n_instances, 1) < 8192;      // points per instance, on average
+    const int lanes_default = std::min(small_instances ? 12 : 4, hw_threads);
     const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 16), n_instances));
     std::vector<tdv_ctx*> lane_ctx{ctx};
     for (tdv_ctx* c = ctx; (int)lane_ctx.size() < want; c = c->helper) {
@@ -252,15 +255,18 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         return TDV_OK;
     };
 
-    // STAGED batch (the default whenever every instance's voxels sit in the batch's own arrays): instead of walking each instance
-    // through the whole chain, the stages that do not depend on an instance's size run ONCE for all instances:
+    // STAGED batch (small instances whose voxels sit in the batch's own arrays): instead of walking each instance through the
+    // whole chain, the descriptor match runs ONCE for all instances:
     //   voxels + reference order (above)  ->  [lanes] normals + FPFH per instance, descriptors into one array
     //   ->  ONE descriptor match for all instances' points against the model  ->  [lanes] RANSAC + ICP per instance.
     // Every point's nearest model descriptor is the same whoever else is in the call (an exact search), so the results are those
     // of the instance-by-instance chain, bit for bit (tests/test_gpu_chain.py, test_gpu_configs.py, test_gpu_c5.py).  For C5's
-    // 1,024 small instances the per-instance match was the largest item of an instance (2 launches, 167 us of 600 us of kernels).
-    static const bool staged_env = !(getenv("TDV_BATCH_STAGED") && atoi(getenv("TDV_BATCH_STAGED")) == 0);   // A/B knob
-    bool staged = staged_env && batched_voxel && voff[n_instances] > 0;
+    // 1,024 instances of ~400 voxels the per-instance match was the largest item of an instance (2 launches, 167 us of 600 us of
+    // kernels): 4,716 -> 6,554 instances/s at 12 lanes.  For C4's 147k-voxel instances it LOSES (497 -> 469 instances/s at 4 lanes,
+    // 429 at 12): there the lanes overlap kernels of different kinds, which the common stages take away - hence the size rule
+    // (TDV_BATCH_STAGED=0 / 1 forces either shape).
+    static const int staged_env = getenv("TDV_BATCH_STAGED") ? atoi(getenv("TDV_BATCH_STAGED")) : -1;   // A/B knob
+    bool staged = (staged_env < 0 ? small_instances : staged_env != 0) && batched_voxel && voff[n_instances] > 0;
     if (staged && want_ref) { if (!vox_ref_all) staged = false; else for (int b = 0; b < n_instances; ++b) if (ref_failed[b] && off[b + 1] > off[b]) staged = false; }
     if (!staged) return for_all_instances(run_instance);
 
