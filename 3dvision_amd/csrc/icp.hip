@@ -599,6 +599,133 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
     }
 }
 
+// ---- the whole loop in ONE launch, for small problems (round 3) ----------------------------------------------------------
+// A 400 x 400 instance (config C5's size) spent 13 iterations' worth of launches - two per iteration, each 9-12 us of pure
+// latency - and a state read-back per burst: 140 us of an instance's 340 us of kernels.  Here one workgroup of 16 waves keeps
+// the target in LDS and runs search, normal equations, solve, update and the stopping rule for every iteration itself, then
+// stores the final state straight into pinned host memory.
+//  * search: one WAVE per source point, lane j scans targets j, j + 64, ... (ascending, strict <: the lowest index of its share)
+//    with the scan's expression d2 = dx*dx + (dy*dy + dz*dz); the wave minimum in (d2, index) order is the scan's answer.
+//  * accumulation: exactly k_icp_accumulate<MODE, 1>'s tree - 256 consecutive points form a block whose four wave sums (DPP) are
+//    added as (w0 + w1) + (w2 + w3) into a slab, slabs folded in the same pattern - so a call gives the same bits whichever path
+//    its size selects.
+constexpr int SM_MAX_N = 2048;           // sources and targets the one-launch loop takes
+constexpr int SM_THREADS = 1024;
+template <int MODE>
+__global__ __launch_bounds__(SM_THREADS)
+void k_icp_small(const float* __restrict__ src, int ns, const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int nt,
+                 const IcpState* __restrict__ st_in, float tau_accept, int max_iterations, int fixed_iterations,
+                 IcpState* __restrict__ st_out, IcpState* __restrict__ st_host) {
+    __shared__ float tx[SM_MAX_N], ty[SM_MAX_N], tz[SM_MAX_N];
+    __shared__ float sbest[SM_MAX_N];
+    __shared__ int sidx[SM_MAX_N];
+    __shared__ double red[SM_THREADS / 64][ACC_NV];       // wave sums, four per virtual block
+    __shared__ double slab[SM_MAX_N / 256][ACC_NV];
+    __shared__ double fold[8][ACC_NV];
+    __shared__ double tot[ACC_NV];
+    __shared__ IcpState st;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < nt; j += SM_THREADS) { tx[j] = tgt[3 * j]; ty[j] = tgt[3 * j + 1]; tz[j] = tgt[3 * j + 2]; }
+    if (threadIdx.x == 0) st = *st_in;
+    __syncthreads();
+    constexpr int NV = MODE == 0 ? 29 : 17;
+    const int nblocks = (ns + 255) / 256;
+    for (int it = 0; it < max_iterations; ++it) {
+        float T[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) T[k] = st.T[k];
+        const int iter0 = st.iter; const float rmse0 = st.rmse;
+        // (a) nearest target of every source point
+        for (int i = wave; i < ns; i += SM_THREADS / 64) {
+            float px, py, pz;
+            transform_point(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+            float best = FLT_MAX; int bi = 0;
+            for (int j = lane; j < nt; j += 64) {
+                const float dx = px - tx[j], dy = py - ty[j], dz = pz - tz[j];
+                const float d2 = dx * dx + (dy * dy + dz * dz);
+                if (d2 < best) { best = d2; bi = j; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64);
+                if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) { sbest[i] = best; sidx[i] = best < FLT_MAX ? bi : 0; }
+        }
+        __syncthreads();
+        // (b) slabs: virtual block B = points [256 B, 256 B + 256), one point per lane
+        for (int B0 = 0; B0 < nblocks; B0 += SM_THREADS / 256) {
+            const int B = B0 + (threadIdx.x >> 8);
+            const int i = B * 256 + (threadIdx.x & 255);
+            double v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = 0.0;
+            if (B < nblocks && i < ns) {
+                float px, py, pz;
+                transform_point(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+                const float best = sbest[i]; const int idx = sidx[i];
+                if (best <= tau_accept) {
+                    v[0] = 1.0; v[1] = (double)best;
+                    const float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
+                    if (MODE == 0) {
+                        const float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
+                        const float J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+                        const float ex = px - qx, ey = py - qy, ez = pz - qz;
+                        const float r = ex * nx + (ey * ny + ez * nz);
+                        int k = 2;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int b = a; b < 6; ++b) v[k++] = (double)(J[a] * J[b]);
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) v[k++] = (double)(J[a] * r);
+                    } else {
+                        const double P[3] = {px, py, pz}, Q[3] = {qx, qy, qz};
+                        v[2] = P[0]; v[3] = P[1]; v[4] = P[2];
+                        v[5] = Q[0]; v[6] = Q[1]; v[7] = Q[2];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) v[8 + a * 3 + b] = P[a] * Q[b];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const double s = wave_sum_lane63(v[k]);
+                if (lane == 63) red[wave][k] = s;
+            }
+            __syncthreads();
+            if (B < nblocks && (threadIdx.x & 255) < ACC_NV) {
+                const int k = threadIdx.x & 255, w0 = (threadIdx.x >> 8) * 4;
+                slab[B][k] = k < NV ? (red[w0][k] + red[w0 + 1][k]) + (red[w0 + 2][k] + red[w0 + 3][k]) : 0.0;
+            }
+            __syncthreads();
+        }
+        // (c) fold, in k_icp_accumulate's pattern (group g of 32 threads takes slabs g, g + 8, ...: here at most one each)
+        if (threadIdx.x < 256) {
+            const int vv = threadIdx.x & 31, g = threadIdx.x >> 5;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            if (g < nblocks) s0 += slab[g][vv];
+            fold[g][vv] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (threadIdx.x < ACC_NV) {
+            const int vv = threadIdx.x;
+            tot[vv] = ((fold[0][vv] + fold[1][vv]) + (fold[2][vv] + fold[3][vv])) + ((fold[4][vv] + fold[5][vv]) + (fold[6][vv] + fold[7][vv]));
+        }
+        __syncthreads();
+        // (d) solve, update, stopping rule
+        if (threadIdx.x == 0) icp_update<MODE>(tot, ns, &st, fixed_iterations, iter0, rmse0, T);
+        __syncthreads();
+        if (st.done) break;
+    }
+    if (threadIdx.x == 0) {
+        *st_out = st;
+        if (st_host) { *st_host = st; __threadfence_system(); }
+    }
+}
+
 namespace {
 
 struct NnPlan {
@@ -699,13 +826,35 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     NnPlan p = make_plan(ns, nt);
     if (pruned) p.nsplit = 1;
     else if (!getenv("TDV_ICP_PPT")) { p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256; }   // measured: 50k x 10k brute 7.6k vs 6.4k iters/s
-    IcpBuffers b;
-    TDV_TRY(alloc_buffers(ctx, p, b));
-    TDV_TRY(pin_reserve(ctx, sizeof(IcpState)));
+    TDV_TRY(pin_reserve(ctx, 2 * sizeof(IcpState)));
     IcpState* h = reinterpret_cast<IcpState*>(ctx->pin);
     std::memset(h, 0, sizeof(IcpState));
     std::memcpy(h->T, T0, 64); std::memcpy(h->res_T, T0, 64);
     hipStream_t s = ctx->stream;
+    // small problems: the whole loop in one launch (k_icp_small), same bits as the launches below
+    static const bool small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;   // A/B knob
+    if (!small_off && !pruned && !cg.usable && ns <= SM_MAX_N && nt <= SM_MAX_N) {
+        IcpState* d_st;
+        TDV_TRY(ws_alloc(ctx, 2, &d_st));
+        IcpState* h_res = h + 1;                          // the kernel stores its final state here itself (pinned memory: no copy kernel)
+        h_res->iter = -1;
+        TDV_HIP(ctx, hipMemcpyAsync(d_st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
+        {
+            ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
+            if (point_to_plane && d_tgt_normals)
+                k_icp_small<0><<<1, SM_THREADS, 0, s>>>(d_src, ns, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+            else
+                k_icp_small<1><<<1, SM_THREADS, 0, s>>>(d_src, ns, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+        }
+        TDV_CHECK_LAUNCH(ctx);
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        if (h_res->iter < 0) { snprintf(ctx->err, sizeof(ctx->err), "icp: the result did not reach the host"); return TDV_ERR_INTERNAL; }
+        std::memcpy(out->T, h_res->res_T, 64);
+        out->fitness = h_res->fitness; out->rmse = h_res->rmse; out->iterations = h_res->applied; out->n_corr = h_res->last_n_corr_applied;
+        return TDV_OK;
+    }
+    IcpBuffers b;
+    TDV_TRY(alloc_buffers(ctx, p, b));
     TDV_HIP(ctx, hipMemcpyAsync(b.st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
     SortedCloud st{};
     if (cg.usable) {
