@@ -604,8 +604,8 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
 // latency - and a state read-back per burst: 140 us of an instance's 340 us of kernels.  Here one workgroup of 16 waves keeps
 // the target in LDS and runs search, normal equations, solve, update and the stopping rule for every iteration itself, then
 // stores the final state straight into pinned host memory.
-//  * search: one WAVE per source point, lane j scans targets j, j + 64, ... (ascending, strict <: the lowest index of its share)
-//    with the scan's expression d2 = dx*dx + (dy*dy + dz*dz); the wave minimum in (d2, index) order is the scan's answer.
+//  * search: one lane per source point scans the targets in LDS in ascending order with strict < and the scan's expression
+//    d2 = dx*dx + (dy*dy + dz*dz): the scan's answer.
 //  * accumulation: exactly k_icp_accumulate<MODE, 1>'s tree - 256 consecutive points form a block whose four wave sums (DPP) are
 //    added as (w0 + w1) + (w2 + w3) into a slab, slabs folded in the same pattern - so a call gives the same bits whichever path
 //    its size selects.
@@ -635,22 +635,20 @@ void k_icp_small(const float* __restrict__ src, int ns, const float* __restrict_
 #pragma unroll
         for (int k = 0; k < 16; ++k) T[k] = st.T[k];
         const int iter0 = st.iter; const float rmse0 = st.rmse;
-        // (a) nearest target of every source point
-        for (int i = wave; i < ns; i += SM_THREADS / 64) {
+        // (a) nearest target of every source point: one LANE per source, the targets read from LDS at a wave-uniform address
+        // (a broadcast, no bank conflict) in ascending order with strict <: the scan's answer.  (One WAVE per source with a
+        // cross-lane (d2, index) minimum at the end was 3x slower at 400 x 400: six dependent shuffle rounds per source.)
+        for (int i = threadIdx.x; i < ns; i += SM_THREADS) {
             float px, py, pz;
             transform_point(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
             float best = FLT_MAX; int bi = 0;
-            for (int j = lane; j < nt; j += 64) {
+#pragma unroll 4
+            for (int j = 0; j < nt; ++j) {
                 const float dx = px - tx[j], dy = py - ty[j], dz = pz - tz[j];
                 const float d2 = dx * dx + (dy * dy + dz * dz);
                 if (d2 < best) { best = d2; bi = j; }
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const float ob = __shfl_down(best, off, 64); const int oi = __shfl_down(bi, off, 64);
-                if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            if (lane == 0) { sbest[i] = best; sidx[i] = best < FLT_MAX ? bi : 0; }
+            sbest[i] = best; sidx[i] = best < FLT_MAX ? bi : 0;
         }
         __syncthreads();
         // (b) slabs: virtual block B = points [256 B, 256 B + 256), one point per lane
