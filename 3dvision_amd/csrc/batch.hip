@@ -13,6 +13,15 @@
 
 namespace tdv {
 
+// out[P] = local[P] + (first voxel of the instance P belongs to): positions inside an instance -> positions in the batch's arrays
+__global__ void k_globalise(const int* __restrict__ local, const int* __restrict__ voff, int n_inst, int total, int* __restrict__ out) {
+    const int P = blockIdx.x * blockDim.x + threadIdx.x;
+    if (P >= total) return;
+    int a = 0, z = n_inst;
+    while (z - a > 1) { const int m = (a + z) >> 1; if (voff[m] <= P) a = m; else z = m; }
+    out[P] = local[P] + voff[a];
+}
+
 __global__ void k_gather_i32(const int* __restrict__ in, const int* __restrict__ idx, int n, int* __restrict__ out) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) out[p] = in[idx[p]];
@@ -95,12 +104,13 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     float* vox_first_all = nullptr; int* vox_rank_all = nullptr; int4* vox_leaders_all = nullptr;
     float* vox_ref_all = nullptr; int *vox_r2f_all = nullptr, *vox_f2r_all = nullptr;
     std::vector<int> ref_failed((size_t)n_instances, 1);        // 1: this instance's reference order is (still) to be made by the host replay
+    int* d_voff = nullptr;                                      // voxel offsets of the instances on the device (n_instances + 2 ints)
     bool batched_voxel = false;
     const int total_pts = off[n_instances];
     if (batched_voxel_env && total_pts > 0 && !getenv("TDV_VOXEL_LEGACY") && !getenv("TDV_VOXEL_SORT")) {
         TDV_TRY(ws_alloc(ctx, (size_t)total_pts * 3, &vox_first_all));
         if (want_ref) { TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_rank_all)); TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_leaders_all)); }
-        int *d_off_inst, *d_voff;
+        int* d_off_inst;
         TDV_TRY(ws_alloc(ctx, (size_t)n_instances + 1, &d_off_inst));
         TDV_TRY(ws_alloc(ctx, (size_t)n_instances + 2, &d_voff));
         TDV_HIP(ctx, hipMemcpyAsync(d_off_inst, off.data(), ((size_t)n_instances + 1) * 4, hipMemcpyHostToDevice, ctx->stream));   // (off outlives the call's sync below)
@@ -297,7 +307,35 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         ws_rewind(c, mark);
         return TDV_OK;
     };
-    TDV_TRY(for_all_instances(stage_features));
+    // small instances with at least k points each: normals + FPFH of ALL of them in one set of launches (knn.hip), not ~16
+    // launches per instance
+    static const bool batched_features_env = !(getenv("TDV_BATCH_FEATURES") && atoi(getenv("TDV_BATCH_FEATURES")) == 0);   // A/B knob
+    bool batched_features = batched_features_env && small_instances && d_voff && prm->normals_k <= 100;
+    for (int b = 0; b < n_instances && batched_features; ++b) { const int v = voff[b + 1] - voff[b]; if (v > 0 && v < prm->normals_k) batched_features = false; }
+    if (batched_features) {
+        for (int b = 0; b < n_instances; ++b) {
+            tdv_instance_result& r = results[b];
+            std::memset(&r, 0, sizeof(r));
+            for (int i = 0; i < 16; ++i) r.T[i] = (i % 5 == 0) ? 1.f : 0.f;
+            r.n_points = off[b + 1] - off[b]; r.n_voxels = voff[b + 1] - voff[b];
+            if (r.n_points == 0) r.status = empty_status[b];
+        }
+        const WsMark fmark = ws_mark(ctx);
+        float* nrm_all; int *tie = nullptr, *tie_inv = nullptr;
+        TDV_TRY(ws_alloc(ctx, tv * 3, &nrm_all));
+        if (coherent) {
+            TDV_TRY(ws_alloc(ctx, tv, &tie)); TDV_TRY(ws_alloc(ctx, tv, &tie_inv));
+            k_globalise<<<(unsigned)((tv + 255) / 256), 256, 0, ctx->stream>>>(vox_f2r_all, d_voff, n_instances, (int)tv, tie);
+            k_globalise<<<(unsigned)((tv + 255) / 256), 256, 0, ctx->stream>>>(vox_r2f_all, d_voff, n_instances, (int)tv, tie_inv);
+            TDV_CHECK_LAUNCH(ctx);
+        }
+        const float* stage_all = coherent ? vox_first_all : (want_ref ? vox_ref_all : vox_first_all);
+        TDV_TRY(normals_fpfh_batch_dev(ctx, stage_all, voff.data(), d_voff, n_instances, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor,
+                                       nrm_all, fpfh_all, tie, tie_inv));
+        ws_rewind(ctx, fmark);        // (stream order: the descriptor match below is enqueued behind the kernels that used the scratch)
+    } else {
+        TDV_TRY(for_all_instances(stage_features));
+    }
     if (have_index && tv >= 4096) TDV_TRY(feature_match_indexed_dev(ctx, fpfh_all, (int)tv, model_index, corr_all));
     else TDV_TRY(feature_match_dev(ctx, fpfh_all, (int)tv, d_model_fpfh, n_model, corr_all));
     auto stage_register = [&](tdv_ctx* c, int b) -> int {

@@ -254,7 +254,9 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
                   const int* __restrict__ qsel, int nqq, const float* __restrict__ bound, float bound0, int seed_own,
                   int k, int stride, int* __restrict__ lists, int* __restrict__ cnt_out,
                   const int* __restrict__ okey /* sorted position -> tie-break id (null: orig) */,
-                  const int* __restrict__ key2idx /* tie-break id -> array index written to the lists (null: the id itself) */) {
+                  const int* __restrict__ key2idx /* tie-break id -> array index written to the lists (null: the id itself) */,
+                  const int* __restrict__ inst_leaf = nullptr /* several clouds in one array: cloud b owns leaves [inst_leaf[b], inst_leaf[b + 1]) */,
+                  int n_inst = 0) {
     constexpr int ROW = 64 * R;
     __shared__ unsigned long long rows[QW_WAVES][ROW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -335,7 +337,15 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
     };
 
     const int own = sp >> 6;
-    const int seed_lo = seed_own ? max(0, own - SEED_SPAN) : 1, seed_hi = seed_own ? min(n_leaf - 1, own + SEED_SPAN) : 0;
+    // Several clouds in one array (the batch's small instances, each padded to whole leaves with NaN coordinates): the walk
+    // stays inside the query's own cloud - boxes of other clouds are never looked at, whatever their coordinates.
+    int l_lo = 0, l_hi = n_leaf;
+    if (inst_leaf) {
+        int a = 0, z = n_inst;
+        while (z - a > 1) { const int m = (a + z) >> 1; if (inst_leaf[m] <= own) a = m; else z = m; }
+        l_lo = inst_leaf[a]; l_hi = inst_leaf[a + 1];
+    }
+    const int seed_lo = seed_own ? max(l_lo, own - SEED_SPAN) : 1, seed_hi = seed_own ? min(l_hi - 1, own + SEED_SPAN) : 0;
     if (seed_own) {
         // unbounded start: the query's own leaf (its 64 curve neighbours) gives the first bound, its curve-adjacent
         // leaves follow; the walk skips them
@@ -345,9 +355,10 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
     }
     // Validity is tracked explicitly (never through "+inf <= bound"): the bound itself is +inf while an unbounded
     // search has seen fewer than k points, or for an unbounded radius.
-    for (int tb = 0; tb < n_top; tb += 64) {
+    const int t_hi = inst_leaf ? ((l_hi - 1) >> 6) + 1 : n_top;
+    for (int tb = inst_leaf ? (l_lo >> 6) : 0; tb < t_hi; tb += 64) {
         const int t = tb + lane;
-        const bool t_valid = t < n_top;
+        const bool t_valid = t < t_hi;
         const float lbt = t_valid ? box_lower_bound(tbox, n_top, t, qp, qp) : INFINITY;
         unsigned long long tmask = __ballot(t_valid && lbt <= B);
         while (tmask) {
@@ -355,7 +366,7 @@ void k_query_wave(const float* __restrict__ sx, const float* __restrict__ sy, co
             tmask &= tmask - 1;
             if (__shfl(lbt, bt, 64) > B) continue;   // the bound may have dropped since the test
             const int u = (tb + bt) * 64 + lane;
-            bool pending = u < n_leaf && !(u >= seed_lo && u <= seed_hi);   // a leaf of this group not evaluated yet
+            bool pending = u >= l_lo && u < l_hi && !(u >= seed_lo && u <= seed_hi);   // a leaf of this group (and cloud) not evaluated yet
             const float lbl = pending ? box_lower_bound(lbox, n_leaf, u, qp, qp) : INFINITY;
             if (BEST_FIRST && seed_own) {
                 while (true) {   // nearest leaf first: the bound tightens before the far leaves are looked at
@@ -782,6 +793,118 @@ int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radiu
     k_normals_from_lists<<<p.blocks_x, KN_BLOCK, 0, s>>>(d_xyz, n, so.orig, kk, nbr, FP_MAXNN, cnt, listsK, kk, cntK, d_normals, nullptr, 0);
     TDV_CHECK_LAUNCH(ctx);
     return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, so.orig, nbr, cnt, d_desc, nullptr, nullptr);
+}
+
+
+// ---- estimateNormals + computeFPFH for MANY SMALL CLOUDS in one set of launches (round 3) ---------------------------------
+// The batch's small instances (config C5: 1,024 clouds of ~400 voxels) are bound by the rate at which the host can issue their
+// ~16 launches each, not by the kernels.  Here all clouds sit in ONE array - cloud b padded to whole 64-point leaves with NaN
+// coordinates (a NaN never passes `d2 <= bound` and is ignored by the boxes' min / max) - and k_query_wave keeps every query
+// inside its own cloud's leaves (inst_leaf).  No Morton order: for a few hundred points in image order the walk visits every
+// leaf of the cloud anyway.  Lists, normals and descriptors are those of normals_fpfh_dev called per cloud, bit for bit: the
+// searches are exact, the lists ordered by (d2, tie id), the estimators the same kernels on global point indices.
+__global__ void k_batch_layout(const float* __restrict__ xyz, const int* __restrict__ voff, const int* __restrict__ ppos, int n_inst, int total_pos,
+                               const int* __restrict__ tie_ids, float* __restrict__ sx, float* __restrict__ sy, float* __restrict__ sz,
+                               int* __restrict__ orig, int* __restrict__ okey, int* __restrict__ pos_of_point, int* __restrict__ iota) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= total_pos) return;
+    int a = 0, z = n_inst;
+    while (z - a > 1) { const int m = (a + z) >> 1; if (ppos[m] <= pos) a = m; else z = m; }
+    const int e = pos - ppos[a], v0 = voff[a], v = voff[a + 1] - v0;
+    if (pos < ppos[n_inst] && e < v) {
+        const size_t P = (size_t)v0 + e;
+        sx[pos] = xyz[3 * P]; sy[pos] = xyz[3 * P + 1]; sz[pos] = xyz[3 * P + 2];
+        orig[pos] = (int)P; pos_of_point[P] = pos; iota[P] = (int)P;
+        if (okey) okey[pos] = tie_ids[P];
+    } else {
+        const float q = __builtin_nanf("");
+        sx[pos] = q; sy[pos] = q; sz[pos] = q; orig[pos] = INT_MAX;
+        if (okey) okey[pos] = INT_MAX;
+    }
+}
+__global__ void k_batch_flag_deficient(const int* __restrict__ cnt, int n, int k, int* __restrict__ flag) {
+    const int P = blockIdx.x * blockDim.x + threadIdx.x;
+    if (P < n) flag[P] = cnt[P] < k ? 1 : 0;
+}
+__global__ void k_batch_compact_flagged(const int* __restrict__ flag, const int* __restrict__ pos, const int* __restrict__ pos_of_point, int n, int* __restrict__ qsel) {
+    const int P = blockIdx.x * blockDim.x + threadIdx.x;
+    if (P < n && flag[P]) qsel[pos[P]] = pos_of_point[P];
+}
+
+// d_xyz: all clouds back to back (cloud b = points [h_voff[b], h_voff[b + 1]), every cloud with at least k points); d_voff: the
+// same offsets on the device.  d_tie_ids / d_tie_ids_inv (optional, both or neither), GLOBAL: neighbour lists are ordered by
+// (d2, d_tie_ids[point]) and receive d_tie_ids_inv[id] - ids of one cloud must be ordered as the wanted positions inside it.
+int normals_fpfh_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_voff, const int* d_voff, int n_clouds, int k, float radius,
+                           float* d_normals, float* d_desc, const int* d_tie_ids, const int* d_tie_ids_inv) {
+    if (!ctx || !d_xyz || !h_voff || !d_voff || n_clouds < 1 || k <= 0 || k > FP_MAXNN || !d_normals || !d_desc) return TDV_ERR_BAD_ARG;
+    if ((d_tie_ids == nullptr) != (d_tie_ids_inv == nullptr)) return TDV_ERR_BAD_ARG;
+    const int n = h_voff[n_clouds];
+    if (n == 0) return TDV_OK;
+    std::vector<int> ppos((size_t)n_clouds + 1, 0), leaf((size_t)n_clouds + 1, 0);
+    for (int b = 0; b < n_clouds; ++b) {
+        const int v = h_voff[b + 1] - h_voff[b];
+        if (v > 0 && v < k) return TDV_ERR_BAD_ARG;          // (min(k, n) of registration.cpp:74 would differ per cloud: the caller takes the per-cloud path)
+        ppos[b + 1] = ppos[b] + (int)align_up((size_t)v, 64);
+        leaf[b + 1] = ppos[b + 1] / 64;
+    }
+    const int total_pos = (int)align_up((size_t)ppos[n_clouds], 256);
+    hipStream_t s = ctx->stream;
+    const float r2 = radius * radius;  // registration.cpp:89
+    float* soa; int *orig, *okey = nullptr, *pos_of_point, *iota, *d_ppos, *d_leaf;
+    TDV_TRY(ws_alloc(ctx, (size_t)3 * total_pos, &soa));
+    TDV_TRY(ws_alloc(ctx, (size_t)total_pos, &orig));
+    if (d_tie_ids) TDV_TRY(ws_alloc(ctx, (size_t)total_pos, &okey));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &pos_of_point));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &iota));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 1, &d_ppos));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 1, &d_leaf));
+    TDV_HIP(ctx, hipMemcpyAsync(d_ppos, ppos.data(), ((size_t)n_clouds + 1) * 4, hipMemcpyHostToDevice, s));
+    TDV_HIP(ctx, hipMemcpyAsync(d_leaf, leaf.data(), ((size_t)n_clouds + 1) * 4, hipMemcpyHostToDevice, s));
+    Sorted so;
+    so.sx = soa; so.sy = soa + total_pos; so.sz = soa + 2 * (size_t)total_pos; so.orig = orig;
+    k_batch_layout<<<(total_pos + 255) / 256, 256, 0, s>>>(d_xyz, d_voff, d_ppos, n_clouds, total_pos, d_tie_ids, so.sx, so.sy, so.sz, orig, okey, pos_of_point, iota);
+    so.n_leaf = total_pos / 64; so.n_top = (so.n_leaf + 63) / 64;
+    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_leaf, &so.lbox));
+    TDV_TRY(ws_alloc(ctx, (size_t)6 * so.n_top, &so.tbox));
+    k_leaf_boxes<<<(so.n_leaf + 3) / 4, 256, 0, s>>>(so.sx, so.sy, so.sz, so.n_leaf, so.lbox);
+    k_top_boxes<<<so.n_top, 64, 0, s>>>(so.lbox, so.n_leaf, so.n_top, so.tbox);
+    TDV_CHECK_LAUNCH(ctx);
+    if (d_tie_ids) { so.okey = okey; so.key2idx = d_tie_ids_inv; }
+    const int n_pad = (int)align_up((size_t)n, KN_BLOCK);
+    int *nbr, *cnt, *flag, *pos, *qsel, *d_total, *listsK, *cntK;
+    TDV_TRY(ws_alloc(ctx, (size_t)FP_MAXNN * n_pad, &nbr));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_pad, &cnt));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &flag));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &pos));
+    TDV_TRY(ws_alloc(ctx, (size_t)n, &qsel));
+    TDV_TRY(ws_alloc(ctx, 1, &d_total));
+    TDV_TRY(ws_alloc(ctx, (size_t)k * n_pad, &listsK));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_pad, &cntK));
+    auto query = [&](int kk, float bound0, int seed_own, int timer, const int* sel, int nsel, int* lists, int* counts) -> int {
+        if (nsel <= 0) return TDV_OK;
+        const unsigned grid = (unsigned)((nsel + QW_WAVES - 1) / QW_WAVES);
+        ScopedTimer tm(ctx, timer);
+#define TDV_QWB(RR) k_query_wave<RR, QW_SEED_SPAN, QW_BEST_FIRST><<<grid, 64 * QW_WAVES, 0, s>>>(so.sx, so.sy, so.sz, so.orig, total_pos, so.n_leaf, so.lbox, so.n_top, so.tbox, \
+                                                            sel, nsel, nullptr, bound0, seed_own, kk, kk, lists, counts, so.okey, so.key2idx, d_leaf, n_clouds)
+        if (kk <= 64) TDV_QWB(2); else TDV_QWB(4);
+#undef TDV_QWB
+        TDV_CHECK_LAUNCH(ctx);
+        return TDV_OK;
+    };
+    TDV_TRY(query(FP_MAXNN, r2, 0, TDV_TIMER_RADIUS, pos_of_point, n, nbr, cnt));                       // radius lists of every point
+    k_batch_flag_deficient<<<(n + 255) / 256, 256, 0, s>>>(cnt, n, k, flag);
+    TDV_TRY(exclusive_scan_dev(ctx, flag, n, pos, d_total));
+    k_batch_compact_flagged<<<(n + 255) / 256, 256, 0, s>>>(flag, pos, pos_of_point, n, qsel);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_TRY(pin_reserve(ctx, 64));
+    int* h_total = reinterpret_cast<int*>(ctx->pin);
+    TDV_HIP(ctx, hipMemcpyAsync(h_total, d_total, 4, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));                                                              // (also: ppos / leaf are host temporaries)
+    TDV_TRY(query(k, INFINITY, 1, TDV_TIMER_KNN, qsel, *h_total, listsK, cntK));                         // kNN lists of the points with fewer than k in radius
+    k_normals_from_lists<<<n_pad / KN_BLOCK, KN_BLOCK, 0, s>>>(d_xyz, n, iota, k, nbr, FP_MAXNN, cnt, listsK, k, cntK, d_normals, nullptr, 0);
+    TDV_CHECK_LAUNCH(ctx);
+    ScanPlan p = make_scan_plan(n);
+    return fpfh_from_lists(ctx, d_xyz, d_normals, n, p, iota, nbr, cnt, d_desc, nullptr, nullptr);
 }
 
 }  // namespace tdv

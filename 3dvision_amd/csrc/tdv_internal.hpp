@@ -206,6 +206,10 @@ int spatial_sort_cloud(tdv_ctx* ctx, const float* d_xyz, int n, SortedCloud& out
 int normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc,
                      const int* d_tie_ids = nullptr, const int* d_tie_ids_inv = nullptr);                                      // padded record count for sort_records_dev
 
+// the same for many small clouds stored back to back, in one set of launches (knn.hip); tie ids / their inverse are GLOBAL here
+int normals_fpfh_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_voff, const int* d_voff, int n_clouds, int k, float radius,
+                           float* d_normals, float* d_desc, const int* d_tie_ids = nullptr, const int* d_tie_ids_inv = nullptr);
+
 int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr, const uint8_t* d_masks, int n_instances,
                        const tdv_batch_params* prm, const float* d_model_xyz, const float* d_model_normals,
                        const float* d_model_fpfh, int n_model, tdv_instance_result* results);
