@@ -311,6 +311,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // launches per instance
     static const bool batched_features_env = !(getenv("TDV_BATCH_FEATURES") && atoi(getenv("TDV_BATCH_FEATURES")) == 0);   // A/B knob
     bool batched_features = batched_features_env && small_instances && d_voff && prm->normals_k <= 100;
+    int *tie = nullptr, *tie_inv = nullptr;     // coherent stages: global first -> reference position and back
     for (int b = 0; b < n_instances && batched_features; ++b) { const int v = voff[b + 1] - voff[b]; if (v > 0 && v < prm->normals_k) batched_features = false; }
     if (batched_features) {
         for (int b = 0; b < n_instances; ++b) {
@@ -320,15 +321,15 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
             r.n_points = off[b + 1] - off[b]; r.n_voxels = voff[b + 1] - voff[b];
             if (r.n_points == 0) r.status = empty_status[b];
         }
-        const WsMark fmark = ws_mark(ctx);
-        float* nrm_all; int *tie = nullptr, *tie_inv = nullptr;
-        TDV_TRY(ws_alloc(ctx, tv * 3, &nrm_all));
-        if (coherent) {
+        if (coherent) {      // positions inside an instance -> positions in the batch's arrays (kept: the RANSAC pass below reorders the match with them)
             TDV_TRY(ws_alloc(ctx, tv, &tie)); TDV_TRY(ws_alloc(ctx, tv, &tie_inv));
             k_globalise<<<(unsigned)((tv + 255) / 256), 256, 0, ctx->stream>>>(vox_f2r_all, d_voff, n_instances, (int)tv, tie);
             k_globalise<<<(unsigned)((tv + 255) / 256), 256, 0, ctx->stream>>>(vox_r2f_all, d_voff, n_instances, (int)tv, tie_inv);
             TDV_CHECK_LAUNCH(ctx);
         }
+        const WsMark fmark = ws_mark(ctx);
+        float* nrm_all;
+        TDV_TRY(ws_alloc(ctx, tv * 3, &nrm_all));
         const float* stage_all = coherent ? vox_first_all : (want_ref ? vox_ref_all : vox_first_all);
         TDV_TRY(normals_fpfh_batch_dev(ctx, stage_all, voff.data(), d_voff, n_instances, prm->normals_k, prm->voxel_size * prm->fpfh_radius_factor,
                                        nrm_all, fpfh_all, tie, tie_inv));
@@ -338,9 +339,18 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     }
     if (have_index && tv >= 4096) TDV_TRY(feature_match_indexed_dev(ctx, fpfh_all, (int)tv, model_index, corr_all));
     else TDV_TRY(feature_match_dev(ctx, fpfh_all, (int)tv, d_model_fpfh, n_model, corr_all));
+    // small instances and a small model: all ICP refinements in ONE launch (icp.hip: k_icp_small, a workgroup per instance) after the
+    // RANSAC pass - same kernel as the per-instance call, same bits
+    int v_max = 0;
+    for (int b = 0; b < n_instances; ++b) v_max = std::max(v_max, voff[b + 1] - voff[b]);
+    static const bool icp_small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;
+    const bool batched_icp = !icp_small_off && d_voff && v_max <= icp_small_max_points() && n_model <= icp_small_max_points() && n_model > 0 &&
+                             (ctx->icp_search == TDV_ICP_SEARCH_AUTO || ctx->icp_search == TDV_ICP_SEARCH_BRUTE);
+    std::vector<float> coarse_T(batched_icp ? (size_t)n_instances * 16 : 0, 0.f);
     auto stage_register = [&](tdv_ctx* c, int b) -> int {
         tdv_instance_result& r = results[b];
         const int v = voff[b + 1] - voff[b];
+        if (batched_icp) for (int i = 0; i < 16; ++i) coarse_T[(size_t)b * 16 + i] = (i % 5 == 0) ? 1.f : 0.f;
         if (off[b + 1] == off[b]) return TDV_OK;
         const WsMark mark = ws_mark(c);
         float* vx; const float* stage_xyz;
@@ -355,6 +365,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         TDV_TRY(ransac_run_dev(c, vx, v, d_model_xyz, n_model, nullptr, nullptr, corr, prm->voxel_size, prm->ransac_max_iterations,
                                prm->ransac_confidence, prm->seed, &coarse, nullptr));
         r.coarse_fitness = coarse.fitness; r.coarse_inliers = coarse.inliers;
+        if (batched_icp) { std::memcpy(&coarse_T[(size_t)b * 16], coarse.T, 64); ws_rewind(c, mark); return TDV_OK; }
         tdv_icp_result fine;
         TDV_TRY(icp_run_dev(c, vx, v, d_model_xyz, d_model_normals, n_model, coarse.T, icp_thr, prm->icp_max_iterations, prm->point_to_plane, 0, &fine,
                             have_sorted ? &model_sorted : nullptr, have_grid ? &model_grid : nullptr));
@@ -364,7 +375,41 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         ws_rewind(c, mark);
         return TDV_OK;
     };
-    return for_all_instances(stage_register);
+    // ... and all coarse alignments in a handful of launches (ransac.hip: ransac_small_batch_dev) when the ICP pass is batched too
+    bool ransac_done = false;
+    if (batched_icp && d_voff && (!coherent || tie_inv)) {
+        int* corr_ref = corr_all;
+        if (coherent) {                                        // the match ran on the coherent ordering: bring it to reference positions
+            TDV_TRY(ws_alloc(ctx, tv, &corr_ref));
+            k_gather_i32<<<(unsigned)((tv + 255) / 256), 256, 0, ctx->stream>>>(corr_all, tie_inv, (int)tv, corr_ref);
+            TDV_CHECK_LAUNCH(ctx);
+        }
+        std::vector<tdv_ransac_result> coarse((size_t)n_instances);
+        int fell_back = 0;
+        TDV_TRY(ransac_small_batch_dev(ctx, want_ref ? vox_ref_all : vox_first_all, voff.data(), d_voff, n_instances, d_model_xyz, n_model, corr_ref, prm->voxel_size,
+                                       prm->ransac_max_iterations, prm->ransac_confidence, prm->seed, coarse.data(), &fell_back));
+        if (!fell_back) {
+            ransac_done = true;
+            for (int b = 0; b < n_instances; ++b) {
+                std::memcpy(&coarse_T[(size_t)b * 16], coarse[b].T, 64);
+                results[b].coarse_fitness = coarse[b].fitness; results[b].coarse_inliers = coarse[b].inliers;
+            }
+        }
+    }
+    if (!ransac_done) TDV_TRY(for_all_instances(stage_register));
+    if (batched_icp) {
+        std::vector<tdv_icp_result> fine((size_t)n_instances);
+        TDV_TRY(icp_small_batch_dev(ctx, want_ref ? vox_ref_all : vox_first_all, d_voff, n_instances, d_model_xyz, d_model_normals, n_model, coarse_T.data(), icp_thr,
+                                    prm->icp_max_iterations, prm->point_to_plane, fine.data()));
+        for (int b = 0; b < n_instances; ++b) {
+            if (off[b + 1] == off[b]) continue;
+            tdv_instance_result& r = results[b];
+            std::memcpy(r.T, fine[b].T, 64);
+            r.fitness = fine[b].fitness; r.rmse = fine[b].rmse; r.icp_iterations = fine[b].iterations;
+            r.status = 0;
+        }
+    }
+    return TDV_OK;
 }
 
 }  // namespace tdv

@@ -118,6 +118,12 @@ void mt19937_lemire_triples(uint32_t seed, uint64_t n, int count, uint64_t* out)
     for (int i = 0; i < count; ++i) ts.next(out + 3 * (size_t)i);
 }
 
+// the raw 32-bit outputs of mt19937(seed), for the device-side index sampler of the batched RANSAC (ransac.hip)
+void mt19937_raw(uint32_t seed, size_t count, uint32_t* out) {
+    Mt19937 g(seed);
+    for (size_t i = 0; i < count; ++i) out[i] = g.next();
+}
+
 struct TripleStream::Impl { Mt19937 g; explicit Impl(uint32_t seed) : g(seed) {} };
 TripleStream::TripleStream(uint32_t seed, uint64_t n) : impl_(new Impl(seed)), n_(n) {}
 TripleStream::~TripleStream() { delete impl_; }

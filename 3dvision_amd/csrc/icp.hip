@@ -611,11 +611,19 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
 //    its size selects.
 constexpr int SM_MAX_N = 2048;           // sources and targets the one-launch loop takes
 constexpr int SM_THREADS = 1024;
+// A grid of several workgroups runs one problem each (the batch's small instances against the shared model): problem b takes the
+// source points [src_off[b], src_off[b + 1]) of src0 and the states st_in[b] / st_out[b]; src_off == nullptr: one problem.
 template <int MODE>
 __global__ __launch_bounds__(SM_THREADS)
-void k_icp_small(const float* __restrict__ src, int ns, const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int nt,
-                 const IcpState* __restrict__ st_in, float tau_accept, int max_iterations, int fixed_iterations,
-                 IcpState* __restrict__ st_out, IcpState* __restrict__ st_host) {
+void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict__ src_off, const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int nt,
+                 const IcpState* __restrict__ st_in0, float tau_accept, int max_iterations, int fixed_iterations,
+                 IcpState* __restrict__ st_out0, IcpState* __restrict__ st_host) {
+    const int prob = blockIdx.x;
+    const float* __restrict__ src = src_off ? src0 + (size_t)src_off[prob] * 3 : src0;
+    const int ns = src_off ? src_off[prob + 1] - src_off[prob] : ns0;
+    const IcpState* __restrict__ st_in = st_in0 + prob;
+    IcpState* __restrict__ st_out = st_out0 + prob;
+    if (ns == 0) { if (threadIdx.x == 0) *st_out = *st_in; return; }   // (an instance without points: the caller ignores its state)
     __shared__ float tx[SM_MAX_N], ty[SM_MAX_N], tz[SM_MAX_N];
     __shared__ float sbest[SM_MAX_N];
     __shared__ int sidx[SM_MAX_N];
@@ -840,9 +848,9 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
         {
             ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
             if (point_to_plane && d_tgt_normals)
-                k_icp_small<0><<<1, SM_THREADS, 0, s>>>(d_src, ns, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+                k_icp_small<0><<<1, SM_THREADS, 0, s>>>(d_src, ns, nullptr, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
             else
-                k_icp_small<1><<<1, SM_THREADS, 0, s>>>(d_src, ns, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+                k_icp_small<1><<<1, SM_THREADS, 0, s>>>(d_src, ns, nullptr, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
         }
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipStreamSynchronize(s));
@@ -905,6 +913,42 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     }
     std::memcpy(out->T, h->res_T, 64);
     out->fitness = h->fitness; out->rmse = h->rmse; out->iterations = h->applied; out->n_corr = h->last_n_corr_applied;
+    return TDV_OK;
+}
+
+int icp_small_max_points() { return SM_MAX_N; }
+
+// icp_run_dev for n_prob small problems against one target in ONE launch: problem b = source points [d_src_off[b], d_src_off[b+1])
+// of d_src (each at most icp_small_max_points(), as nt), start pose T0s[b] (host, column-major).  Results as icp_run_dev's, bit for
+// bit (the same kernel).  One upload, one launch, one download.
+int icp_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* d_src_off, int n_prob, const float* d_tgt, const float* d_tgt_normals, int nt,
+                        const float* T0s, float thr, int max_iterations, int point_to_plane, tdv_icp_result* out) {
+    if (!ctx || !d_src || !d_src_off || !d_tgt || !T0s || !out || n_prob < 0 || nt <= 0 || nt > SM_MAX_N || max_iterations < 0) return TDV_ERR_BAD_ARG;
+    if (n_prob == 0) return TDV_OK;
+    hipStream_t s = ctx->stream;
+    const float tau = tau_le(thr);
+    IcpState* d_st;
+    TDV_TRY(ws_alloc(ctx, (size_t)2 * n_prob, &d_st));
+    TDV_TRY(pin_reserve(ctx, (size_t)n_prob * sizeof(IcpState)));
+    IcpState* h = reinterpret_cast<IcpState*>(ctx->pin);
+    std::memset(h, 0, (size_t)n_prob * sizeof(IcpState));
+    for (int b = 0; b < n_prob; ++b) { std::memcpy(h[b].T, T0s + 16 * (size_t)b, 64); std::memcpy(h[b].res_T, T0s + 16 * (size_t)b, 64); }
+    TDV_HIP(ctx, hipMemcpyAsync(d_st, h, (size_t)n_prob * sizeof(IcpState), hipMemcpyHostToDevice, s));
+    if (max_iterations > 0) {
+        ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
+        if (point_to_plane && d_tgt_normals)
+            k_icp_small<0><<<n_prob, SM_THREADS, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+        else
+            k_icp_small<1><<<n_prob, SM_THREADS, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+        TDV_CHECK_LAUNCH(ctx);
+        TDV_HIP(ctx, hipMemcpyAsync(h, d_st + n_prob, (size_t)n_prob * sizeof(IcpState), hipMemcpyDeviceToHost, s));
+    }
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    ctx->last_icp_search = TDV_ICP_SEARCH_BRUTE;
+    for (int b = 0; b < n_prob; ++b) {
+        std::memcpy(out[b].T, h[b].res_T, 64);
+        out[b].fitness = h[b].fitness; out[b].rmse = h[b].rmse; out[b].iterations = h[b].applied; out[b].n_corr = h[b].last_n_corr_applied;
+    }
     return TDV_OK;
 }
 

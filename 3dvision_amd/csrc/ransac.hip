@@ -76,16 +76,9 @@ __device__ __forceinline__ float tau_mid_default(float sqrt_tau) { return sqrt_t
 // Invalid (skipped) iterations get NaN so that no comparison is ever true -> 0 inliers.
 // Rows 12, 13 of hyp: the band of the fast scoring pass for this hypothesis (RansacBand below): mid and half-width of
 // the d2 interval inside which the FMA arithmetic and the reference's arithmetic might disagree on `d2 < tau`.
-__global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __restrict__ triples, int count, int h_pad,
-                                    float* __restrict__ hyp, const unsigned* __restrict__ pmax, float sqrt_tau, int* __restrict__ counts,
-                                    float band_u /* E = band_u (A + s): 16 u for the FMA pass, 24 u for the matrix-core pass */) {
-    int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= h_pad) return;
-    counts[h] = 0;                       // the scoring kernel adds its point-splits' counts here (one memset launch less per batch)
+__device__ __forceinline__ void ransac_hypothesis_lane(const float* __restrict__ pq, const int4 tr, const bool valid, const int h, const int h_pad,
+                                                       float* __restrict__ hyp, const unsigned* __restrict__ pmax, const float sqrt_tau, const float band_u) {
     float o[12];
-    bool valid = false;
-    int4 tr = make_int4(0, 0, 0, 0);
-    if (h < count) { tr = triples[h]; valid = tr.w != 0; }
     if (valid) {
         const int id[3] = {tr.x, tr.y, tr.z};
         float sp[3][3], tp[3][3];
@@ -145,6 +138,22 @@ __global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __
     }
     hyp[(size_t)12 * h_pad + h] = mid;
     hyp[(size_t)13 * h_pad + h] = half;
+}
+__global__ void k_ransac_hypotheses(const float* __restrict__ pq, const int4* __restrict__ triples, int count, int h_pad,
+                                    float* __restrict__ hyp, const unsigned* __restrict__ pmax, float sqrt_tau, int* __restrict__ counts,
+                                    float band_u /* E = band_u (A + s): 16 u for the FMA pass, 24 u for the matrix-core pass */) {
+    int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= h_pad) return;
+    counts[h] = 0;                       // the scoring kernel adds its point-splits' counts here (one memset launch less per batch)
+    bool valid = false;
+    int4 tr = make_int4(0, 0, 0, 0);
+    if (h < count) { tr = triples[h]; valid = tr.w != 0; }
+    ransac_hypothesis_lane(pq, tr, valid, h, h_pad, hyp, pmax, sqrt_tau, band_u);
+}
+
+__device__ __forceinline__ unsigned long long shfl_u64_down(unsigned long long v, int o) {
+    const unsigned lo = __shfl_down((unsigned)v, o, 64), hi = __shfl_down((unsigned)(v >> 32), o, 64);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // ------------------------------------------------------------------ scoring
@@ -884,6 +893,236 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         }
     } else if (want_stats) {
         stats(h_res);
+    }
+    return TDV_OK;
+}
+
+
+// ---- many small clouds against one target: the whole coarse alignment in a handful of launches (round 3) ---------------------
+// A batch of small instances (config C5: 1,024 clouds of ~400 voxels, 10,000 hypotheses each) is bound by what ransac_run_dev
+// does on the HOST per call - 30,000 index draws, a dozen launches, two synchronisations - not by its kernels.  Here:
+//   k_rb_sample      the reference's index stream on the device.  mt19937(42)'s raw outputs are the same for every cloud (the host
+//                    draws them once per call); only libstdc++'s Lemire mapping to [0, n) depends on the cloud.  A workgroup per
+//                    cloud maps the raw draws 1,024 at a time and compacts away the rejected ones (probability n / 2^32 each) with
+//                    a workgroup scan, so a rejection shifts everything after it exactly as the sequential loop does.
+//   k_rb_gather_pq   the (point, matched target) pairs of all clouds, each cloud padded to whole scoring chunks; k_pack_pq2 as usual
+//   k_rb_hypotheses  one lane per (cloud, iteration): the lane function of k_ransac_hypotheses
+//   k_rb_score       one workgroup per (cloud, 1,024 hypotheses): score_range_fast over all the cloud's chunks
+//   k_rb_select      one workgroup per cloud: the loop of registration.cpp:281-290 as two reductions - the first iteration
+//                    whose fitness passes the confidence bounds the prefix, then the first largest fitness inside it.
+// Index stream, transforms, counts and the winner are ransac_run_dev's (tests/test_gpu_c5.py and test_gpu_chain.py hold the batch
+// against the operator chain bit for bit).  The winner's rmse is not evaluated: the batch does not report it.
+struct RbResult { float T[12]; int best_iter, inliers, iterations_run, pad; };
+
+__global__ __launch_bounds__(1024)
+void k_rb_sample(const unsigned* __restrict__ raw, int n_raw, const int* __restrict__ off, int H, int* __restrict__ idx_out /* [clouds][3 H] */, int* __restrict__ fail) {
+    const int b = blockIdx.x, n = off[b + 1] - off[b];
+    if (n <= 0) return;
+    const unsigned range = (unsigned)n, thr = (0u - range) % range;        // libstdc++ 11 uniform_int_distribution (Lemire), see ctx.hip
+    int* out = idx_out + (size_t)b * 3 * H;
+    __shared__ int s_wave[16];
+    __shared__ int s_produced;
+    if (threadIdx.x == 0) s_produced = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r0 = 0; r0 < n_raw; r0 += 1024) {
+        const int produced = s_produced;
+        if (produced >= 3 * H) break;                                      // workgroup-uniform
+        const int r = r0 + threadIdx.x;
+        unsigned long long prod = 0ull; bool acc = false;
+        if (r < n_raw) { prod = (unsigned long long)raw[r] * (unsigned long long)range; acc = !((unsigned)prod < thr); }
+        const unsigned long long m = __ballot(acc);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
+        const int q = produced + before + __popcll(m & ((1ull << lane) - 1ull));
+        if (acc && q < 3 * H) out[q] = (int)(prod >> 32);
+        __syncthreads();
+        if (threadIdx.x == 0) s_produced = produced + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && s_produced < 3 * H) *fail = 1;                  // ran out of raw draws (cannot happen with the slack the host adds)
+}
+
+// pos_off[b]: first padded pair slot of cloud b (multiples of RS_PCH * 64); grid over all padded slots
+__global__ void k_rb_gather_pq(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr, const int* __restrict__ off,
+                               const int* __restrict__ pos_off, int n_clouds, int total_pos, int nt, float* __restrict__ pq, int* __restrict__ bad,
+                               unsigned* __restrict__ pmax /* [clouds] */) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= total_pos) return;
+    int a = 0, z = n_clouds;
+    while (z - a > 1) { const int m = (a + z) >> 1; if (pos_off[m] <= pos) a = m; else z = m; }
+    const int i = pos - pos_off[a], n = off[a + 1] - off[a];
+    float4 A, Bq;
+    if (i < n) {
+        const size_t P = (size_t)off[a] + i;
+        int c = corr[P];
+        if ((unsigned)c >= (unsigned)nt) { *bad = 1; c = 0; }
+        A = make_float4(src[3 * P], src[3 * P + 1], src[3 * P + 2], tgt[3 * c]);
+        Bq = make_float4(tgt[3 * c + 1], tgt[3 * c + 2], 0.f, 0.f);
+        float am = fmaxf(fabsf(A.x), fmaxf(fabsf(A.y), fabsf(A.z)));
+        if (!(am <= FLT_MAX)) am = INFINITY;
+        if (A.w != A.w || Bq.x != Bq.x || Bq.y != Bq.y) am = INFINITY;      // as k_gather_pq
+        if (am > 0.f) atomicMax(&pmax[a], __float_as_uint(am));
+    } else {
+        A = make_float4(0.f, 0.f, 0.f, INFINITY);
+        Bq = make_float4(INFINITY, INFINITY, 0.f, 0.f);
+    }
+    reinterpret_cast<float4*>(pq)[2 * (size_t)pos] = A;
+    reinterpret_cast<float4*>(pq)[2 * (size_t)pos + 1] = Bq;
+}
+
+__global__ void k_rb_hypotheses(const float* __restrict__ pq, const int* __restrict__ pos_off, const int* __restrict__ off, const int* __restrict__ idx /* [clouds][3 H] */,
+                                int H, int h_pad, float* __restrict__ hyp /* [clouds][14][h_pad] */, const unsigned* __restrict__ pmax, float sqrt_tau, float band_u) {
+    const int b = blockIdx.y, h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= h_pad || off[b + 1] == off[b]) return;
+    bool valid = false;
+    int4 tr = make_int4(0, 0, 0, 0);
+    if (h < H) {
+        const int* t = idx + (size_t)b * 3 * H + 3 * (size_t)h;
+        tr = make_int4(t[0], t[1], t[2], 0);
+        valid = !(tr.x == tr.y || tr.y == tr.z || tr.x == tr.z);           // registration.cpp:240
+    }
+    ransac_hypothesis_lane(pq + (size_t)pos_off[b] * 8, tr, valid, h, h_pad, hyp + (size_t)b * 14 * h_pad, pmax + b, sqrt_tau, band_u);
+}
+
+__global__ __launch_bounds__(RS_BLOCK)
+void k_rb_score(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq2, const int* __restrict__ pos_off, const int* __restrict__ off, float tau,
+                int* __restrict__ counts /* [clouds][h_pad] */) {
+    const int b = blockIdx.y;
+    if (off[b + 1] == off[b]) return;
+    const int base = blockIdx.x * RS_BLOCK + threadIdx.x;
+    const int chunks = (pos_off[b + 1] - pos_off[b]) / RS_PCH;
+    unsigned n_rescored = 0;
+    const int cnt = score_range_fast(hyp + (size_t)b * 14 * h_pad, h_pad, base, pq2 + (size_t)pos_off[b] * 6, 0, chunks, tau, n_rescored);
+    counts[(size_t)b * h_pad + base] = cnt;
+}
+
+__global__ __launch_bounds__(256)
+void k_rb_select(const int* __restrict__ idx, const int* __restrict__ counts, const float* __restrict__ hyp, const int* __restrict__ off, int H, int h_pad,
+                 float confidence, RbResult* __restrict__ res) {
+    const int b = blockIdx.x, n = off[b + 1] - off[b];
+    RbResult* r = res + b;
+    if (n <= 0) { if (threadIdx.x == 0) { r->best_iter = -1; r->inliers = 0; r->iterations_run = 0; } return; }
+    const int* t = idx + (size_t)b * 3 * H;
+    const int* c = counts + (size_t)b * h_pad;
+    const float fn = static_cast<float>((size_t)n);
+    __shared__ int s_stop;
+    __shared__ unsigned long long s_best[4];
+    if (threadIdx.x == 0) s_stop = H;
+    __syncthreads();
+    // the first iteration whose fitness passes the confidence ends the loop (registration.cpp:290)
+    int stop = H;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const bool valid = !(t[3 * h] == t[3 * h + 1] || t[3 * h + 1] == t[3 * h + 2] || t[3 * h] == t[3 * h + 2]);
+        if (valid && static_cast<float>(c[h]) / fn > confidence) { stop = h; break; }
+    }
+    atomicMin(&s_stop, stop);
+    __syncthreads();
+    const int k_end = s_stop < H ? s_stop + 1 : H;
+    // the first largest fitness among iterations [0, k_end): key = fitness bits (positive floats order as their bits), then
+    // the EARLIEST iteration (largest H - h)
+    unsigned long long best = 0ull;
+    for (int h = threadIdx.x; h < k_end; h += 256) {
+        const bool valid = !(t[3 * h] == t[3 * h + 1] || t[3 * h + 1] == t[3 * h + 2] || t[3 * h] == t[3 * h + 2]);
+        if (!valid) continue;
+        const float fit = static_cast<float>(c[h]) / fn;                     // registration.cpp:281
+        if (!(fit > 0.f)) continue;                                          // has to beat the initial best fitness 0 (:284)
+        const unsigned long long key = ((unsigned long long)__float_as_uint(fit) << 32) | (unsigned)(H - h);
+        best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = shfl_u64_down(best, o); best = x > best ? x : best; }
+    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) best = s_best[w] > best ? s_best[w] : best;
+        r->iterations_run = k_end;
+        if (best == 0ull) { r->best_iter = -1; r->inliers = 0; }
+        else {
+            const int h = H - (int)(unsigned)(best & 0xffffffffull);
+            r->best_iter = h; r->inliers = c[h];
+            const float* hp = hyp + (size_t)b * 14 * h_pad;
+            for (int e = 0; e < 12; ++e) r->T[e] = hp[(size_t)e * h_pad + h];
+        }
+    }
+}
+
+int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, const int* d_off, int n_clouds, const float* d_tgt, int nt, const int* d_corr,
+                           float voxel, int max_iterations, float confidence, uint32_t seed, tdv_ransac_result* out, int* fell_back) {
+    if (!ctx || !h_off || !d_off || !out || !fell_back || n_clouds < 0 || nt < 0 || max_iterations < 0) return TDV_ERR_BAD_ARG;
+    *fell_back = 0;
+    for (int b = 0; b < n_clouds; ++b) {      // RegistrationResult defaults (include/registration.hpp:26-30)
+        for (int i = 0; i < 16; ++i) out[b].T[i] = (i % 5 == 0) ? 1.f : 0.f;
+        out[b].fitness = 0.f; out[b].rmse = 0.f; out[b].inliers = 0; out[b].best_iteration = -1; out[b].iterations_run = 0;
+    }
+    const int total = n_clouds ? h_off[n_clouds] : 0;
+    if (total == 0 || nt == 0 || max_iterations == 0) return TDV_OK;
+    if (!d_src || !d_tgt || !d_corr) return TDV_ERR_BAD_ARG;
+    static const bool off_env = getenv("TDV_RANSAC_BATCH") && atoi(getenv("TDV_RANSAC_BATCH")) == 0;   // A/B knob
+    const bool fast_mode = ctx->ransac_score_mode == TDV_RANSAC_SCORE_FAST && !(getenv("TDV_RANSAC_SCORE") && strcmp(getenv("TDV_RANSAC_SCORE"), "fast"));
+    int v_max = 0;
+    for (int b = 0; b < n_clouds; ++b) v_max = std::max(v_max, h_off[b + 1] - h_off[b]);
+    if (off_env || !fast_mode || v_max > 4096 || max_iterations > 32768) { *fell_back = 1; return TDV_OK; }
+    hipStream_t s = ctx->stream;
+    const float thr = voxel * 1.5f;  // registration.cpp:213
+    const float tau = tau_lt(thr);
+    const float sqrt_tau = std::nextafter((float)std::sqrt((double)tau), INFINITY);
+    const int H = max_iterations, h_pad = (int)align_up((size_t)H, RS_HYP_PER_BLOCK), hb = h_pad / RS_HYP_PER_BLOCK;
+    // padded pair slots per cloud
+    std::vector<int> pos_off((size_t)n_clouds + 1, 0);
+    for (int b = 0; b < n_clouds; ++b) pos_off[b + 1] = pos_off[b] + (int)align_up((size_t)(h_off[b + 1] - h_off[b]), (size_t)RS_PCH * 64);
+    const int total_pos = pos_off[n_clouds];
+    const int n_raw = 3 * H + 4096;                                            // slack for rejected draws (each has probability n / 2^32)
+    int* d_pos_off; unsigned* d_raw; int* d_idx; float *pq, *pq2, *hyp; int* counts; unsigned* d_pmax; int* d_flags; RbResult* d_res;
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 1, &d_pos_off));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_raw, &d_raw));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds * 3 * H, &d_idx));
+    TDV_TRY(ws_alloc(ctx, (size_t)total_pos * 8, &pq));
+    TDV_TRY(ws_alloc(ctx, (size_t)total_pos * 6, &pq2));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds * 14 * h_pad, &hyp));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds * h_pad, &counts));
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_pmax));                     // pmax[clouds] | bad | fail
+    d_flags = reinterpret_cast<int*>(d_pmax + n_clouds);
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds, &d_res));
+    const size_t pin_raw = align_up((size_t)n_raw * 4, 64), pin_res = align_up((size_t)n_clouds * sizeof(RbResult), 64);
+    TDV_TRY(pin_reserve(ctx, pin_raw + pin_res + 64 + ((size_t)n_clouds + 1) * 4));
+    unsigned* h_raw = reinterpret_cast<unsigned*>(ctx->pin);
+    RbResult* h_res = reinterpret_cast<RbResult*>(ctx->pin + pin_raw);
+    int* h_flags = reinterpret_cast<int*>(ctx->pin + pin_raw + pin_res);
+    int* h_pos = h_flags + 16;
+    mt19937_raw(seed, (size_t)n_raw, h_raw);
+    std::memcpy(h_pos, pos_off.data(), ((size_t)n_clouds + 1) * 4);
+    TDV_HIP(ctx, hipMemcpyAsync(d_raw, h_raw, (size_t)n_raw * 4, hipMemcpyHostToDevice, s));
+    TDV_HIP(ctx, hipMemcpyAsync(d_pos_off, h_pos, ((size_t)n_clouds + 1) * 4, hipMemcpyHostToDevice, s));
+    TDV_HIP(ctx, hipMemsetAsync(d_pmax, 0, ((size_t)n_clouds + 2) * 4, s));
+    k_rb_sample<<<n_clouds, 1024, 0, s>>>(d_raw, n_raw, d_off, H, d_idx, d_flags + 1);
+    k_rb_gather_pq<<<(total_pos + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, d_off, d_pos_off, n_clouds, total_pos, nt, pq, d_flags, d_pmax);
+    k_pack_pq2<<<(total_pos / 2 + 255) / 256, 256, 0, s>>>(pq, total_pos, pq2);
+    k_rb_hypotheses<<<dim3((h_pad + 255) / 256, n_clouds), 256, 0, s>>>(pq, d_pos_off, d_off, d_idx, H, h_pad, hyp, d_pmax, sqrt_tau, 16.f * 5.9604644775390625e-08f);
+    {
+        ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
+        k_rb_score<<<dim3(hb, n_clouds), RS_BLOCK, 0, s>>>(hyp, h_pad, pq2, d_pos_off, d_off, tau, counts);
+    }
+    k_rb_select<<<n_clouds, 256, 0, s>>>(d_idx, counts, hyp, d_off, H, h_pad, confidence, d_res);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)n_clouds * sizeof(RbResult), hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipMemcpyAsync(h_flags, d_flags, 8, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    ctx->last_ransac_rescore = -1.0; ctx->last_ransac_scored = 1.0;
+    if (h_flags[0]) { std::snprintf(ctx->err, sizeof(ctx->err), "ransac: a correspondence index lies outside [0, %d)", nt); return TDV_ERR_BAD_ARG; }
+    if (h_flags[1]) { *fell_back = 1; return TDV_OK; }
+    for (int b = 0; b < n_clouds; ++b) {
+        const int n = h_off[b + 1] - h_off[b];
+        if (n == 0) continue;
+        const RbResult& r = h_res[b];
+        out[b].iterations_run = r.iterations_run;
+        if (r.best_iter < 0) continue;
+        for (int c = 0; c < 3; ++c) for (int q = 0; q < 3; ++q) out[b].T[c * 4 + q] = r.T[c * 3 + q];
+        out[b].T[12] = r.T[9]; out[b].T[13] = r.T[10]; out[b].T[14] = r.T[11];
+        out[b].inliers = r.inliers; out[b].best_iteration = r.best_iter;
+        out[b].fitness = static_cast<float>(r.inliers) / static_cast<float>((size_t)n);
     }
     return TDV_OK;
 }

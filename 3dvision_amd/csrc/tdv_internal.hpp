@@ -126,12 +126,21 @@ int cell_grid_build(tdv_ctx* ctx, const float* d_tgt, int nt, float thr, CellGri
 int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, const float* d_tgt_normals, int nt,
                 const float* T0, float thr, int max_iterations, int point_to_plane, int fixed_iterations,
                 tdv_icp_result* out, const SortedCloud* tgt_sorted = nullptr, const CellGrid* tgt_grid = nullptr);
+// many small problems against one target in one launch (icp.hip: k_icp_small); sizes up to icp_small_max_points() each
+int icp_small_max_points();
+int icp_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* d_src_off, int n_prob, const float* d_tgt, const float* d_tgt_normals, int nt,
+                        const float* T0s, float thr, int max_iterations, int point_to_plane, tdv_icp_result* out);
 int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
                             const float* T, float thr, IcpOutputs outs, int* n_corr);
 int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
                    const float* d_fs, const float* d_ft, const int* d_corr,
                    float voxel, int max_iterations, float confidence, uint32_t seed,
                    tdv_ransac_result* out, int* trace_inliers);
+// ransac_run_dev for many small clouds against one target in a handful of launches (ransac.hip): cloud b = points
+// [h_off[b], h_off[b+1]) of d_src with correspondences d_corr (same indexing); out[b].rmse is NOT evaluated (0).  *fell_back = 1:
+// nothing was computed (a cloud too large, too many hypotheses, or the index sampler ran out of draws) - use ransac_run_dev.
+int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, const int* d_off, int n_clouds, const float* d_tgt, int nt, const int* d_corr,
+                           float voxel, int max_iterations, float confidence, uint32_t seed, tdv_ransac_result* out, int* fell_back);
 int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr);
 // Packed index of a target descriptor set (fmatch.hip): rows in sort-tile-recursive order along the set's principal
 // directions, padded per column, with 33-D boxes of the 64-row leaves and the 64-leaf groups.  Lives in the workspace
@@ -216,6 +225,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
 
 // host helpers
 void mt19937_lemire_triples(uint32_t seed, uint64_t n, int count, uint64_t* out);
+void mt19937_raw(uint32_t seed, size_t count, uint32_t* out);
 // the same index stream, drawn incrementally (one (i0, i1, i2) triple per call) so that it can be produced batch by
 // batch while the GPU scores the previous batch
 class TripleStream {
