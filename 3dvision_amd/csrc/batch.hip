@@ -400,7 +400,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     if (batched_icp) {
         std::vector<tdv_icp_result> fine((size_t)n_instances);
         TDV_TRY(icp_small_batch_dev(ctx, want_ref ? vox_ref_all : vox_first_all, d_voff, n_instances, d_model_xyz, d_model_normals, n_model, coarse_T.data(), icp_thr,
-                                    prm->icp_max_iterations, prm->point_to_plane, fine.data()));
+                                    prm->icp_max_iterations, prm->point_to_plane, fine.data(), v_max));
         for (int b = 0; b < n_instances; ++b) {
             if (off[b + 1] == off[b]) continue;
             tdv_instance_result& r = results[b];

@@ -562,6 +562,84 @@ void k_depth_emit_bits(const uint16_t* __restrict__ raw0, const int* __restrict_
     }
 }
 
+// ---- label images: every instance's cloud from ONE pass over the frame (round 3) ---------------------------------------------
+// A label image assigns each pixel to at most one instance (label = instance + 1, u8 or u16), so the per-instance kernels above
+// - a grid of (pixel blocks x instances), every instance re-reading the whole image: 1.7 ms for C5's 1,024 instances - are the
+// wrong shape.  Here a wave owns a tile of 1,024 consecutive pixels and walks it in 16 rounds of 64 (lane = pixel).  The valid
+// pixels of a round are grouped by label (one pass per distinct label: an object's pixels are neighbours, a round holds one to
+// three labels): pass 1 adds the group's size to counts[instance][tile]; after the usual scan, pass 2 takes the group's base
+// from the scanned entry with an atomic add of its size - only this wave ever touches (instance, tile), and it walks its rounds
+// in order, so the bases it gets are the row-major ones - and every pixel writes at base + its rank among the group's lanes.
+// Frame bytes are read twice (4 B per pixel and pass), the clouds written once.
+template <bool L16>
+__device__ __forceinline__ int label_at(const uint8_t* __restrict__ labels, size_t i) {
+    return L16 ? (int)reinterpret_cast<const uint16_t*>(labels)[i] : (int)labels[i];
+}
+template <bool L16>
+__global__ __launch_bounds__(256)
+void k_label_count(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ labels, size_t n, int n_inst, float inv_scale, float zmax, int ntiles,
+                   int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    for (int j = 0; j < 16; ++j) {
+        const size_t i = (size_t)tile * 1024 + 64 * j + lane;
+        int L = 0;
+        if (i < n) {
+            const float z = (float)raw[i] * inv_scale;                         // pipeline.cpp:47
+            const int l = label_at<L16>(labels, i);
+            if (!(z <= 0.f || z > zmax) && l >= 1 && l <= n_inst) L = l;       // pipeline.cpp:71
+        }
+        unsigned long long todo = __ballot(L != 0);
+        while (todo) {                                                          // wave-uniform
+            const int src = __builtin_ctzll(todo);
+            const int Ls = __builtin_amdgcn_readlane(L, src);
+            const unsigned long long m = __ballot(L == Ls);
+            if (lane == src) atomicAdd(&counts[(size_t)(Ls - 1) * ntiles + tile], __popcll(m));
+            todo &= ~m;
+        }
+    }
+}
+template <bool L16>
+__global__ __launch_bounds__(256)
+void k_label_emit(const uint16_t* __restrict__ raw, const uint8_t* __restrict__ labels, const uint8_t* __restrict__ bgr, int width, size_t n, int n_inst,
+                  float inv_scale, float fx, float fy, float cx, float cy, float zmax, int ntiles, int* __restrict__ offsets,
+                  float* __restrict__ xyz, float* __restrict__ rgb) {
+    const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    for (int j = 0; j < 16; ++j) {
+        const size_t i = (size_t)tile * 1024 + 64 * j + lane;
+        int L = 0; float z = 0.f;
+        if (i < n) {
+            z = (float)raw[i] * inv_scale;
+            const int l = label_at<L16>(labels, i);
+            if (!(z <= 0.f || z > zmax) && l >= 1 && l <= n_inst) L = l;
+        }
+        unsigned long long todo = __ballot(L != 0);
+        int slot = 0;
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            const int Ls = __builtin_amdgcn_readlane(L, src);
+            const unsigned long long m = __ballot(L == Ls);
+            int base = 0;
+            if (lane == src) base = atomicAdd(&offsets[(size_t)(Ls - 1) * ntiles + tile], __popcll(m));
+            base = __builtin_amdgcn_readlane(base, src);
+            if (L == Ls) slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            todo &= ~m;
+        }
+        if (L != 0) {
+            const int v = (int)(i / width), u = (int)(i - (size_t)v * width);
+            const size_t o = 3 * (size_t)slot;
+            xyz[o] = ((float)u - cx) * z / fx;                                    // pipeline.cpp:73
+            xyz[o + 1] = ((float)v - cy) * z / fy;                                // pipeline.cpp:74
+            xyz[o + 2] = z;
+            if (rgb && bgr) {
+                const uint8_t* p = bgr + i * 3;
+                rgb[o] = (float)p[2] / 255.0f; rgb[o + 1] = (float)p[1] / 255.0f; rgb[o + 2] = (float)p[0] / 255.0f;   // pipeline.cpp:78-80
+            }
+        }
+    }
+}
+
 __global__ void k_gather_instance_offsets(const int* __restrict__ offsets, const int* __restrict__ total, int blocks, int n_inst, int* __restrict__ out) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < n_inst) out[b] = offsets[(size_t)b * blocks];
@@ -623,8 +701,9 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
     int raw_lo = 1, raw_hi = 0;
-    const bool vec = stacked != 2 && batch_vectorisable(d_raw, d_masks, n) && depth_valid_range(inv_scale, zmax, &raw_lo, &raw_hi);
-    const int blocks = vec ? (int)((n + DB_TILE - 1) / DB_TILE) : (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);   // tiles resp. workgroups per instance
+    const bool label_image = stacked != 1;                      // one u8 (0) or u16 (2) label image: the one-pass kernels
+    const bool vec = !label_image && batch_vectorisable(d_raw, d_masks, n) && depth_valid_range(inv_scale, zmax, &raw_lo, &raw_hi);
+    const int blocks = vec ? (int)((n + DB_TILE - 1) / DB_TILE) : (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);   // tiles resp. workgroups per instance (1,024 pixels either way)
     int *counts, *offsets, *d_total, *d_inst;
     TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &counts));
     TDV_TRY(ws_alloc(ctx, (size_t)blocks * n_inst, &offsets));
@@ -633,13 +712,17 @@ int depth_to_cloud_batch_count(tdv_ctx* ctx, const uint16_t* d_raw, const int* d
     ctx->depth_bits = nullptr;
     if (vec) TDV_TRY(ws_alloc(ctx, (size_t)n_inst * (n / DB_PX), &ctx->depth_bits));
     hipStream_t s = ctx->stream;
+    if (label_image && d_frame_of) return TDV_ERR_BAD_ARG;      // a label image belongs to one frame
+    if (label_image) TDV_HIP(ctx, hipMemsetAsync(counts, 0, (size_t)blocks * n_inst * 4, s));
     {
         ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-        if (vec) {
+        if (label_image) {
+            if (stacked == 2) k_label_count<true><<<(blocks + 3) / 4, 256, 0, s>>>(d_raw, d_masks, n, n_inst, inv_scale, zmax, blocks, counts);
+            else k_label_count<false><<<(blocks + 3) / 4, 256, 0, s>>>(d_raw, d_masks, n, n_inst, inv_scale, zmax, blocks, counts);
+        } else if (vec) {
             const dim3 grid((blocks + DP_BLOCK / 64 - 1) / (DP_BLOCK / 64), (n_inst + DB_GROUP - 1) / DB_GROUP);
 #define TDV_DEPTH_BITS(ST, PF) k_depth_bits<ST, PF><<<grid, DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, n_inst, raw_lo, raw_hi, mask_mode, blocks, ctx->depth_bits, counts)
-            if (stacked) { if (d_frame_of) TDV_DEPTH_BITS(true, true); else TDV_DEPTH_BITS(true, false); }
-            else { if (d_frame_of) TDV_DEPTH_BITS(false, true); else TDV_DEPTH_BITS(false, false); }
+            if (d_frame_of) TDV_DEPTH_BITS(true, true); else TDV_DEPTH_BITS(true, false);
 #undef TDV_DEPTH_BITS
         } else k_valid_count_batch<<<dim3(blocks, n_inst), DP_BLOCK, 0, s>>>(d_raw, d_frame_of, d_masks, n, stacked, inv_scale, mask_mode, zmax, counts);
     }
@@ -664,9 +747,14 @@ int depth_to_cloud_batch_emit(tdv_ctx* ctx, const uint16_t* d_raw, const int* d_
                               const int* d_offsets, float* d_xyz, float* d_rgb) {
     const size_t n = (size_t)w * h;
     const float inv_scale = (float)(1.0 / (double)scale);
-    const bool vec = batch_vectorisable(d_raw, d_masks, n) && ctx->depth_bits;   // pass 1 left a bitmap: it took the tiled path
+    const bool vec = stacked == 1 && batch_vectorisable(d_raw, d_masks, n) && ctx->depth_bits;   // pass 1 left a bitmap: it took the tiled path
     ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-    if (vec) {
+    if (stacked != 1) {                                          // label image: the one-pass kernels (the scanned offsets serve as cursors)
+        const int ntiles = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
+        int* cursors = const_cast<int*>(d_offsets);
+        if (stacked == 2) k_label_emit<true><<<(ntiles + 3) / 4, 256, 0, ctx->stream>>>(d_raw, d_masks, d_bgr, w, n, n_inst, inv_scale, fx, fy, cx, cy, zmax, ntiles, cursors, d_xyz, d_rgb);
+        else k_label_emit<false><<<(ntiles + 3) / 4, 256, 0, ctx->stream>>>(d_raw, d_masks, d_bgr, w, n, n_inst, inv_scale, fx, fy, cx, cy, zmax, ntiles, cursors, d_xyz, d_rgb);
+    } else if (vec) {
         const int ntiles = (int)((n + DB_TILE - 1) / DB_TILE);
         const int tiles_per_block = (DE_BLOCK / 64) * DE_TPW;
         const dim3 grid((ntiles + tiles_per_block - 1) / tiles_per_block, n_inst);

@@ -610,10 +610,11 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
 //    added as (w0 + w1) + (w2 + w3) into a slab, slabs folded in the same pattern - so a call gives the same bits whichever path
 //    its size selects.
 constexpr int SM_MAX_N = 2048;           // sources and targets the one-launch loop takes
-constexpr int SM_THREADS = 1024;
 // A grid of several workgroups runs one problem each (the batch's small instances against the shared model): problem b takes the
 // source points [src_off[b], src_off[b + 1]) of src0 and the states st_in[b] / st_out[b]; src_off == nullptr: one problem.
-template <int MODE>
+// Two shapes: 1,024 lanes and room for 2,048 x 2,048 points, or 256 lanes and 1,024 x 1,024 - a quarter of the LDS and of the
+// wave slots, so that several times as many problems of a batch run at once (the loop is a chain of latencies, not throughput).
+template <int MODE, int SM_THREADS, int SM_CAP>
 __global__ __launch_bounds__(SM_THREADS)
 void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict__ src_off, const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int nt,
                  const IcpState* __restrict__ st_in0, float tau_accept, int max_iterations, int fixed_iterations,
@@ -624,11 +625,11 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
     const IcpState* __restrict__ st_in = st_in0 + prob;
     IcpState* __restrict__ st_out = st_out0 + prob;
     if (ns == 0) { if (threadIdx.x == 0) *st_out = *st_in; return; }   // (an instance without points: the caller ignores its state)
-    __shared__ float tx[SM_MAX_N], ty[SM_MAX_N], tz[SM_MAX_N];
-    __shared__ float sbest[SM_MAX_N];
-    __shared__ int sidx[SM_MAX_N];
+    __shared__ float tx[SM_CAP], ty[SM_CAP], tz[SM_CAP];
+    __shared__ float sbest[SM_CAP];
+    __shared__ int sidx[SM_CAP];
     __shared__ double red[SM_THREADS / 64][ACC_NV];       // wave sums, four per virtual block
-    __shared__ double slab[SM_MAX_N / 256][ACC_NV];
+    __shared__ double slab[SM_CAP / 256][ACC_NV];
     __shared__ double fold[8][ACC_NV];
     __shared__ double tot[ACC_NV];
     __shared__ IcpState st;
@@ -848,9 +849,9 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
         {
             ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
             if (point_to_plane && d_tgt_normals)
-                k_icp_small<0><<<1, SM_THREADS, 0, s>>>(d_src, ns, nullptr, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+                k_icp_small<0, 1024, SM_MAX_N><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
             else
-                k_icp_small<1><<<1, SM_THREADS, 0, s>>>(d_src, ns, nullptr, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+                k_icp_small<1, 1024, SM_MAX_N><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
         }
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipStreamSynchronize(s));
@@ -922,7 +923,7 @@ int icp_small_max_points() { return SM_MAX_N; }
 // of d_src (each at most icp_small_max_points(), as nt), start pose T0s[b] (host, column-major).  Results as icp_run_dev's, bit for
 // bit (the same kernel).  One upload, one launch, one download.
 int icp_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* d_src_off, int n_prob, const float* d_tgt, const float* d_tgt_normals, int nt,
-                        const float* T0s, float thr, int max_iterations, int point_to_plane, tdv_icp_result* out) {
+                        const float* T0s, float thr, int max_iterations, int point_to_plane, tdv_icp_result* out, int ns_max) {
     if (!ctx || !d_src || !d_src_off || !d_tgt || !T0s || !out || n_prob < 0 || nt <= 0 || nt > SM_MAX_N || max_iterations < 0) return TDV_ERR_BAD_ARG;
     if (n_prob == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
@@ -936,10 +937,15 @@ int icp_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* d_src_off, 
     TDV_HIP(ctx, hipMemcpyAsync(d_st, h, (size_t)n_prob * sizeof(IcpState), hipMemcpyHostToDevice, s));
     if (max_iterations > 0) {
         ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
-        if (point_to_plane && d_tgt_normals)
-            k_icp_small<0><<<n_prob, SM_THREADS, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
-        else
-            k_icp_small<1><<<n_prob, SM_THREADS, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+        const bool p2pl = point_to_plane && d_tgt_normals;
+        const bool tiny = ns_max > 0 && ns_max <= 1024 && nt <= 1024;      // every problem fits the quarter-size shape (same results: the same reduction tree)
+        if (tiny) {
+            if (p2pl) k_icp_small<0, 256, 1024><<<n_prob, 256, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+            else k_icp_small<1, 256, 1024><<<n_prob, 256, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+        } else {
+            if (p2pl) k_icp_small<0, 1024, SM_MAX_N><<<n_prob, 1024, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+            else k_icp_small<1, 1024, SM_MAX_N><<<n_prob, 1024, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+        }
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipMemcpyAsync(h, d_st + n_prob, (size_t)n_prob * sizeof(IcpState), hipMemcpyDeviceToHost, s));
     }

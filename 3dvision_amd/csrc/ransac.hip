@@ -945,7 +945,7 @@ void k_rb_sample(const unsigned* __restrict__ raw, int n_raw, const int* __restr
     if (threadIdx.x == 0 && s_produced < 3 * H) *fail = 1;                  // ran out of raw draws (cannot happen with the slack the host adds)
 }
 
-// pos_off[b]: first padded pair slot of cloud b (multiples of RS_PCH * 64); grid over all padded slots
+// pos_off[b]: first padded pair slot of cloud b (multiples of 2 RS_PCH); grid over all padded slots
 __global__ void k_rb_gather_pq(const float* __restrict__ src, const float* __restrict__ tgt, const int* __restrict__ corr, const int* __restrict__ off,
                                const int* __restrict__ pos_off, int n_clouds, int total_pos, int nt, float* __restrict__ pq, int* __restrict__ bad,
                                unsigned* __restrict__ pmax /* [clouds] */) {
@@ -1072,7 +1072,7 @@ int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, c
     const int H = max_iterations, h_pad = (int)align_up((size_t)H, RS_HYP_PER_BLOCK), hb = h_pad / RS_HYP_PER_BLOCK;
     // padded pair slots per cloud
     std::vector<int> pos_off((size_t)n_clouds + 1, 0);
-    for (int b = 0; b < n_clouds; ++b) pos_off[b + 1] = pos_off[b] + (int)align_up((size_t)(h_off[b + 1] - h_off[b]), (size_t)RS_PCH * 64);
+    for (int b = 0; b < n_clouds; ++b) pos_off[b + 1] = pos_off[b] + (int)align_up((size_t)(h_off[b + 1] - h_off[b]), (size_t)RS_PCH * 2);   // whole chunks of RS_PCH pairs, 64-B aligned records
     const int total_pos = pos_off[n_clouds];
     const int n_raw = 3 * H + 4096;                                            // slack for rejected draws (each has probability n / 2^32)
     int* d_pos_off; unsigned* d_raw; int* d_idx; float *pq, *pq2, *hyp; int* counts; unsigned* d_pmax; int* d_flags; RbResult* d_res;
