@@ -290,12 +290,16 @@ TDV_DI bool smallest_eigvec3(float a00, float a10, float a20, float a11, float a
 }
 
 // Solve A x = b for symmetric 6x6 A (row-major, lower triangle read) by pivoted LDL^T.
-__device__ inline void ldlt6_solve(const float* Ain, const float* b, float* x) {
+// ws: 54 words of scratch for the factor, the pivots and two vectors.  The pivoting indexes them at run time, so as private arrays
+// they live in scratch MEMORY and every access is a round trip to the cache hierarchy (the ICP kernels spent 25-40 us per
+// iteration in this one-lane solve); callers pass LDS.  Same operations in the same order either way.
+__device__ inline void ldlt6_solve(const float* Ain, const float* b, float* x, float* ws) {
     const int N = 6;
-    float mat[6][6];
+    float (*mat)[6] = reinterpret_cast<float (*)[6]>(ws);
+    float* temp = ws + 36;
+    float* y = ws + 42;
+    int* transp = reinterpret_cast<int*>(ws + 48);
     for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) mat[i][j] = Ain[i * 6 + j];
-    int transp[6];
-    float temp[6];
     for (int k = 0; k < N; ++k) {
         int big = k; float bv = fabsf(mat[k][k]);
         for (int i = k + 1; i < N; ++i) if (fabsf(mat[i][i]) > bv) { bv = fabsf(mat[i][i]); big = i; }
@@ -324,7 +328,6 @@ __device__ inline void ldlt6_solve(const float* Ain, const float* b, float* x) {
         if (k == 0 && !valid) { for (int j = 0; j < N; ++j) transp[j] = j; break; }
         if (rs > 0 && valid) for (int i = 0; i < rs; ++i) mat[k + 1 + i][k] /= akk;
     }
-    float y[6];
     for (int i = 0; i < N; ++i) y[i] = b[i];
     for (int k = 0; k < N; ++k) if (transp[k] != k) { float t = y[k]; y[k] = y[transp[k]]; y[transp[k]] = t; }
     for (int i = 0; i < N; ++i) { float a = y[i]; for (int j = 0; j < i; ++j) a -= mat[i][j] * y[j]; y[i] = a; }
@@ -332,6 +335,10 @@ __device__ inline void ldlt6_solve(const float* Ain, const float* b, float* x) {
     for (int i = N - 1; i >= 0; --i) { float a = y[i]; for (int j = i + 1; j < N; ++j) a -= mat[j][i] * y[j]; y[i] = a; }
     for (int k = N - 1; k >= 0; --k) if (transp[k] != k) { float t = y[k]; y[k] = y[transp[k]]; y[transp[k]] = t; }
     for (int i = 0; i < N; ++i) x[i] = y[i];
+}
+__device__ inline void ldlt6_solve(const float* Ain, const float* b, float* x) {   // private scratch: for callers without LDS to spare
+    float ws[54];
+    ldlt6_solve(Ain, b, x, ws);
 }
 
 // Rx(a) * Ry(b) * Rz(g) through quaternions.

@@ -412,7 +412,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // (iter, prev_rmse, Tcur: the state as the kernel read it at its start - no other launch writes it in between - so that the
 // tail of the iteration does not begin with another round trip to memory)
 template <int MODE>
-__device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_iterations, int iter, float prev_rmse, const float* Tcur) {
+__device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_iterations, int iter, float prev_rmse, const float* Tcur, float* solve_ws /* LDS, 54 words */) {
     const int n_corr = (int)(tot[0] + 0.5);
     st->iter = iter + 1;
     st->n_corr = n_corr;
@@ -429,7 +429,7 @@ __device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_it
         for (int a = 0; a < 6; ++a)
             for (int b = a; b < 6; ++b) { float val = (float)tot[k++]; ATA[a * 6 + b] = val; ATA[b * 6 + a] = val; }
         for (int a = 0; a < 6; ++a) nb[a] = -(float)tot[k++];
-        dl::ldlt6_solve(ATA, nb, x);
+        dl::ldlt6_solve(ATA, nb, x, solve_ws);
         dl::Mat3 dR = dl::euler_xyz(x[0], x[1], x[2]);
         for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) delta[c * 4 + r] = dl::el(dR, r, c);
         delta[12] = x[3]; delta[13] = x[4]; delta[14] = x[5];
@@ -544,6 +544,7 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
     constexpr int NV = MODE == 0 ? 29 : (MODE == 1 ? 17 : 2);
     __shared__ double red[8][ACC_NV];
     __shared__ double tot[ACC_NV];
+    __shared__ float solve_ws[56];
     __shared__ bool is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -595,7 +596,7 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
         float T16[16];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { T16[c * 4] = T[c * 3]; T16[c * 4 + 1] = T[c * 3 + 1]; T16[c * 4 + 2] = T[c * 3 + 2]; T16[c * 4 + 3] = Tb[c]; }
-        icp_update<MODE>(tot, ns, st, fixed_iterations, iter0, rmse0, T16);
+        icp_update<MODE>(tot, ns, st, fixed_iterations, iter0, rmse0, T16, solve_ws);
     }
 }
 
@@ -632,6 +633,7 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
     __shared__ double slab[SM_CAP / 256][ACC_NV];
     __shared__ double fold[8][ACC_NV];
     __shared__ double tot[ACC_NV];
+    __shared__ float solve_ws[56];
     __shared__ IcpState st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int j = threadIdx.x; j < nt; j += SM_THREADS) { tx[j] = tgt[3 * j]; ty[j] = tgt[3 * j + 1]; tz[j] = tgt[3 * j + 2]; }
@@ -723,7 +725,7 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
         }
         __syncthreads();
         // (d) solve, update, stopping rule
-        if (threadIdx.x == 0) icp_update<MODE>(tot, ns, &st, fixed_iterations, iter0, rmse0, T);
+        if (threadIdx.x == 0) icp_update<MODE>(tot, ns, &st, fixed_iterations, iter0, rmse0, T, solve_ws);
         __syncthreads();
         if (st.done) break;
     }
