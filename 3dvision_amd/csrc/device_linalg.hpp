@@ -289,56 +289,123 @@ TDV_DI bool smallest_eigvec3(float a00, float a10, float a20, float a11, float a
     return ok;
 }
 
-// Solve A x = b for symmetric 6x6 A (row-major, lower triangle read) by pivoted LDL^T.
-// ws: 54 words of scratch for the factor, the pivots and two vectors.  The pivoting indexes them at run time, so as private arrays
-// they live in scratch MEMORY and every access is a round trip to the cache hierarchy (the ICP kernels spent 25-40 us per
-// iteration in this one-lane solve); callers pass LDS.  Same operations in the same order either way.
-__device__ inline void ldlt6_solve(const float* Ain, const float* b, float* x, float* ws) {
-    const int N = 6;
-    float (*mat)[6] = reinterpret_cast<float (*)[6]>(ws);
-    float* temp = ws + 36;
-    float* y = ws + 42;
-    int* transp = reinterpret_cast<int*>(ws + 48);
-    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) mat[i][j] = Ain[i * 6 + j];
+// Solve A x = b for symmetric 6x6 A (row-major, lower triangle read) by pivoted LDL^T (the sequence of operations of
+// Eigen::LDLT<Matrix<float,6,6>>::compute + solve, as oracle/small_linalg.hpp restates it).
+//
+// The only run-time index of the algorithm is the pivot `big` of step k.  With the lower triangle in 21 REGISTERS and the
+// symmetric interchange of k and big written as predicated moves over the (static) triangle positions, every other access has
+// compile-time indices: no scratch memory, no LDS.  (As private arrays indexed at run time the factor lived in scratch memory:
+// ~500 dependent round trips per solve, 25-40 us per ICP iteration in round 2's one-lane tail; in LDS ~10 us.)  The values each
+// operation sees, and the order of the operations, are unchanged - tests/test_gpu_icp.py and test_gpu_demo_chain.py hold the
+// device transform against the CPU restatement bit for bit, the rank-deficient planar case (zero pivots) included.
+__device__ __forceinline__ void ldlt6_solve(const float* Ain, const float* b, float* x) {
+    constexpr int N = 6;
+    float L[N][N];                                      // only j <= i is used
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) L[i][j] = Ain[i * 6 + j];
+    int transp[N];
+    bool stop = false;                                  // k == 0 with a zero pivot: Eigen leaves the matrix alone, identity permutation
+#pragma unroll
     for (int k = 0; k < N; ++k) {
-        int big = k; float bv = fabsf(mat[k][k]);
-        for (int i = k + 1; i < N; ++i) if (fabsf(mat[i][i]) > bv) { bv = fabsf(mat[i][i]); big = i; }
+        if (stop) break;
+        int big = k; float bv = fabsf(L[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) { const float a = fabsf(L[i][i]); if (a > bv) { bv = a; big = i; } }
         transp[k] = big;
-        if (k != big) {
-            int s = N - big - 1;
-            for (int j = 0; j < k; ++j) { float t = mat[k][j]; mat[k][j] = mat[big][j]; mat[big][j] = t; }
-            for (int i = 0; i < s; ++i) { float t = mat[big + 1 + i][k]; mat[big + 1 + i][k] = mat[big + 1 + i][big]; mat[big + 1 + i][big] = t; }
-            { float t = mat[k][k]; mat[k][k] = mat[big][big]; mat[big][big] = t; }
-            for (int i = k + 1; i < big; ++i) { float t = mat[i][k]; mat[i][k] = mat[big][i]; mat[big][i] = t; }
+        if (big != k) {
+            // the four partial interchanges of Eigen's in-place LDLT on the lower triangle, each written over the STATIC rows /
+            // columns that `big` can be: a predicated swap per candidate position
+            auto cswap = [](bool c, float& a, float& b2) { const float t = a; a = c ? b2 : a; b2 = c ? t : b2; };
+#pragma unroll
+            for (int r = k + 1; r < N; ++r) {
+                const bool is_big = r == big;
+#pragma unroll
+                for (int j = 0; j < k; ++j) cswap(is_big, L[k][j], L[r][j]);              // row k <-> row big, columns before k
+                cswap(is_big, L[k][k], L[r][r]);                                           // the two diagonal entries
+#pragma unroll
+                for (int i = k + 1; i < r; ++i) cswap(is_big, L[i][k], L[r][i]);          // column k below k <-> row big, between k and big
+            }
+#pragma unroll
+            for (int r = k + 2; r < N; ++r)
+#pragma unroll
+                for (int c = k + 1; c < r; ++c) cswap(c == big, L[r][k], L[r][c]);        // column k <-> column big, rows below big
         }
-        int rs = N - k - 1;
         if (k > 0) {
-            for (int j = 0; j < k; ++j) temp[j] = mat[j][j] * mat[k][j];
+            float temp[N];
+#pragma unroll
+            for (int j = 0; j < k; ++j) temp[j] = L[j][j] * L[k][j];
             float acc = 0.f;
-            for (int j = 0; j < k; ++j) acc += mat[k][j] * temp[j];
-            mat[k][k] -= acc;
-            for (int i = 0; i < rs; ++i) {
+#pragma unroll
+            for (int j = 0; j < k; ++j) acc += L[k][j] * temp[j];
+            L[k][k] -= acc;
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) {
                 float a2 = 0.f;
-                for (int j = 0; j < k; ++j) a2 += mat[k + 1 + i][j] * temp[j];
-                mat[k + 1 + i][k] -= a2;
+#pragma unroll
+                for (int j = 0; j < k; ++j) a2 += L[i][j] * temp[j];
+                L[i][k] -= a2;
             }
         }
-        float akk = mat[k][k];
-        bool valid = fabsf(akk) > 0.f;
-        if (k == 0 && !valid) { for (int j = 0; j < N; ++j) transp[j] = j; break; }
-        if (rs > 0 && valid) for (int i = 0; i < rs; ++i) mat[k + 1 + i][k] /= akk;
+        const float akk = L[k][k];
+        const bool valid = fabsf(akk) > 0.f;
+        if (k == 0 && !valid) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) transp[j] = j;
+            stop = true;
+        } else if (valid) {
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) L[i][k] /= akk;
+        }
     }
+    float y[N];
+#pragma unroll
     for (int i = 0; i < N; ++i) y[i] = b[i];
-    for (int k = 0; k < N; ++k) if (transp[k] != k) { float t = y[k]; y[k] = y[transp[k]]; y[transp[k]] = t; }
-    for (int i = 0; i < N; ++i) { float a = y[i]; for (int j = 0; j < i; ++j) a -= mat[i][j] * y[j]; y[i] = a; }
-    for (int i = 0; i < N; ++i) { if (fabsf(mat[i][i]) > FLT_MIN) y[i] /= mat[i][i]; else y[i] = 0.f; }
-    for (int i = N - 1; i >= 0; --i) { float a = y[i]; for (int j = i + 1; j < N; ++j) a -= mat[j][i] * y[j]; y[i] = a; }
-    for (int k = N - 1; k >= 0; --k) if (transp[k] != k) { float t = y[k]; y[k] = y[transp[k]]; y[transp[k]] = t; }
+    // y = P b: interchanges k <-> transp[k] in ascending k (run-time partner: predicated over the static candidates)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int t = transp[k];
+        if (t != k) {
+            const float yk = y[k];
+            float yt = yk;
+#pragma unroll
+            for (int q = 0; q < N; ++q) if (q == t) yt = y[q];
+            y[k] = yt;
+#pragma unroll
+            for (int q = 0; q < N; ++q) if (q == t) y[q] = yk;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { float a = y[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) a -= L[i][j] * y[j];
+        y[i] = a; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) { if (fabsf(L[i][i]) > FLT_MIN) y[i] /= L[i][i]; else y[i] = 0.f; }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) { float a = y[i];
+#pragma unroll
+        for (int j = i + 1; j < N; ++j) a -= L[j][i] * y[j];
+        y[i] = a; }
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        const int t = transp[k];
+        if (t != k) {
+            const float yk = y[k];
+            float yt = yk;
+#pragma unroll
+            for (int q = 0; q < N; ++q) if (q == t) yt = y[q];
+            y[k] = yt;
+#pragma unroll
+            for (int q = 0; q < N; ++q) if (q == t) y[q] = yk;
+        }
+    }
+#pragma unroll
     for (int i = 0; i < N; ++i) x[i] = y[i];
 }
-__device__ inline void ldlt6_solve(const float* Ain, const float* b, float* x) {   // private scratch: for callers without LDS to spare
-    float ws[54];
-    ldlt6_solve(Ain, b, x, ws);
+__device__ __forceinline__ void ldlt6_solve(const float* Ain, const float* b, float* x, float* /* LDS scratch of an earlier version: unused */) {
+    ldlt6_solve(Ain, b, x);
 }
 
 // Rx(a) * Ry(b) * Rz(g) through quaternions.
