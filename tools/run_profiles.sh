@@ -23,6 +23,11 @@ python3 $R/tools/bench_batch.py --instances 256 > $O/bench_batch_c4_256.jsonl 2>
 python3 $R/tools/bench_batch.py --instances 256 --order first >> $O/bench_batch_c4_256.jsonl 2>> $O/bench_batch_c4_256.err
 python3 $R/tools/bench_batch.py --instances 256 --voxel-px 2.0 >> $O/bench_batch_c4_256.jsonl 2>> $O/bench_batch_c4_256.err
 TDV_BATCH_LANES=1 python3 $R/tools/bench_batch.py --instances 64 >> $O/bench_batch_c4_256.jsonl 2>> $O/bench_batch_c4_256.err
+# C5, one rank's share (1,024 instances from one label image): the line, its kernel trace, and the unbatched shapes for comparison
+python3 $R/tools/c5_tray.py --reps 3 > $O/bench_c5_1gpu.jsonl 2> $O/bench_c5_1gpu.err
+TDV_RANSAC_BATCH=0 python3 $R/tools/c5_tray.py --reps 2 >> $O/bench_c5_1gpu.jsonl 2>> $O/bench_c5_1gpu.err
+TDV_BATCH_STAGED=0 python3 $R/tools/c5_tray.py --reps 2 >> $O/bench_c5_1gpu.jsonl 2>> $O/bench_c5_1gpu.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5 -- python3 $R/tools/c5_tray.py --reps 1 > /dev/null 2> $O/kt_c5.err
 # keep the merge small: per-dispatch traces are dropped, the stats and counter tables stay
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
 du -sh $O; cat $O/bench.json | head -c 600
