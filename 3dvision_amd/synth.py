@@ -301,7 +301,7 @@ def render_tray(points, poses, fx, fy, cx, cy, width, height, scale_to_meters):
 
 
 def tray_scene(n_instances, width=1280, height=720, f=1500.0, distance=0.45, part_px=25, cell_w=31, cell_h=28, voxel_px=1.2,
-               tilt_deg=12.0, jitter_px=1.0, scale_to_meters=50000.0, seed=3, feature_voxels=3.5):
+               tilt_deg=12.0, jitter_px=1.0, scale_to_meters=50000.0, seed=3, feature_voxels=3.5, pose_seed=None):
     """The C5 workload: dict(depth u16 [H,W], label u16 [H,W], T_gt list (scene -> model), model_depth, model_mask, voxel,
     intrinsics).  Defaults: 1,025 cells of 31 x 28 px in a 1280 x 720 frame, parts of 25 px diameter (~490 px)."""
     cx, cy = width / 2.0, height / 2.0
@@ -312,7 +312,8 @@ def tray_scene(n_instances, width=1280, height=720, f=1500.0, distance=0.45, par
     M = scan_pose(distance)
     model_depth, model_mask = render_depth(dense, M, f, f, cx, cy, width, height, scale_to_meters)
     cells = tray_cells(n_instances, width, height, cell_w, cell_h)
-    poses = [tray_instance_pose(b, cells[b], f, f, cx, cy, distance, tilt_deg, jitter_px, seed) for b in range(n_instances)]
+    # (pose_seed: other poses of the SAME part - the ranks of a sharded job each see their own tray of one part)
+    poses = [tray_instance_pose(b, cells[b], f, f, cx, cy, distance, tilt_deg, jitter_px, seed if pose_seed is None else pose_seed) for b in range(n_instances)]
     depth, label = render_tray(dense, poses, f, f, cx, cy, width, height, scale_to_meters)
     return dict(depth=depth, label=label, T_gt=[M @ np.linalg.inv(S) for S in poses], model_depth=model_depth, model_mask=model_mask,
                 voxel=float(np.float32(voxel)), fx=f, fy=f, cx=cx, cy=cy, width=width, height=height, scale=scale_to_meters,

@@ -27,11 +27,11 @@ TRAY = dict(feature_voxels=3.0)      # part geometry of the C5 tray (see synth.t
 MAX_ANGLE = 3e-2                     # rad: a 25-pixel part at 0.45 m; 3e-2 rad moves its rim by 0.3 pixel footprints
 
 
-def build(tdv, synth, ctx, n_instances, dev, seed=7, order=None, hyps=10000, icp_iters=50):
+def build(tdv, synth, ctx, n_instances, dev, seed=7, order=None, hyps=10000, icp_iters=50, pose_seed=None):
     """The tray on the device: dict(sc = the numpy scene, depth / label device tensors, model = (xyz, normals, fpfh, n), params)."""
     import torch
     order = tdv.TDV_VOXEL_ORDER_REFERENCE if order is None else order
-    sc = synth.tray_scene(n_instances, seed=seed, **TRAY)
+    sc = synth.tray_scene(n_instances, seed=seed, pose_seed=pose_seed, **TRAY)
     W, H = sc["width"], sc["height"]
     d_depth = torch.from_numpy(sc["depth"].view(np.int16)).to(dev)
     d_label = torch.from_numpy(sc["label"].view(np.int16)).to(dev)
