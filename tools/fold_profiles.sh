@@ -13,7 +13,4 @@ cp $(nf kt_bench kernel_stats.csv) $P/kernel_stats_bench.csv
 cp $(nf kt_ops kernel_stats.csv) $P/kernel_stats_ops.csv
 [ -d $O/kt_c5 ] && cp $(nf kt_c5 kernel_stats.csv) $P/kernel_stats_c5.csv
 [ -f $O/bench_c5_1gpu.jsonl ] && cp $O/bench_c5_1gpu.jsonl $P/
-N1="rocprofv3 --pmc passes, one counter group per pass, no tracing combined; means over every dispatch of the command. Command: python3 bench.py --no-cpu-baseline --no-operators (100 steps + 5 warm-up at 200k x 200k)."
-N2="rocprofv3 --pmc passes, one counter group per pass, no tracing combined; means over every dispatch of the command. Command: python3 tools/bench_ops.py (every operator of tools/opbench.py, median-of-3 loops: each kernel is dispatched several times)."
-python tools/summarize_pmc.py --out $P/pmc_summary.json --n 200000 --note "$N1" $(nf pmc_fetch_bench counter_collection.csv) $(nf pmc_write_bench counter_collection.csv)
-python tools/summarize_pmc.py --out $P/pmc_ops_summary.json --n 200000 --note "$N2" $(nf pmc_fetch_ops counter_collection.csv) $(nf pmc_write_ops counter_collection.csv) $(nf pmc_sq_ops counter_collection.csv)
+cp $O/pmc_summary.json $O/pmc_ops_summary.json $P/

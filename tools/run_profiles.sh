@@ -28,6 +28,12 @@ python3 $R/tools/c5_tray.py --reps 3 > $O/bench_c5_1gpu.jsonl 2> $O/bench_c5_1gp
 TDV_RANSAC_BATCH=0 python3 $R/tools/c5_tray.py --reps 2 >> $O/bench_c5_1gpu.jsonl 2>> $O/bench_c5_1gpu.err
 TDV_BATCH_STAGED=0 python3 $R/tools/c5_tray.py --reps 2 >> $O/bench_c5_1gpu.jsonl 2>> $O/bench_c5_1gpu.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5 -- python3 $R/tools/c5_tray.py --reps 1 > /dev/null 2> $O/kt_c5.err
-# keep the merge small: per-dispatch traces are dropped, the stats and counter tables stay
-find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
+# fold the PMC passes here (the per-dispatch counter tables are hundreds of MB with the 256- and 1,024-instance batches in the run;
+# gpurun copies back at most 64 MiB), then keep only statistics and summaries
+nf() { ls -t $O/$1/*/*$2 2>/dev/null | head -1; }
+N1="rocprofv3 --pmc passes, one counter group per pass, no tracing combined; means over every dispatch of the command. Command: python3 bench.py --no-cpu-baseline --no-operators (100 steps + 5 warm-up at 200k x 200k)."
+N2="rocprofv3 --pmc passes, one counter group per pass, no tracing combined; means over every dispatch of the command. Command: python3 tools/bench_ops.py (every operator of tools/opbench.py: each kernel is dispatched several times)."
+python3 $R/tools/summarize_pmc.py --out $O/pmc_summary.json --n 200000 --note "$N1" $(nf pmc_fetch_bench counter_collection.csv) $(nf pmc_write_bench counter_collection.csv) || echo "pmc fold (bench) failed" >> $O/notes.txt
+python3 $R/tools/summarize_pmc.py --out $O/pmc_ops_summary.json --n 200000 --note "$N2" $(nf pmc_fetch_ops counter_collection.csv) $(nf pmc_write_ops counter_collection.csv) $(nf pmc_sq_ops counter_collection.csv) || echo "pmc fold (ops) failed" >> $O/notes.txt
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete; find $O -name "*counter_collection.csv" -delete
 du -sh $O; cat $O/bench.json | head -c 600
