@@ -93,7 +93,7 @@ void k_valid_count(const uint16_t* __restrict__ raw, const float* __restrict__ d
 
 // exclusive scan of nblocks counts by ONE workgroup of 1024 threads; total -> offsets[nblocks]
 __global__ __launch_bounds__(1024)
-void k_block_scan(const int* __restrict__ counts, int nblocks, int* __restrict__ offsets) {
+void k_block_scan(const int* __restrict__ counts, int nblocks, int* __restrict__ offsets, int* __restrict__ host_total = nullptr) {
     __shared__ int wsum[16];
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
@@ -115,7 +115,10 @@ void k_block_scan(const int* __restrict__ counts, int nblocks, int* __restrict__
         if (threadIdx.x == 1023) carry_s = carry + wbase + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) offsets[nblocks] = carry_s;
+    if (threadIdx.x == 0) {
+        offsets[nblocks] = carry_s;
+        if (host_total) { *host_total = carry_s; __threadfence_system(); }   // straight into pinned host memory: a 4-byte D2H copy is a 9-us blit kernel
+    }
 }
 
 template <bool RAW>
@@ -875,7 +878,9 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
         ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
         if (d_raw) k_valid_count<true><<<blocks, DP_BLOCK, 0, s>>>(d_raw, nullptr, d_mask, n, inv_scale, mask_mode, zmax, counts);
         else k_valid_count<false><<<blocks, DP_BLOCK, 0, s>>>(nullptr, d_depth, nullptr, n, 0.f, 0, zmax, counts);
-        k_block_scan<<<1, 1024, 0, s>>>(counts, blocks, offsets);
+        int* h_total0 = reinterpret_cast<int*>(ctx->pin);
+        *h_total0 = -1;
+        k_block_scan<<<1, 1024, 0, s>>>(counts, blocks, offsets, h_total0);
         if (d_xyz && capacity > 0) {
             if (d_raw) k_emit<true><<<blocks, DP_BLOCK, 0, s>>>(d_raw, nullptr, d_mask, d_bgr, w, n, inv_scale, mask_mode, fx, fy, cx, cy, zmax, offsets, capacity, d_xyz, d_rgb);
             else k_emit<false><<<blocks, DP_BLOCK, 0, s>>>(nullptr, d_depth, nullptr, d_bgr, w, n, 0.f, 0, fx, fy, cx, cy, zmax, offsets, capacity, d_xyz, d_rgb);
@@ -883,8 +888,8 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
     }
     TDV_CHECK_LAUNCH(ctx);
     int* h_total = reinterpret_cast<int*>(ctx->pin);
-    TDV_HIP(ctx, hipMemcpyAsync(h_total, offsets + blocks, 4, hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
+    if (*h_total < 0) { snprintf(ctx->err, sizeof(ctx->err), "depth_to_cloud: the count did not reach the host"); return TDV_ERR_INTERNAL; }
     *n_out = *h_total;
     if (*h_total > capacity) return TDV_ERR_BAD_ARG;  // caller's buffers too small; *n_out = needed
     return TDV_OK;

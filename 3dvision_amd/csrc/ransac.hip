@@ -366,13 +366,21 @@ __global__ void k_ransac_plan(int* __restrict__ state, int* __restrict__ plan, i
         c_split = min(n_pchunks, (ns - rest + RS_PCH - 1) / RS_PCH);
     plan[0] = c_split; plan[1] = 0; plan[2] = 0; plan[3] = (c_split + ps - 1) / ps;
 }
-// largest count of a batch (prefix counts after phase 1, full counts after phase 2) -> *dst by atomic max
-__global__ void k_ransac_best(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int* __restrict__ dst) {
+// largest count of a batch (prefix counts after phase 1, full counts after phase 2) -> *dst by atomic max, one atomic per
+// workgroup (one per wave on the same address cost 12 us for a 65,536-hypothesis batch)
+__global__ __launch_bounds__(1024)
+void k_ransac_best(const int4* __restrict__ triples, int count, const int* __restrict__ counts, int* __restrict__ dst) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     int c = (h < count && triples[h].w != 0) ? counts[h] : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, 64));
-    if ((threadIdx.x & 63) == 0 && c > 0) atomicMax(dst, c);
+    __shared__ int s_max[16];
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) c = max(c, s_max[w]);
+        if (c > 0) atomicMax(dst, c);
+    }
 }
 // Which hypotheses of a batch go on to phase 2.  With rest = the points phase 1 left out, ub = count + rest bounds a
 // hypothesis' full count from above.  It is dropped when it provably is neither the result nor the iteration the loop of
@@ -747,7 +755,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
             if (a) k_ransac_score_fast<<<g1 + g2, RS_BLOCK, 0, s>>>(*a, jb, g1, h_pad, pq2, n_pchunks, tau, d_rescored);
             else k_ransac_score_fast<<<g2, RS_BLOCK, 0, s>>>(jb, jb, 0, h_pad, pq2, n_pchunks, tau, d_rescored);
         }
-        k_ransac_best<<<(pending_cnt + 255) / 256, 256, 0, s>>>(d_tri[p], pending_cnt, counts[p], d_state);
+        k_ransac_best<<<(pending_cnt + 1023) / 1024, 1024, 0, s>>>(d_tri[p], pending_cnt, counts[p], d_state);
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipMemcpyAsync(h_cnt[p], counts[p], (size_t)pending_cnt * 4, hipMemcpyDeviceToHost, s));
         TDV_HIP(ctx, hipEventRecord(ev[p], s));
@@ -785,9 +793,12 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                     }
                     // survivors of this batch: the in-batch bound first (largest prefix count), then the list; the prefix counts
                     // also raise the best known for the batches after this one
-                    k_ransac_best<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], d_plan[q] + 2);
+                    const bool merge_on = getenv("TDV_RANSAC_MERGE") && atoi(getenv("TDV_RANSAC_MERGE")) == 1;     // (read per call: the tests switch it)
+                    k_ransac_best<<<(cnt + 1023) / 1024, 1024, 0, s>>>(d_tri[q], cnt, counts[q], d_plan[q] + 2);
                     k_ransac_select<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], ns, confidence, d_state, d_plan[q], d_list[q]);
-                    k_ransac_best<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], d_state);
+                    // (merged mode only: phase 2 comes a dispatch later, the prefix counts raise the bound for the batch in between;
+                    //  otherwise the full counts do that right after phase 2)
+                    if (merge_on) k_ransac_best<<<(cnt + 1023) / 1024, 1024, 0, s>>>(d_tri[q], cnt, counts[q], d_state);
                     pending = q; pending_cnt = cnt;
                     wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
                     TDV_CHECK_LAUNCH(ctx);
@@ -797,7 +808,6 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                     // dispatch later, the host prepares the next index batch with nothing queued behind it, and the call loses 11 %
                     // end to end (19.0 vs 21.7 M hypotheses/s; profiles/r3/history/ransac_merged_dispatch.md).  Two batches in flight
                     // (three buffer sets) would hide that for one point of utilisation - not built.
-                    const bool merge_on = getenv("TDV_RANSAC_MERGE") && atoi(getenv("TDV_RANSAC_MERGE")) == 1;     // (read per call: the tests switch it)
                     if (!merge_on) return finish_pending(nullptr, 0);
                     return TDV_OK;                           // counts and event follow with this batch's phase 2 (finish_pending)
                 } else {
