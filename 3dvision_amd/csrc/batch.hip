@@ -94,11 +94,11 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
             have_sorted = true;
         }
     }
-    static const bool coherent_stages = !(getenv("TDV_BATCH_COHERENT") && atoi(getenv("TDV_BATCH_COHERENT")) == 0);   // A/B knob
+    const bool coherent_stages = !(getenv("TDV_BATCH_COHERENT") && atoi(getenv("TDV_BATCH_COHERENT")) == 0);   // A/B knob (read per call: the tests switch it)
     // voxels of ALL instances in first-occurrence order with one memset + two launches (voxel.hip, hash-table path); a lane then
     // only finishes its instance's reference order.  A voxel too full for the table's member rows (a very coarse grid) sends the
     // whole batch back to per-instance calls.
-    static const bool batched_voxel_env = !(getenv("TDV_BATCH_VOXEL") && atoi(getenv("TDV_BATCH_VOXEL")) == 0);          // A/B knob
+    const bool batched_voxel_env = !(getenv("TDV_BATCH_VOXEL") && atoi(getenv("TDV_BATCH_VOXEL")) == 0);          // A/B knob (read per call: the tests switch it)
     const bool want_ref = prm->voxel_order == TDV_VOXEL_ORDER_REFERENCE;
     std::vector<int> voff((size_t)n_instances + 1, 0);
     float* vox_first_all = nullptr; int* vox_rank_all = nullptr; int4* vox_leaders_all = nullptr;
@@ -121,7 +121,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         ws_rewind(ctx, vmark);
         batched_voxel = !overflowed;
         // ... and their reference order, on the device too (the host replay stays as the fall-back of a cloud whose hash degenerates)
-        static const bool device_order_env = !(getenv("TDV_VOXEL_DEVICE_ORDER") && atoi(getenv("TDV_VOXEL_DEVICE_ORDER")) == 0);   // A/B knob
+        const bool device_order_env = !(getenv("TDV_VOXEL_DEVICE_ORDER") && atoi(getenv("TDV_VOXEL_DEVICE_ORDER")) == 0);   // A/B knob (read per call: the tests switch it)
         if (batched_voxel && want_ref && device_order_env && voff[n_instances] > 0) {
             const size_t tv = (size_t)voff[n_instances];
             TDV_TRY(ws_alloc(ctx, tv * 3, &vox_ref_all));
@@ -275,7 +275,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // kernels): 4,716 -> 6,554 instances/s at 12 lanes.  For C4's 147k-voxel instances it LOSES (497 -> 469 instances/s at 4 lanes,
     // 429 at 12): there the lanes overlap kernels of different kinds, which the common stages take away - hence the size rule
     // (TDV_BATCH_STAGED=0 / 1 forces either shape).
-    static const int staged_env = getenv("TDV_BATCH_STAGED") ? atoi(getenv("TDV_BATCH_STAGED")) : -1;   // A/B knob
+    const int staged_env = getenv("TDV_BATCH_STAGED") ? atoi(getenv("TDV_BATCH_STAGED")) : -1;   // A/B knob (read per call: the tests switch it)
     bool staged = (staged_env < 0 ? small_instances : staged_env != 0) && batched_voxel && voff[n_instances] > 0;
     if (staged && want_ref) { if (!vox_ref_all) staged = false; else for (int b = 0; b < n_instances; ++b) if (ref_failed[b] && off[b + 1] > off[b]) staged = false; }
     if (!staged) return for_all_instances(run_instance);
@@ -309,7 +309,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     };
     // small instances with at least k points each: normals + FPFH of ALL of them in one set of launches (knn.hip), not ~16
     // launches per instance
-    static const bool batched_features_env = !(getenv("TDV_BATCH_FEATURES") && atoi(getenv("TDV_BATCH_FEATURES")) == 0);   // A/B knob
+    const bool batched_features_env = !(getenv("TDV_BATCH_FEATURES") && atoi(getenv("TDV_BATCH_FEATURES")) == 0);   // A/B knob (read per call: the tests switch it)
     bool batched_features = batched_features_env && small_instances && d_voff && prm->normals_k <= 100;
     int *tie = nullptr, *tie_inv = nullptr;     // coherent stages: global first -> reference position and back
     for (int b = 0; b < n_instances && batched_features; ++b) { const int v = voff[b + 1] - voff[b]; if (v > 0 && v < prm->normals_k) batched_features = false; }
@@ -343,7 +343,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // RANSAC pass - same kernel as the per-instance call, same bits
     int v_max = 0;
     for (int b = 0; b < n_instances; ++b) v_max = std::max(v_max, voff[b + 1] - voff[b]);
-    static const bool icp_small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;
+    const bool icp_small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;   // (read per call: the tests switch it)
     const bool batched_icp = !icp_small_off && d_voff && v_max <= icp_small_max_points() && n_model <= icp_small_max_points() && n_model > 0 &&
                              (ctx->icp_search == TDV_ICP_SEARCH_AUTO || ctx->icp_search == TDV_ICP_SEARCH_BRUTE);
     std::vector<float> coarse_T(batched_icp ? (size_t)n_instances * 16 : 0, 0.f);

@@ -841,7 +841,7 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     std::memcpy(h->T, T0, 64); std::memcpy(h->res_T, T0, 64);
     hipStream_t s = ctx->stream;
     // small problems: the whole loop in one launch (k_icp_small), same bits as the launches below
-    static const bool small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;   // A/B knob
+    const bool small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;   // A/B knob (read per call: the tests switch it)
     if (!small_off && !pruned && !cg.usable && ns <= SM_MAX_N && nt <= SM_MAX_N) {
         IcpState* d_st;
         TDV_TRY(ws_alloc(ctx, 2, &d_st));

@@ -1070,7 +1070,7 @@ int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, c
     const int total = n_clouds ? h_off[n_clouds] : 0;
     if (total == 0 || nt == 0 || max_iterations == 0) return TDV_OK;
     if (!d_src || !d_tgt || !d_corr) return TDV_ERR_BAD_ARG;
-    static const bool off_env = getenv("TDV_RANSAC_BATCH") && atoi(getenv("TDV_RANSAC_BATCH")) == 0;   // A/B knob
+    const bool off_env = getenv("TDV_RANSAC_BATCH") && atoi(getenv("TDV_RANSAC_BATCH")) == 0;   // A/B knob (read per call: the tests switch it)
     const bool fast_mode = ctx->ransac_score_mode == TDV_RANSAC_SCORE_FAST && !(getenv("TDV_RANSAC_SCORE") && strcmp(getenv("TDV_RANSAC_SCORE"), "fast"));
     int v_max = 0;
     for (int b = 0; b < n_clouds; ++b) v_max = std::max(v_max, h_off[b + 1] - h_off[b]);

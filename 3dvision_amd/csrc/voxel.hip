@@ -741,7 +741,7 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     if (both && (order != TDV_VOXEL_ORDER_REFERENCE || !both->first_xyz || !both->ref2first || !both->first2ref)) return TDV_ERR_BAD_ARG;
     *n_out = 0;
     if (n == 0) return TDV_OK;
-    static const bool legacy = getenv("TDV_VOXEL_LEGACY") != nullptr || getenv("TDV_VOXEL_SORT") != nullptr;   // A/B knobs: the counting-sort path / the full sort
+    const bool legacy = getenv("TDV_VOXEL_LEGACY") != nullptr || getenv("TDV_VOXEL_SORT") != nullptr;   // A/B knobs: the counting-sort path / the full sort (read per call: the tests switch it)
     if (legacy) return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
     // hash-table path (memset + 2 kernels); first-occurrence order lands in the caller's buffer directly
     hipStream_t s = ctx->stream;
