@@ -160,10 +160,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = env_world > 1
+    # Rehearsal on a ONE-GPU box (TDV_BENCH_REHEARSE=1): the ranks share GPU 0 and rendezvous over gloo with host tensors - RCCL
+    # refuses two ranks on one device - so that every line of the N > 1 path below except RCCL itself runs before the driver's
+    # multi-GPU node sees it.  Never the default: a real run is one rank per GPU over RCCL / xGMI.
+    rehearse = os.environ.get("TDV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=torch.device("cuda", local_rank))
+        if rehearse: dist.init_process_group("gloo", rank=rank, world_size=env_world)
+        else: dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=torch.device("cuda", local_rank))
     world = dist.get_world_size() if distributed else 1      # the ranks RCCL actually joined: what n_gpus reports
     if args.gpus != world:
         raise SystemExit("--gpus %d but %d rank(s) joined the job" % (args.gpus, world))
@@ -173,6 +180,7 @@ def main():
     assert os.path.exists(tdv.LIB_PATH), "lib3dvision_hip.so missing — run __graft_entry__.build(); there is no CPU fallback"
     ctx = tdv.Context(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev      # where the (tiny) collectives' tensors live
 
     n = args.points
     voxel = float(np.float32(synth.mean_spacing(n)))
@@ -184,7 +192,7 @@ def main():
     if rank == 0:
         tgt_np, nrm_np = synth.sample_object(n, 42)
         pack = sharding.pack_model(tgt_np, nrm_np, synth.random_features(n, 42))  # points | normals | FPFH = 156 B per point
-    model = sharding.broadcast_model(pack, n, dev)
+    model = sharding.broadcast_model(pack, n, cdev).to(dev)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t_b0) * 1e3
     d_tgt = model[:, :3].contiguous(); d_nrm = model[:, 3:6].contiguous()
@@ -227,7 +235,7 @@ def main():
     regions = 1
     if args.min_region_ms > 0 and region_est is not None:
         regions = max(1, int(np.ceil(args.min_region_ms * 1e-3 / max(region_est, 1e-6))))
-    rg = torch.tensor([regions], dtype=torch.int64, device=dev)
+    rg = torch.tensor([regions], dtype=torch.int64, device=cdev)
     if distributed:
         dist.all_reduce(rg, op=dist.ReduceOp.MAX)      # same count on every rank
     regions = int(rg.item())
@@ -257,14 +265,14 @@ def main():
     rescore_share = ctx.last_ransac_rescore()  # fast scoring pass: share of (wave, chunk) pairs scored a second time exactly; -1: exact mode
     scored_share = ctx.last_ransac_scored()    # share of the (hypothesis, point) tests evaluated at all (exact bail-out: DESIGN.md 4)
 
-    times = torch.tensor([elapsed, t_icp, t_rs], dtype=torch.float64, device=dev)
+    times = torch.tensor([elapsed, t_icp, t_rs], dtype=torch.float64, device=cdev)
     if distributed:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, t_icp, t_rs = [float(x) for x in times.cpu()]
     # per-rank view (rank 0 prints it at N > 1): own steps/s, the dominant kernel's average dispatch and executed-op fraction
     ops_mine = ((16.6 + 28.0 * rescore_share) if rescore_share >= 0.0 else 28.0) * scored_share * n * float(steps_timed) * HYPS_PER_STEP
     mine = torch.tensor([rank, steps_timed / t_local, sc_ms / max(sc_launches, 1), ops_mine / max(sc_ms * 1e-3, 1e-12) / 1e12 / VALU_PEAK_TOPS,
-                         bcast_ms], dtype=torch.float64, device=dev)
+                         bcast_ms], dtype=torch.float64, device=cdev)
     per_rank = [torch.zeros_like(mine) for _ in range(world)]
     if distributed:
         dist.all_gather(per_rank, mine)
@@ -415,7 +423,7 @@ def main():
             "config": {"workload": "headline: N_s=N_t=%d, point-to-plane ICP (fixed %d iterations per call, %s correspondence search) + RANSAC scoring (%d hyps per call), "
                                    "%d call(s) of each in the timed region, one instance pair per GPU"
                                    % (n, args.steps, {"grid": "exact hash-grid", "pruned": "exact pruned"}.get(icp_search_used, "brute-force"), args.steps * HYPS_PER_STEP, regions),
-                       "n_src": n, "n_tgt": n, "hyps_per_step": HYPS_PER_STEP, "parallelism": "instances sharded, %d rank(s)" % world,
+                       "n_src": n, "n_tgt": n, "hyps_per_step": HYPS_PER_STEP, "parallelism": "instances sharded, %d rank(s)%s" % (world, " - REHEARSAL: all ranks on GPU 0, gloo" if rehearse else ""),
                        "icp_start": "0.3 deg / 0.5 mm from the ground truth (inside the basin of the reference's 0.4-voxel threshold; SURVEY 8d's 3 deg / 5 mm start "
                                     "lies outside it and every iteration count is fixed, so the start only decides how many correspondences are accepted)",
                        "model_bcast_ms": bcast_ms if distributed else None},
