@@ -638,6 +638,14 @@ static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float*
     return TDV_OK;
 }
 
+// out[p] = in[idx[p]] for rows of three floats
+__global__ void k_gather_rows3(const float* __restrict__ in, const int* __restrict__ idx, int n, float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const size_t q = (size_t)idx[p];
+    out[3 * (size_t)p] = in[3 * q]; out[3 * (size_t)p + 1] = in[3 * q + 1]; out[3 * (size_t)p + 2] = in[3 * q + 2];
+}
+
 namespace {
 struct VoxelKey {
     int x, y, z;
@@ -774,6 +782,28 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     *n_out = v;
     if (v > capacity) return TDV_ERR_BAD_ARG;
     if (!ref) return TDV_OK;
+    // The container order: on the device (the batch's way, ~17 rehash periods of small launches) when there are enough voxels for
+    // the host replay's 22 ns per voxel + two copies to cost more - measured cross-over around 10k voxels (tools/studies/voxel_probe.py);
+    // TDV_VOXEL_DEVICE_ORDER=0 / 1 forces either.  Colours ride along through the permutation.
+    const int dev_env = getenv("TDV_VOXEL_DEVICE_ORDER") ? atoi(getenv("TDV_VOXEL_DEVICE_ORDER")) : -1;   // (read per call: the tests switch it)
+    if (TDV_HAVE_LIBSTDCXX_EMULATION && (dev_env < 0 ? v >= 10000 : dev_env != 0)) {
+        int *r2f, *f2r; int failed = 1;
+        if (both) { r2f = both->ref2first; f2r = both->first2ref; }
+        else { TDV_TRY(ws_alloc(ctx, (size_t)v, &r2f)); TDV_TRY(ws_alloc(ctx, (size_t)v, &f2r)); }
+        int* d_voff1;
+        TDV_TRY(ws_alloc(ctx, 2, &d_voff1));
+        const int h_voff1[2] = {0, v};
+        TDV_HIP(ctx, hipMemcpyAsync(d_voff1, h_voff1, 8, hipMemcpyHostToDevice, s));
+        TDV_TRY(voxel_reference_order_batch_dev(ctx, 1, h_voff1, d_voff1, d_leaders, tmp_xyz, d_out_xyz, r2f, f2r, &failed));
+        if (!failed) {
+            if (tmp_rgb && d_out_rgb) {
+                k_gather_rows3<<<(v + 255) / 256, 256, 0, s>>>(tmp_rgb, r2f, v, d_out_rgb);
+                TDV_CHECK_LAUNCH(ctx);
+                TDV_HIP(ctx, hipStreamSynchronize(s));
+            }
+            return TDV_OK;
+        }
+    }
     return voxel_reference_order(ctx, v, n, d_leaders, tmp_xyz, tmp_rgb, d_rank, 0, d_out_xyz, d_out_rgb, both);
 }
 

@@ -107,3 +107,25 @@ def test_member_counts_around_the_hash_path_row_size(ctx, orc, tdv, kmax):
     order = np.argsort(first, kind="stable")
     f_xyz, f_rgb = ctx.voxel_downsample(pts, rgb, float(voxel), tdv.TDV_VOXEL_ORDER_FIRST)
     assert f_xyz.tobytes() == ref_xyz[order].tobytes() and f_rgb.tobytes() == ref_rgb[order].tobytes()
+
+
+@pytest.mark.parametrize("n,voxel", [(200000, 0.0008), (120000, 0.003), (7, 0.001), (100000, 1e-5), (30000, 0.004), (60000, 0.0015)])
+def test_reference_order_on_the_device_at_size(ctx, orc, synth, tdv, n, voxel):
+    """The container order computed ON THE DEVICE (closed form per rehash period: what the batch uses for all its instances, and the
+    single-cloud call from 10k voxels) against the oracle's real std::unordered_map over all points and against the host replay:
+    up to 17 rehash periods, negative keys, heavy sharing, colours carried through the permutation."""
+    import os
+    pts, _ = synth.sample_object(n, 11)
+    pts = pts - np.float32(0.07)
+    rgb = np.random.default_rng(n).random((n, 3)).astype(np.float32)
+    ref_xyz, ref_rgb, _ = orc.voxel_downsample(pts, rgb, voxel)
+    try:
+        os.environ["TDV_VOXEL_DEVICE_ORDER"] = "1"
+        got_xyz, got_rgb = ctx.voxel_downsample(pts, rgb, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
+        os.environ["TDV_VOXEL_DEVICE_ORDER"] = "0"
+        host_xyz, host_rgb = ctx.voxel_downsample(pts, rgb, voxel, tdv.TDV_VOXEL_ORDER_REFERENCE)
+    finally:
+        os.environ.pop("TDV_VOXEL_DEVICE_ORDER", None)
+    assert len(got_xyz) == len(ref_xyz)
+    assert got_xyz.tobytes() == ref_xyz.tobytes() and got_rgb.tobytes() == ref_rgb.tobytes()
+    assert host_xyz.tobytes() == ref_xyz.tobytes() and host_rgb.tobytes() == ref_rgb.tobytes()
