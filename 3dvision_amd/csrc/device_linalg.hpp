@@ -290,7 +290,7 @@ TDV_DI bool smallest_eigvec3(float a00, float a10, float a20, float a11, float a
 }
 
 // Solve A x = b for symmetric 6x6 A (row-major, lower triangle read) by pivoted LDL^T (the sequence of operations of
-// Eigen::LDLT<Matrix<float,6,6>>::compute + solve, as oracle/small_linalg.hpp restates it).
+// Eigen::LDLT<Matrix<float,6,6>>::compute + solve; the CPU restatement used by the tests follows the same sequence).
 //
 // The only run-time index of the algorithm is the pivot `big` of step k.  With the lower triangle in 21 REGISTERS and the
 // symmetric interchange of k and big written as predicated moves over the (static) triangle positions, every other access has
