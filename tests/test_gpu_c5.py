@@ -36,6 +36,8 @@ def test_c5_1024_instances_from_one_label_image(ctx, tdv, synth, orc):
     omx, _, _ = orc.voxel_downsample(oxyz, None, V); omn = orc.estimate_normals(omx, 30); omf = orc.compute_fpfh(omx, omn, V * 5.0)
     assert mx.tobytes() == omx.tobytes() and mn.tobytes() == omn.tobytes() and mf.tobytes() == omf.tobytes()
     hyps, iters = wl["params"].ransac_max_iterations, wl["params"].icp_max_iterations
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "vectors_r3.npz"))   # the oracle's chain on instances 0 and 511, made in the build container
+    assert np.array_equal(per, golden["tray_per_instance"])
     for b in SAMPLE:
         mask = np.where(sc["label"] == b + 1, 255, 0).astype(np.uint8)
         # the oracle's processInstance
@@ -53,6 +55,8 @@ def test_c5_1024_instances_from_one_label_image(ctx, tdv, synth, orc):
         fp = ctx.compute_fpfh(src, nr, V * 5.0); assert fp.tobytes() == ofp.tobytes()
         co = ctx.ransac(src, mx, fs=fp, ft=mf, voxel=V, max_iterations=hyps, confidence=0.999)
         assert co.transformation.tobytes() == oco["T"].tobytes() and co.best_iteration == oco["best_iter"] and co.fitness == oco["fitness"]
+        if "tray_%d_coarse_T" % b in golden.files:            # ... and the committed vectors: the oracle on this box equals the build container's
+            assert oco["T"].tobytes() == golden["tray_%d_coarse_T" % b].tobytes() and ofi["T"].tobytes() == golden["tray_%d_fine_T" % b].tobytes()
         fi = ctx.icp(src, mx, mn, co.transformation, V * 0.4, iters, True)
         # north star: 1e-4 rad on rotation, 1e-3 mm on translation.  The translation is taken where the instance IS (the image of
         # its centroid under the two transforms): the origin of the frame is the camera, 0.45 m away, where the rotation
