@@ -345,6 +345,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     for (int b = 0; b < n_instances; ++b) v_max = std::max(v_max, voff[b + 1] - voff[b]);
     const bool icp_small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;   // (read per call: the tests switch it)
     const bool batched_icp = !icp_small_off && d_voff && v_max <= icp_small_max_points() && n_model <= icp_small_max_points() && n_model > 0 &&
+                             (long long)v_max * n_model <= icp_small_max_pairs_batch() &&
                              (ctx->icp_search == TDV_ICP_SEARCH_AUTO || ctx->icp_search == TDV_ICP_SEARCH_BRUTE);
     std::vector<float> coarse_T(batched_icp ? (size_t)n_instances * 16 : 0, 0.f);
     auto stage_register = [&](tdv_ctx* c, int b) -> int {

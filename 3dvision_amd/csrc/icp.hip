@@ -611,6 +611,8 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
 //    added as (w0 + w1) + (w2 + w3) into a slab, slabs folded in the same pattern - so a call gives the same bits whichever path
 //    its size selects.
 constexpr int SM_MAX_N = 2048;           // sources and targets the one-launch loop takes
+constexpr long long SM_MAX_PAIRS_SINGLE = 1ll << 18;    // ... in a single call (tools/studies/icp_small_probe.py)
+constexpr long long SM_MAX_PAIRS_BATCH = 1ll << 20;     // ... per problem of a batch
 // A grid of several workgroups runs one problem each (the batch's small instances against the shared model): problem b takes the
 // source points [src_off[b], src_off[b + 1]) of src0 and the states st_in[b] / st_out[b]; src_off == nullptr: one problem.
 // Two shapes: 1,024 lanes and room for 2,048 x 2,048 points, or 256 lanes and 1,024 x 1,024 - a quarter of the LDS and of the
@@ -626,7 +628,7 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
     const IcpState* __restrict__ st_in = st_in0 + prob;
     IcpState* __restrict__ st_out = st_out0 + prob;
     if (ns == 0) { if (threadIdx.x == 0) *st_out = *st_in; return; }   // (an instance without points: the caller ignores its state)
-    __shared__ float tx[SM_CAP], ty[SM_CAP], tz[SM_CAP];
+    __shared__ __attribute__((aligned(16))) float tx[SM_CAP], ty[SM_CAP], tz[SM_CAP];
     __shared__ float sbest[SM_CAP];
     __shared__ int sidx[SM_CAP];
     __shared__ double red[SM_THREADS / 64][ACC_NV];       // wave sums, four per virtual block
@@ -636,7 +638,11 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
     __shared__ float solve_ws[56];
     __shared__ IcpState st;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = threadIdx.x; j < nt; j += SM_THREADS) { tx[j] = tgt[3 * j]; ty[j] = tgt[3 * j + 1]; tz[j] = tgt[3 * j + 2]; }
+    const int nt4 = (nt + 3) / 4;                          // targets in chunks of four, the last one padded with +inf (never a minimum)
+    for (int j = threadIdx.x; j < nt4 * 4; j += SM_THREADS) {
+        const bool in = j < nt;
+        tx[j] = in ? tgt[3 * j] : INFINITY; ty[j] = in ? tgt[3 * j + 1] : INFINITY; tz[j] = in ? tgt[3 * j + 2] : INFINITY;
+    }
     if (threadIdx.x == 0) st = *st_in;
     __syncthreads();
     constexpr int NV = MODE == 0 ? 29 : 17;
@@ -652,12 +658,31 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
         for (int i = threadIdx.x; i < ns; i += SM_THREADS) {
             float px, py, pz;
             transform_point(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
-            float best = FLT_MAX; int bi = 0;
-#pragma unroll 4
-            for (int j = 0; j < nt; ++j) {
-                const float dx = px - tx[j], dy = py - ty[j], dz = pz - tz[j];
-                const float d2 = dx * dx + (dy * dy + dz * dz);
-                if (d2 < best) { best = d2; bi = j; }
+            // four targets per step (three 16-byte LDS reads at a wave-uniform address): the running minimum and the first CHUNK
+            // that reached it (strict <), then the lowest target of that chunk with that distance - the scan kernel's two-level argmin
+            float best = FLT_MAX; int bc = 0;
+            const float4* __restrict__ X4 = reinterpret_cast<const float4*>(tx);
+            const float4* __restrict__ Y4 = reinterpret_cast<const float4*>(ty);
+            const float4* __restrict__ Z4 = reinterpret_cast<const float4*>(tz);
+#pragma unroll 2
+            for (int c = 0; c < nt4; ++c) {
+                const float4 X = X4[c], Y = Y4[c], Z = Z4[c];
+                const float ax = px - X.x, ay = py - Y.x, az = pz - Z.x, bx = px - X.y, by = py - Y.y, bz = pz - Z.y;
+                const float cx = px - X.z, cy = py - Y.z, cz = pz - Z.z, ex = px - X.w, ey = py - Y.w, ez = pz - Z.w;
+                const float d0 = ax * ax + (ay * ay + az * az), d1 = bx * bx + (by * by + bz * bz);
+                const float d2 = cx * cx + (cy * cy + cz * cz), d3 = ex * ex + (ey * ey + ez * ez);
+                const float m = fminf(fminf(d0, d1), fminf(d2, d3));
+                if (m < best) { best = m; bc = c; }
+            }
+            int bi = 0;
+            if (best < FLT_MAX) {
+                bi = 4 * bc;
+#pragma unroll
+                for (int t = 3; t >= 0; --t) {
+                    const int j = 4 * bc + t;
+                    const float dx = px - tx[j], dy = py - ty[j], dz = pz - tz[j];
+                    if (dx * dx + (dy * dy + dz * dz) == best) bi = j;
+                }
             }
             sbest[i] = best; sidx[i] = best < FLT_MAX ? bi : 0;
         }
@@ -842,7 +867,10 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     hipStream_t s = ctx->stream;
     // small problems: the whole loop in one launch (k_icp_small), same bits as the launches below
     const bool small_off = getenv("TDV_ICP_SMALL") && atoi(getenv("TDV_ICP_SMALL")) == 0;   // A/B knob (read per call: the tests switch it)
-    if (!small_off && !pruned && !cg.usable && ns <= SM_MAX_N && nt <= SM_MAX_N) {
+    // (one workgroup walks all ns x nt pairs of an iteration: measured per iteration 22 us at 400 x 398 against 28 us for the two
+    //  launches, but 65 us at 1,000 x 1,000 and 237 us at 2,000 x 2,000 against 25-27: a single call only takes this path while the pair
+    //  count is small; a BATCH of such problems is another matter - there the grid is the parallelism, icp_small_batch_dev)
+    if (!small_off && !pruned && !cg.usable && ns <= SM_MAX_N && nt <= SM_MAX_N && (long long)ns * nt <= SM_MAX_PAIRS_SINGLE) {
         IcpState* d_st;
         TDV_TRY(ws_alloc(ctx, 2, &d_st));
         IcpState* h_res = h + 1;                          // the kernel stores its final state here itself (pinned memory: no copy kernel)
@@ -920,6 +948,7 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
 }
 
 int icp_small_max_points() { return SM_MAX_N; }
+long long icp_small_max_pairs_batch() { return SM_MAX_PAIRS_BATCH; }
 
 // icp_run_dev for n_prob small problems against one target in ONE launch: problem b = source points [d_src_off[b], d_src_off[b+1])
 // of d_src (each at most icp_small_max_points(), as nt), start pose T0s[b] (host, column-major).  Results as icp_run_dev's, bit for

@@ -128,6 +128,7 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
                 tdv_icp_result* out, const SortedCloud* tgt_sorted = nullptr, const CellGrid* tgt_grid = nullptr);
 // many small problems against one target in one launch (icp.hip: k_icp_small); sizes up to icp_small_max_points() each
 int icp_small_max_points();
+long long icp_small_max_pairs_batch();
 int icp_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* d_src_off, int n_prob, const float* d_tgt, const float* d_tgt_normals, int nt,
                         const float* T0s, float thr, int max_iterations, int point_to_plane, tdv_icp_result* out, int ns_max = 0 /* largest problem, if known */);
 int icp_correspondences_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, int nt,
