@@ -615,8 +615,8 @@ constexpr long long SM_MAX_PAIRS_SINGLE = 1ll << 18;    // ... in a single call 
 constexpr long long SM_MAX_PAIRS_BATCH = 1ll << 20;     // ... per problem of a batch
 // A grid of several workgroups runs one problem each (the batch's small instances against the shared model): problem b takes the
 // source points [src_off[b], src_off[b + 1]) of src0 and the states st_in[b] / st_out[b]; src_off == nullptr: one problem.
-// Two shapes: 1,024 lanes and room for 2,048 x 2,048 points, or 256 lanes and 1,024 x 1,024 - a quarter of the LDS and of the
-// wave slots, so that several times as many problems of a batch run at once (the loop is a chain of latencies, not throughput).
+// Two shapes: 1,024 lanes and room for 2,048 x 2,048 points (the default), or 256 lanes and 1,024 x 1,024 - a quarter of the LDS and
+// of the wave slots, so that more problems of a batch run at once (an A/B variant: measured slower, see icp_small_batch_dev).
 template <int MODE, int SM_THREADS, int SM_CAP>
 __global__ __launch_bounds__(SM_THREADS)
 void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict__ src_off, const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int nt,
@@ -969,7 +969,10 @@ int icp_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* d_src_off, 
     if (max_iterations > 0) {
         ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
         const bool p2pl = point_to_plane && d_tgt_normals;
-        const bool tiny = ns_max > 0 && ns_max <= 1024 && nt <= 1024;      // every problem fits the quarter-size shape (same results: the same reduction tree)
+        // The quarter-size shape (256 lanes: more problems resident at once) was measured against the full one on C5's 1,024 instances:
+        // 1.59 ms against 1.33 ms.  The pass lasts as long as its slowest problem (the few that run all 50 iterations), and a lone
+        // workgroup iterates faster with 16 waves.  Kept behind TDV_ICP_TINY=1 (same results: the same reduction tree).
+        const bool tiny = ns_max > 0 && ns_max <= 1024 && nt <= 1024 && getenv("TDV_ICP_TINY") && atoi(getenv("TDV_ICP_TINY")) == 1;
         if (tiny) {
             if (p2pl) k_icp_small<0, 256, 1024><<<n_prob, 256, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
             else k_icp_small<1, 256, 1024><<<n_prob, 256, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
