@@ -243,6 +243,10 @@ struct ScoreJob {
 };
 // One block of hypotheses (lane = hypothesis `base`, -1: none) over the chunks [c0, c1) of the point pairs; returns the lane's
 // inlier count, adds the chunks the wave scored twice to n_rescored (wave-uniform).
+// FINE: the band test and the exact re-scoring per PAIR of points instead of per chunk of eight.  On the headline's clouds a wave
+// re-scores 5 % of its chunks and the coarser test is cheaper; on the batch's small clouds - half of whose hypotheses are decent, so
+// that some of a wave's 512 tests per chunk nearly always sit at the threshold - it re-scored 49 % of the chunks (k_rb_score, C5).
+template <bool FINE = false>
 __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, const int h_pad, const int base, const float* __restrict__ pq2,
                                                 const int c0, const int c1, const float tau, unsigned& n_rescored) {
     v2f r[12];
@@ -269,12 +273,25 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
             // d2_fma - mid as one chain ending in -mid: its own rounding, at most 3 u mid = 1.5 u s in distance, sits inside
             // the 3.7 u A + 4 u s that the band's E keeps in reserve over the proven bound
             const v2f t = fma2(dx, dx, fma2(dy, dy, fma2(dz, dz, nmid)));
-            m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));                       // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
+            if (!FINE) m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));            // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
             sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.x), 31);      // sgn = sgn << 1 | sign(t.x)
             sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.y), 31);
+            if (FINE) {
+                const float m2 = fminf(fabsf(t.x), fabsf(t.y));
+                // (a NaN hypothesis: m2 is NaN, half is NaN: the pair is re-scored and counts nothing, as the exact arithmetic would)
+                if (__any(!(m2 >= half))) {     // some lane of the wave is inside its band (or has none): the reference arithmetic decides this pair
+                    ++n_rescored;
+                    const v2f x = (r[0] * px + (r[3] * py + r[6] * pz)) + r[9];
+                    const v2f y = (r[1] * px + (r[4] * py + r[7] * pz)) + r[10];
+                    const v2f z = (r[2] * px + (r[5] * py + r[8] * pz)) + r[11];
+                    const v2f ex = x - qx, ey = y - qy, ez = z - qz;
+                    const v2f d2 = ex * ex + (ey * ey + ez * ez);
+                    sgn = (sgn & ~3u) | ((d2.x < tau) ? 2u : 0u) | ((d2.y < tau) ? 1u : 0u);   // the two bits just shifted in
+                }
+            }
         }
         cf = __popc(sgn);
-        if (__any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
+        if (!FINE && __any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
             ++n_rescored;
             cf = 0;
 #pragma unroll
@@ -999,14 +1016,26 @@ __global__ void k_rb_hypotheses(const float* __restrict__ pq, const int* __restr
 
 __global__ __launch_bounds__(RS_BLOCK)
 void k_rb_score(const float* __restrict__ hyp, int h_pad, const float* __restrict__ pq2, const int* __restrict__ pos_off, const int* __restrict__ off, float tau,
-                int* __restrict__ counts /* [clouds][h_pad] */) {
-    const int b = blockIdx.y;
+                int* __restrict__ counts /* [clouds][h_pad] */, unsigned long long* __restrict__ rescored /* [0] chunks scored twice, [1] chunks scored (per wave) */) {
+    // consecutive workgroup ids = consecutive clouds of ONE hypothesis block: a cloud's 10 blocks land on the same XCD (id mod 8 =
+    // cloud mod 8), so its pair records are pulled into one L2 only, and stay there for the next block
+    const int b = blockIdx.x;
     if (off[b + 1] == off[b]) return;
-    const int base = blockIdx.x * RS_BLOCK + threadIdx.x;
+    const int base = blockIdx.y * RS_BLOCK + threadIdx.x;
     const int chunks = (pos_off[b + 1] - pos_off[b]) / RS_PCH;
     unsigned n_rescored = 0;
-    const int cnt = score_range_fast(hyp + (size_t)b * 14 * h_pad, h_pad, base, pq2 + (size_t)pos_off[b] * 6, 0, chunks, tau, n_rescored);
+    const int cnt = score_range_fast<true>(hyp + (size_t)b * 14 * h_pad, h_pad, base, pq2 + (size_t)pos_off[b] * 6, 0, chunks, tau, n_rescored);
     counts[(size_t)b * h_pad + base] = cnt;
+    // statistics only (tdv_ctx_last_ransac_rescore): two atomics per workgroup
+    __shared__ unsigned s_rescored;
+    if (threadIdx.x == 0) s_rescored = 0u;
+    __syncthreads();
+    if (n_rescored && (threadIdx.x & 63) == 0) atomicAdd(&s_rescored, n_rescored);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_rescored) atomicAdd(rescored, (unsigned long long)s_rescored);
+        atomicAdd(rescored + 1, (unsigned long long)(RS_BLOCK / 64) * (unsigned long long)chunks * (RS_PCH / 2));   // (pairs: the unit of the fine band test)
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -1093,8 +1122,9 @@ int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, c
     TDV_TRY(ws_alloc(ctx, (size_t)total_pos * 6, &pq2));
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds * 14 * h_pad, &hyp));
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds * h_pad, &counts));
-    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_pmax));                     // pmax[clouds] | bad | fail
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 8, &d_pmax));                     // pmax[clouds] | bad | fail | (pad) | rescored, scored (u64 each)
     d_flags = reinterpret_cast<int*>(d_pmax + n_clouds);
+    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(d_pmax + ((n_clouds + 2 + 1) & ~1) + 2);
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds, &d_res));
     const size_t pin_raw = align_up((size_t)n_raw * 4, 64), pin_res = align_up((size_t)n_clouds * sizeof(RbResult), 64);
     TDV_TRY(pin_reserve(ctx, pin_raw + pin_res + 64 + ((size_t)n_clouds + 1) * 4));
@@ -1106,21 +1136,25 @@ int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, c
     std::memcpy(h_pos, pos_off.data(), ((size_t)n_clouds + 1) * 4);
     TDV_HIP(ctx, hipMemcpyAsync(d_raw, h_raw, (size_t)n_raw * 4, hipMemcpyHostToDevice, s));
     TDV_HIP(ctx, hipMemcpyAsync(d_pos_off, h_pos, ((size_t)n_clouds + 1) * 4, hipMemcpyHostToDevice, s));
-    TDV_HIP(ctx, hipMemsetAsync(d_pmax, 0, ((size_t)n_clouds + 2) * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(d_pmax, 0, ((size_t)n_clouds + 8) * 4, s));
     k_rb_sample<<<n_clouds, 1024, 0, s>>>(d_raw, n_raw, d_off, H, d_idx, d_flags + 1);
     k_rb_gather_pq<<<(total_pos + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, d_off, d_pos_off, n_clouds, total_pos, nt, pq, d_flags, d_pmax);
     k_pack_pq2<<<(total_pos / 2 + 255) / 256, 256, 0, s>>>(pq, total_pos, pq2);
     k_rb_hypotheses<<<dim3((h_pad + 255) / 256, n_clouds), 256, 0, s>>>(pq, d_pos_off, d_off, d_idx, H, h_pad, hyp, d_pmax, sqrt_tau, 16.f * 5.9604644775390625e-08f);
     {
         ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
-        k_rb_score<<<dim3(hb, n_clouds), RS_BLOCK, 0, s>>>(hyp, h_pad, pq2, d_pos_off, d_off, tau, counts);
+        k_rb_score<<<dim3(n_clouds, hb), RS_BLOCK, 0, s>>>(hyp, h_pad, pq2, d_pos_off, d_off, tau, counts, d_stats);
     }
     k_rb_select<<<n_clouds, 256, 0, s>>>(d_idx, counts, hyp, d_off, H, h_pad, confidence, d_res);
     TDV_CHECK_LAUNCH(ctx);
     TDV_HIP(ctx, hipMemcpyAsync(h_res, d_res, (size_t)n_clouds * sizeof(RbResult), hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipMemcpyAsync(h_flags, d_flags, 8, hipMemcpyDeviceToHost, s));
+    TDV_HIP(ctx, hipMemcpyAsync(h_flags + 4, d_stats, 16, hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
-    ctx->last_ransac_rescore = -1.0; ctx->last_ransac_scored = 1.0;
+    {
+        const unsigned long long* st = reinterpret_cast<const unsigned long long*>(h_flags + 4);
+        ctx->last_ransac_rescore = st[1] ? (double)st[0] / (double)st[1] : 0.0; ctx->last_ransac_scored = 1.0;
+    }
     if (h_flags[0]) { std::snprintf(ctx->err, sizeof(ctx->err), "ransac: a correspondence index lies outside [0, %d)", nt); return TDV_ERR_BAD_ARG; }
     if (h_flags[1]) { *fell_back = 1; return TDV_OK; }
     for (int b = 0; b < n_clouds; ++b) {

@@ -77,6 +77,7 @@ def measure(tdv, synth, ctx, torch, dev, n_instances=1024, order=None, hyps=1000
                 scene_points=int(npnt.sum()), status_ok=int(sum(r["status"] == 0 for r in res)),
                 registered_share=float((ang <= MAX_ANGLE).mean()), max_angle_rad=MAX_ANGLE, median_angle_to_ground_truth_rad=float(np.median(ang)),
                 icp_iterations_per_instance=float(np.mean([r["icp_iterations"] for r in res])),
+                ransac_rescore_share=ctx.last_ransac_rescore(),
                 workspace_high_water_MiB=ctx.workspace_high_water() / 2 ** 20 if hasattr(ctx, "workspace_high_water") else None,
                 bound="chain of small per-instance launches (launch- and host-bound at ~500 points per instance)"), wl, res
 
