@@ -246,7 +246,10 @@ struct ScoreJob {
 // FINE: the band test and the exact re-scoring per PAIR of points instead of per chunk of eight.  On the headline's clouds a wave
 // re-scores 5 % of its chunks and the coarser test is cheaper; on the batch's small clouds - half of whose hypotheses are decent, so
 // that some of a wave's 512 tests per chunk nearly always sit at the threshold - it re-scored 49 % of the chunks (k_rb_score, C5).
-template <bool FINE = false>
+// ADAPT: a wave that had to re-score three of its first eight chunks stops trying the FMA pass and scores the rest of its range with
+// the reference arithmetic alone (28 ops per test instead of 16.6 + 28: cheaper from a re-scoring share of 0.4 on).  Measured on C5:
+// per-chunk band test 2.30 ms, per-pair band test 2.52 ms (the share stays at 49 % even for 128 tests), adaptive exact: see k_rb_score.
+template <bool FINE = false, bool ADAPT = false>
 __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, const int h_pad, const int base, const float* __restrict__ pq2,
                                                 const int c0, const int c1, const float tau, unsigned& n_rescored) {
     v2f r[12];
@@ -255,7 +258,9 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
     const float mid = base >= 0 ? hyp[(size_t)12 * h_pad + base] : tau, half = base >= 0 ? hyp[(size_t)13 * h_pad + base] : 0.f;   // a lane without a hypothesis has no band
     const v2f nmid = {-mid, -mid};
     int cnt = 0;
-    for (int c = c0; c < c1; ++c) {
+    int c_fast_end = c1;         // ADAPT: where the FMA pass gives up (wave-uniform)
+    for (int c = c0; c < c_fast_end; ++c) {
+        if (ADAPT && c == c0 + 8 && n_rescored >= 3u) { c_fast_end = c; break; }
         const float* __restrict__ g = pq2 + (size_t)c * (6 * RS_PCH);  // RS_PCH points = RS_PCH/2 records of 12 floats, wave-uniform
         float v[6 * RS_PCH];
 #pragma unroll
@@ -308,6 +313,26 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
             }
         }
         cnt += cf;
+    }
+    if (ADAPT) {
+        for (int c = c_fast_end; c < c1; ++c) {          // the reference arithmetic alone (k_ransac_score's loop)
+            const float* __restrict__ g = pq2 + (size_t)c * (6 * RS_PCH);
+            float v[6 * RS_PCH];
+#pragma unroll
+            for (int e = 0; e < 6 * RS_PCH; ++e) v[e] = g[e];
+#pragma unroll
+            for (int p = 0; p < RS_PCH / 2; ++p) {
+                const v2f px = {v[12 * p + 0], v[12 * p + 1]}, py = {v[12 * p + 2], v[12 * p + 3]}, pz = {v[12 * p + 4], v[12 * p + 5]};
+                const v2f qx = {v[12 * p + 6], v[12 * p + 7]}, qy = {v[12 * p + 8], v[12 * p + 9]}, qz = {v[12 * p + 10], v[12 * p + 11]};
+                const v2f x = (r[0] * px + (r[3] * py + r[6] * pz)) + r[9];
+                const v2f y = (r[1] * px + (r[4] * py + r[7] * pz)) + r[10];
+                const v2f z = (r[2] * px + (r[5] * py + r[8] * pz)) + r[11];
+                const v2f dx = x - qx, dy = y - qy, dz = z - qz;
+                const v2f d2 = dx * dx + (dy * dy + dz * dz);
+                cnt += (d2.x < tau) ? 1 : 0;
+                cnt += (d2.y < tau) ? 1 : 0;
+            }
+        }
     }
     return cnt;
 }
@@ -1024,7 +1049,7 @@ void k_rb_score(const float* __restrict__ hyp, int h_pad, const float* __restric
     const int base = blockIdx.y * RS_BLOCK + threadIdx.x;
     const int chunks = (pos_off[b + 1] - pos_off[b]) / RS_PCH;
     unsigned n_rescored = 0;
-    const int cnt = score_range_fast<true>(hyp + (size_t)b * 14 * h_pad, h_pad, base, pq2 + (size_t)pos_off[b] * 6, 0, chunks, tau, n_rescored);
+    const int cnt = score_range_fast<false, true>(hyp + (size_t)b * 14 * h_pad, h_pad, base, pq2 + (size_t)pos_off[b] * 6, 0, chunks, tau, n_rescored);
     counts[(size_t)b * h_pad + base] = cnt;
     // statistics only (tdv_ctx_last_ransac_rescore): two atomics per workgroup
     __shared__ unsigned s_rescored;
@@ -1034,7 +1059,7 @@ void k_rb_score(const float* __restrict__ hyp, int h_pad, const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_rescored) atomicAdd(rescored, (unsigned long long)s_rescored);
-        atomicAdd(rescored + 1, (unsigned long long)(RS_BLOCK / 64) * (unsigned long long)chunks * (RS_PCH / 2));   // (pairs: the unit of the fine band test)
+        atomicAdd(rescored + 1, (unsigned long long)(RS_BLOCK / 64) * (unsigned long long)chunks);
     }
 }
 
