@@ -692,6 +692,7 @@ __device__ __forceinline__ float box_bound(const float (&f)[FD], const float* __
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 // the descriptors of the K sources of every wave, interleaved: fsk[wave][d][k] = fs[sperm[K wave + k]][d] (a wave past the
 // end of an uneven count repeats the last source, as FmWave does): (q_k[d], q_k+1[d]) is then one aligned SGPR pair
@@ -1107,6 +1108,388 @@ void k_fm_query_overflow(FmTables t, const int* __restrict__ overflow_count, con
     }
 }
 
+// ---- leaf-major search (round 3; the default) --------------------------------------------------------------------------
+// k_fm_query spends 40 % of its instructions on box tests (lane = box, one or two sources per wave) and walks a source's
+// leaves one after the other, so a few sources that need hundreds of leaves decide when the call ends.  Here the roles are
+// swapped: LANE = SOURCE everywhere, boxes and target rows come through the scalar path, and the leaves are not walked
+// by the sources that need them but collected:
+//   k_lm_boxes<1>   a wave = 64 sources in home-leaf order.  Every lane evaluates the wave's distinct home leaves (1-3
+//                   of them: a first bound), then tests the leaf boxes of the wave's home group(s) - the 3-D principal
+//                   box first, the 33-D box where any lane passes it - and emits a (leaf, source) PAIR for every box a
+//                   source cannot exclude.  Pairs are buffered per wave in LDS (leaf, lane mask) and written with one
+//                   returning atomic per 96 boxes.
+//   k_lm_plan       one workgroup: scan of the per-leaf pair counts -> where each leaf's sources start, and the list of
+//                   work units (a leaf x up to 64 of its sources).
+//   k_lm_scatter    pairs to their leaf's stretch (one atomic per run of equal leaves inside a wave).
+//   k_lm_eval       one wave per unit: the leaf's 64 rows x 33 dimensions through the scalar path (16 rows of one dimension
+//                   per s_load_dwordx16), two rows per packed instruction: 3 x 33 x 32 v_pk_*_f32 per 64 sources x 64 rows,
+//                   the reference's operations in the reference's order (registration.cpp:222-224).  A lane that found a
+//                   smaller (distance, index) key lowers its source's key with a 64-bit atomic min.  Units of one leaf
+//                   run next to each other, so its 8.4 KB stay in the scalar cache.
+//   k_lm_boxes<2>   the same for every OTHER group, with the bounds round 1 left (group boxes first), then plan / scatter /
+//                   eval again, and k_lm_finish writes the correspondences.
+// A source that needs hundreds of leaves simply owns hundreds of pairs spread over as many units: there is no tail and no
+// overflow pass.  Exactness as before: every row that is not evaluated lies in a box whose bound (same expression, same
+// order, monotone float operations) exceeds a distance the source had already reached; bounds only shrink, so a pair
+// emitted early is at worst superfluous.  The result is the minimum over 64-bit (distance bits : original index) keys,
+// which does not depend on the order of the atomics.  Descriptors without structure (every box passes) overflow the pair
+// pool (32 per source): the call then falls back to k_fm_query and its scan class.
+constexpr int LM_BOX = 72;        // floats per scalar-layout box: min[33] | max[33] | pmin[3] | pmax[3]
+constexpr int LM_WAVES = 4;       // waves per workgroup
+constexpr int LM_ENTRIES = 96;    // (leaf, lane mask) entries a wave buffers before it reserves room for their pairs
+constexpr int LM_PAIRS_PER_SOURCE = 32;
+constexpr int LM_POOLS = 64;
+constexpr unsigned long long LM_KEY_NONE = (unsigned long long)0x7f7fffffu << 32;   // FLT_MAX : 0 - only dist < FLT_MAX is ever taken (registration.cpp:218-219)
+
+struct LmLists {
+    int *pool_count, *entry_cursor, *overflow;            // zeroed per round: [LM_POOLS][nleaf] (sources per pool and leaf) [LM_POOLS] [1]
+    int *leaf_count, *pool_start;                         // written by k_lm_plan: [nleaf] sources per leaf, [LM_POOLS][nleaf] where a pool's sources of a leaf go
+    int4* entries; int pool_cap;                          // (leaf, first source of the workgroup, lane mask): LM_POOLS pools of pool_cap entries, every pool
+                                                          // with its own cursor (one cursor for everything: 9,000 returning atomics on one address, 50 us)
+    int pair_cap;                                         // room in sorted_src
+    int *leaf_start, *unit_start;                         // [nleaf + 1]
+    int *unit_leaf;                                       // [pair_cap / 64 + nleaf + 2]
+    int *sorted_src;                                      // [pair_cap]
+    unsigned long long* keys;                             // [ns]
+};
+struct LmSrc { v2f p[(FD + 1) / 2]; float pq[PD]; };     // a lane's source: descriptor as 17 register pairs, principal coordinates
+// Index tables as the kernels below read them: the "constant" address space tells the compiler that nothing in the kernel
+// writes them, which is what lets it use the scalar path (s_load) although the same kernels store pairs and keys.
+typedef const __attribute__((address_space(4))) float* lm_cfloat_p;
+typedef const __attribute__((address_space(4))) int* lm_cint_p;
+typedef const __attribute__((address_space(4))) v16f* lm_cv16_p;
+
+__global__ void k_lm_box_layout(const float* __restrict__ lbox, const float* __restrict__ pbox, const float* __restrict__ gbox, const float* __restrict__ gpbox,
+                                int nleaf, int ngroup, float* __restrict__ sleaf, float* __restrict__ sgroup) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (nleaf + ngroup) * LM_BOX) return;
+    const int b = e / LM_BOX, f = e % LM_BOX;
+    if (b < nleaf) {
+        const int g = b / FX_GROUP, l = b % FX_GROUP;
+        sleaf[e] = f < 2 * FD ? lbox[(size_t)g * (2 * FD * FX_GROUP) + f * FX_GROUP + l] : pbox[(size_t)g * (2 * PD * FX_GROUP) + (f - 2 * FD) * FX_GROUP + l];
+    } else {
+        const int gi = b - nleaf, c = gi / 64, k = gi % 64;
+        sgroup[(size_t)gi * LM_BOX + f] = f < 2 * FD ? gbox[(size_t)c * (2 * FD * 64) + f * 64 + k] : gpbox[(size_t)c * (2 * PD * 64) + (f - 2 * FD) * 64 + k];
+    }
+}
+
+__device__ __forceinline__ void lm_load_source(const FmTables& t, int src, LmSrc& q) {
+    const float* __restrict__ f = t.fs + (size_t)src * FD;
+#pragma unroll
+    for (int d = 0; d < FD; ++d) { if (d & 1) q.p[d >> 1].y = f[d]; else q.p[d >> 1].x = f[d]; }
+    q.p[FD >> 1].y = 0.f;
+#pragma unroll
+    for (int r = 0; r < PD; ++r) q.pq[r] = t.sp[(size_t)src * 4 + r];
+}
+// The scalar path cannot feed this: a leaf is 8.4 KB, the scalar cache 16 KB per CU and its fill path slow (waves of one
+// CU on different leaves evict each other: 193 us for the home leaves alone).  Rows and boxes are therefore STAGED IN LDS -
+// coalesced vector loads in, broadcast reads (every lane the same address) out.
+typedef float v4f_lm __attribute__((ext_vector_type(4)));
+// the wave's own copy of a leaf: rows[d * 64 + r]
+__device__ __forceinline__ void lm_stage_leaf(const float* __restrict__ T, int leaf, float* rows, int lane) {
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(T + (size_t)leaf * (FD * FX_LEAF));
+    float4* dst = reinterpret_cast<float4*>(rows);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < (FD * FX_LEAF / 4 + 63) / 64; ++k) { const int e = k * 64 + lane; if (e < FD * FX_LEAF / 4) dst[e] = src[e]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// One staged leaf against every lane's source; key = the lane's best (distance bits : original index) so far.
+__device__ __forceinline__ void lm_eval_leaf(const float* rows, const int* __restrict__ torig, int leaf, const LmSrc& q, unsigned long long& key) {
+    const lm_cint_p ro = (lm_cint_p)(torig + (size_t)leaf * FX_LEAF);
+#pragma unroll 1
+    for (int r0 = 0; r0 < FX_LEAF; r0 += 16) {
+        v2f acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < FD; ++d) {
+            const v2f pr = q.p[d >> 1];
+            const v2f qq = (d & 1) ? __builtin_shufflevector(pr, pr, 1, 1) : __builtin_shufflevector(pr, pr, 0, 0);
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4) {
+                const v4f_lm r4 = *reinterpret_cast<const v4f_lm*>(rows + d * FX_LEAF + r0 + 4 * j4);   // 4 rows of dimension d: one broadcast ds_read_b128
+                const v2f d0 = qq - (v2f){r4[0], r4[1]}, d1 = qq - (v2f){r4[2], r4[3]};              // registration.cpp:222-224
+                acc[2 * j4] += d0 * d0; acc[2 * j4 + 1] += d1 * d1;
+            }
+        }
+        // the 16 distances against the lane's best: the keys are only built where some lane can improve (or tie)
+        float mn = fminf(acc[0].x, acc[0].y);
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mn = fminf(mn, fminf(acc[j].x, acc[j].y));
+        if (__any(mn <= __uint_as_float((unsigned)(key >> 32)))) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long k0 = ((unsigned long long)__float_as_uint(acc[j].x) << 32) | (unsigned)ro[r0 + 2 * j];
+                const unsigned long long k1 = ((unsigned long long)__float_as_uint(acc[j].y) << 32) | (unsigned)ro[r0 + 2 * j + 1];
+                key = k0 < key ? k0 : key;      // strict < on (distance, index): NaN and +inf have larger bit patterns than FLT_MAX
+                key = k1 < key ? k1 : key;
+            }
+        }
+    }
+}
+// box: 72 floats in LDS (min[33] | max[33] | pmin[3] | pmax[3]), the same for every lane
+__device__ __forceinline__ bool lm_pass3(const float* box, const LmSrc& q, float pmargin, float pscale, float bound) {   // principal_bound_note (FmWave::box_mask)
+    float lbp = 0.f;
+#pragma unroll
+    for (int r = 0; r < PD; ++r) {
+        const float g = fmaxf(fmaxf(box[2 * FD + r] - q.pq[r], q.pq[r] - box[2 * FD + PD + r]) - pmargin, 0.f);
+        lbp += g * g;
+    }
+    return !(lbp * pscale > bound);
+}
+__device__ __forceinline__ float lm_bound33(const float* box, const LmSrc& q) {
+    float lb = 0.f;
+#pragma unroll
+    for (int d = 0; d < FD; ++d) {
+        const float qd = (d & 1) ? q.p[d >> 1].y : q.p[d >> 1].x;
+        const float g = fmaxf(fmaxf(box[d] - qd, qd - box[FD + d]), 0.f);
+        lb += g * g;
+    }
+    return lb;
+}
+
+// Rounds 1 and 2: box tests.  A WORKGROUP = 64 sources in home-leaf order (lane = source in each of its LM_WAVES waves); the
+// boxes of a group are staged in LDS by the whole workgroup and its waves share the leaves between them (leaf i of the group
+// goes to wave i % LM_WAVES).  (First version: one wave per 64 sources, boxes through the scalar path - a chain of dependent
+// scalar loads with two waves per SIMD: 267 us for what is 20 us of instructions.)
+// ROUND 1: the leaves of the workgroup's home group(s); ROUND 2: every other group, group boxes first.  The four waves hold the
+// same sources, so every mask that steers the staging is the same in all of them: the barriers are reached together.
+template <int ROUND>
+__global__ __launch_bounds__(64 * LM_WAVES)
+void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __restrict__ sgroup, LmLists L, unsigned long long* __restrict__ stats) {
+    const unsigned long long t_begin = stats ? wall_clock64() : 0ull;
+    unsigned n3 = 0, n33 = 0, nemit = 0; unsigned long long t_flush = 0;
+    __shared__ __attribute__((aligned(16))) float s_box[FX_GROUP * LM_BOX];
+    __shared__ int s_leaf[LM_WAVES][LM_ENTRIES];
+    __shared__ unsigned long long s_mask[LM_WAVES][LM_ENTRIES];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int s0 = blockIdx.x * 64;
+    if (s0 >= t.ns) return;
+    const bool valid = s0 + lane < t.ns;
+    const int src = t.sperm[min(s0 + lane, t.ns - 1)];          // past the end: the last source again (tested, never emitted)
+    LmSrc q;
+    {   // the workgroup's 64 descriptors: rows in (four threads per 132-B row), through LDS, a lane's own row out
+        constexpr int PITCH = FD + 4;                            // 37 floats: a lane reading its row meets no bank twice
+        const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const float* __restrict__ row = t.fs + (size_t)t.sperm[min(s0 + r, t.ns - 1)] * FD;
+        for (int d = part; d < FD; d += 4) s_box[r * PITCH + d] = row[d];
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < FD; ++d) { if (d & 1) q.p[d >> 1].y = s_box[lane * PITCH + d]; else q.p[d >> 1].x = s_box[lane * PITCH + d]; }
+        q.p[FD >> 1].y = 0.f;
+        const float4 pc = *reinterpret_cast<const float4*>(t.sp + (size_t)src * 4);
+        q.pq[0] = pc.x; q.pq[1] = pc.y; q.pq[2] = pc.z;
+    }
+    const int home = min(t.nleaf - 1, max(0, t.home_of[src])), hg = home / FX_GROUP;
+    const float pmargin = 3e-5f * fmaxf(__uint_as_float(__builtin_amdgcn_readfirstlane(*t.amax_t)), __uint_as_float(__builtin_amdgcn_readfirstlane(*t.amax_s)));
+    const float bound = __uint_as_float((unsigned)(L.keys[src] >> 32));
+    const unsigned long long t_loaded = stats ? (bound == -1.f ? 1ull : wall_clock64()) : 0ull;
+    int n_ent = 0;
+    auto stage = [&](const float* __restrict__ boxes, int count) {     // count boxes -> s_box, by the whole workgroup
+        __syncthreads();
+        const float4* __restrict__ from = reinterpret_cast<const float4*>(boxes);
+        float4* to = reinterpret_cast<float4*>(s_box);
+        for (int e = threadIdx.x; e < count * (LM_BOX / 4); e += 64 * LM_WAVES) to[e] = from[e];
+        __syncthreads();
+    };
+    auto flush = [&]() {
+        if (n_ent == 0) return;
+        const int pool = (blockIdx.x * LM_WAVES + wave) % LM_POOLS;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(L.entry_cursor + pool, n_ent);
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < n_ent; e += 64)      // one instruction for all the boxes' counters, nothing waits for them; per pool: a counter per leaf alone
+            atomicAdd(&L.pool_count[(size_t)pool * t.nleaf + s_leaf[wave][e]], __popcll(s_mask[wave][e]));   // queued ~20 atomics from all over the chip on one address
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + n_ent > L.pool_cap) { if (lane == 0) *L.overflow = 1; }
+        else
+            for (int e = lane; e < n_ent; e += 64) {
+                const unsigned long long m = s_mask[wave][e];
+                L.entries[(size_t)pool * L.pool_cap + base + e] = make_int4(s_leaf[wave][e], s0, (int)(unsigned)m, (int)(unsigned)(m >> 32));
+            }
+        __builtin_amdgcn_wave_barrier();
+        n_ent = 0;
+    };
+    auto leaves_of_group = [&](int g) {
+        const int l0 = g * FX_GROUP, cnt = min(FX_GROUP, t.nleaf - l0);
+        stage(sleaf + (size_t)l0 * LM_BOX, cnt);
+        for (int i = wave; i < cnt; i += LM_WAVES) {
+            const int l = l0 + i;
+            const float* box = s_box + i * LM_BOX;
+            const bool p3 = lm_pass3(box, q, pmargin, t.pscale, bound);
+            ++n3;
+            if (!__any(p3)) continue;
+            ++n33;
+            const float lb = lm_bound33(box, q);
+            const unsigned long long m = __ballot(valid && p3 && lb <= bound && l != home);   // (its home leaf: round 0 evaluated it; an empty box (+inf, -inf) has lb = +inf: never set)
+            if (!m) continue;
+            if (lane == 0) { s_leaf[wave][n_ent] = l; s_mask[wave][n_ent] = m; }
+            ++nemit;
+            if (++n_ent == LM_ENTRIES) flush();
+        }
+    };
+    if (ROUND == 1) {
+        unsigned long long todo = __ballot(valid);
+        while (todo) {                                           // the workgroup's distinct home groups
+            const int g = __builtin_amdgcn_readlane(hg, __builtin_ctzll(todo));
+            todo &= ~__ballot(hg == g);
+            leaves_of_group(g);
+        }
+    } else {
+        for (int g0 = 0; g0 < t.ngroup; g0 += 64) {
+            const int gcnt = min(64, t.ngroup - g0);
+            stage(sgroup + (size_t)g0 * LM_BOX, gcnt);
+            unsigned long long gm = 0ull;                        // groups some lane cannot exclude (the same in all four waves)
+            for (int i = 0; i < gcnt; ++i) {
+                if (ROUND == 2 && __ballot(hg == g0 + i)) continue;   // one of the home groups: round 1 tested its leaves for every lane
+                const float* box = s_box + i * LM_BOX;
+                const bool p3 = lm_pass3(box, q, pmargin, t.pscale, bound);
+                if (!__any(p3)) continue;
+                const float lb = lm_bound33(box, q);
+                if (__ballot(valid && p3 && lb <= bound)) gm |= 1ull << i;
+            }
+            while (gm) {
+                const int g = g0 + __builtin_ctzll(gm);
+                gm &= gm - 1ull;
+                leaves_of_group(g);
+            }
+        }
+    }
+    const unsigned long long t_f0 = stats ? wall_clock64() : 0ull;
+    flush();
+    if (stats && lane == 0) {      // [0] waves [1] ticks total [2] ticks until the source is loaded [3] ticks of the last flush [4] 3-D tests [5] 33-D tests [6] boxes emitted [7] max ticks
+        const unsigned long long t_end = wall_clock64();
+        atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], t_end - t_begin); atomicAdd(&stats[2], t_loaded - t_begin); atomicAdd(&stats[3], t_end - t_f0);
+        atomicAdd(&stats[4], (unsigned long long)n3); atomicAdd(&stats[5], (unsigned long long)n33); atomicAdd(&stats[6], (unsigned long long)nemit); atomicMax(&stats[7], t_end - t_begin);
+    }
+    (void)t_flush;
+}
+
+// leaf_start / unit_start: exclusive scans of the pair counts and of the unit counts (a unit = up to 64 sources of one leaf).
+// POOLS: the counts come per pool; every pool also learns where its sources of every leaf go (pool order inside a leaf).
+template <bool POOLS>
+__global__ __launch_bounds__(1024)
+void k_lm_plan(LmLists L, int nleaf) {
+    __shared__ int s_w[2][16], s_carry[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_carry[0] = 0; s_carry[1] = 0; }
+    __syncthreads();
+    const bool dead = *L.overflow != 0;                      // the entry pool ran over: nothing below may be trusted, the call falls back
+    for (int l0 = 0; l0 < nleaf; l0 += 1024) {
+        const int l = l0 + threadIdx.x;
+        int c = 0;
+        int pc_of[POOLS ? LM_POOLS : 1];                     // (registers: the loop is unrolled; loads first, stores later, so that they overlap)
+        if (l < nleaf && !dead) {
+            if (POOLS) {
+#pragma unroll
+                for (int p = 0; p < LM_POOLS; ++p) pc_of[p] = L.pool_count[(size_t)p * nleaf + l];
+#pragma unroll
+                for (int p = 0; p < LM_POOLS; ++p) c += pc_of[p];
+                L.leaf_count[l] = c;
+            } else c = L.leaf_count[l];
+        }
+        const int u = (c + 63) >> 6;
+        int ic = c, iu = u;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int a = __shfl_up(ic, off, 64), b = __shfl_up(iu, off, 64); if (lane >= off) { ic += a; iu += b; } }
+        if (lane == 63) { s_w[0][wave] = ic; s_w[1][wave] = iu; }
+        __syncthreads();
+        int bc = s_carry[0], bu = s_carry[1];
+        for (int w = 0; w < wave; ++w) { bc += s_w[0][w]; bu += s_w[1][w]; }
+        const int pc = bc + ic - c, pu = bu + iu - u;
+        if (l < nleaf) {
+            L.leaf_start[l] = pc; L.unit_start[l] = pu;
+            for (int k = 0; k < u; ++k) L.unit_leaf[pu + k] = l;
+            if (POOLS && !dead) {
+                int run = pc;
+#pragma unroll
+                for (int p = 0; p < LM_POOLS; ++p) { L.pool_start[(size_t)p * nleaf + l] = run; run += pc_of[p]; }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { s_carry[0] = bc + ic; s_carry[1] = bu + iu; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool fits = s_carry[0] <= L.pair_cap;          // (round 0: the sources themselves)
+        if (!fits) *L.overflow = 1;
+        L.leaf_start[nleaf] = s_carry[0]; L.unit_start[nleaf] = fits ? s_carry[1] : 0;
+    }
+}
+
+// every entry's sources to their leaf's stretch of sorted_src: ONE WORKGROUP PER POOL, with the pool's write positions (one per leaf) in
+// LDS.  A wave takes 64 entries - a returning LDS atomic per lane - then goes through them entry by entry with lane = source.
+// (Positions from returning atomics on one global counter per leaf: 45 us however the rest was arranged - some twenty atomics from all
+// over the chip on one address wait for each other.)
+__global__ __launch_bounds__(1024)
+void k_lm_scatter(LmLists L, int nleaf) {      // grid LM_POOLS, dynamic LDS nleaf ints
+    extern __shared__ int s_cur[];
+    if (*L.overflow) return;
+    const int pool = blockIdx.x;
+    for (int l = threadIdx.x; l < nleaf; l += 1024) s_cur[l] = L.pool_start[(size_t)pool * nleaf + l];
+    __syncthreads();
+    const int n = min(L.entry_cursor[pool], L.pool_cap);
+    const int4* __restrict__ ent = L.entries + (size_t)pool * L.pool_cap;
+    int* __restrict__ out = L.sorted_src;
+    const int lane = threadIdx.x & 63;
+    for (int i0 = threadIdx.x - lane; i0 < n; i0 += 1024) {
+        const bool valid = i0 + lane < n;
+        const int4 e = valid ? ent[i0 + lane] : make_int4(0, 0, 0, 0);
+        const unsigned long long m = ((unsigned long long)(unsigned)e.w << 32) | (unsigned)e.z;
+        const int base = valid ? atomicAdd(&s_cur[e.x], __popcll(m)) : 0;
+        const int cnt = min(64, n - i0);
+        for (int k = 0; k < cnt; ++k) {
+            const unsigned long long mk = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(e.w, k) << 32) | (unsigned)__builtin_amdgcn_readlane(e.z, k);
+            const int bk = __builtin_amdgcn_readlane(base, k), sk = __builtin_amdgcn_readlane(e.y, k);
+            if ((mk >> lane) & 1ull) out[bk + __popcll(mk & ((1ull << lane) - 1ull))] = sk + lane;     // (the position in the search order: k_lm_eval looks the source up)
+        }
+    }
+}
+
+// INIT: round 0 - the units are the sources of every leaf that are at home there (L.sorted_src = the search order itself, L.leaf_count =
+// the histogram the ordering made); every source occurs exactly once and gets its first key.
+template <bool INIT>
+__global__ __launch_bounds__(64 * LM_WAVES)
+void k_lm_eval(FmTables t, LmLists L) {
+    __shared__ __attribute__((aligned(16))) float s_rows[LM_WAVES][FD * FX_LEAF];
+    if (*L.overflow) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int total = L.unit_start[t.nleaf];
+    // workgroups are dealt round-robin over the 8 XCDs: every XCD takes a contiguous stretch of the units (= of the leaves)
+    const int vblocks = (total + LM_WAVES - 1) / LM_WAVES, per_xcd = (vblocks + 7) / 8;
+    const int xcd = blockIdx.x & 7, step = max(1, (int)gridDim.x >> 3);
+    for (int j = blockIdx.x >> 3; j < per_xcd; j += step) {
+        const int u = __builtin_amdgcn_readfirstlane((xcd * per_xcd + j) * LM_WAVES + wave);
+        if (u >= total) continue;
+        const int leaf = __builtin_amdgcn_readfirstlane(L.unit_leaf[u]);
+        const int chunk = u - L.unit_start[leaf];
+        const int p0 = L.leaf_start[leaf] + chunk * 64, cnt = L.leaf_count[leaf] - chunk * 64;
+        const bool valid = lane < cnt;
+        const int listed = L.sorted_src[p0 + (valid ? lane : 0)];
+        const int src = INIT ? listed : t.sperm[listed];         // (round 0 walks the search order itself; later rounds list positions in it)
+        const unsigned long long before = INIT ? LM_KEY_NONE : L.keys[src];
+        LmSrc q;
+        lm_load_source(t, src, q);
+        unsigned long long key = before;
+        lm_stage_leaf(t.T, leaf, s_rows[wave], lane);
+        lm_eval_leaf(s_rows[wave], t.torig, leaf, q, key);
+        if (INIT) { if (valid) L.keys[src] = key; }
+        else if (valid && key < before) atomicMin(&L.keys[src], key);
+    }
+}
+
+__global__ void k_lm_finish(const unsigned long long* __restrict__ keys, int ns, const int* __restrict__ ovf1, const int* __restrict__ ovf2,
+                            int* __restrict__ corr, int* __restrict__ host_flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { host_flag[0] = (*ovf1 | *ovf2) ? 1 : 0; __threadfence_system(); }
+    if (i >= ns) return;
+    const unsigned long long k = keys[i];
+    corr[i] = (unsigned)(k >> 32) == 0x7f7fffffu ? 0 : (int)(unsigned)k;   // nothing finite -> the reference keeps index 0
+}
+
 namespace {
 
 // cyclic Jacobi eigen-solver for a symmetric n x n matrix (host, double): eigenvalues descending, eigenvectors in rows
@@ -1254,6 +1637,8 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     TDV_TRY(ws_alloc(ctx, (size_t)ngroup * 2 * PD * FX_GROUP, &ix->pbox));
     TDV_TRY(ws_alloc(ctx, (size_t)nchunk * 2 * PD * 64, &ix->gpbox));
     TDV_TRY(ws_alloc(ctx, 1, &ix->amax));
+    TDV_TRY(ws_alloc(ctx, (size_t)nleaf * LM_BOX, &ix->sleaf));
+    TDV_TRY(ws_alloc(ctx, (size_t)ngroup * LM_BOX, &ix->sgroup));
     const WsMark scratch = ws_mark(ctx);   // everything below is build scratch
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &p0));
     TDV_TRY(ws_alloc(ctx, (size_t)nt, &p1));
@@ -1303,6 +1688,7 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     k_fm_place_rows<<<(unsigned)(((size_t)nk * FD + 255) / 256), 256, 0, s>>>(rec, nk, d_col_start, d_col_row0, ncol, d_ft, p0, p1, p2, ix->T, ix->torig, ix->leaf_p2, prow, rows);
     k_fm_leaf_boxes<<<(ngroup * FX_GROUP * (FD + PD) + 255) / 256, 256, 0, s>>>(ix->T, ix->torig, prow, rows, nleaf, ngroup, ix->lbox, ix->pbox);
     k_fm_group_boxes<<<(nchunk * 64 * (FD + PD) + 255) / 256, 256, 0, s>>>(ix->lbox, ix->pbox, ngroup, nchunk, ix->gbox, ix->gpbox);
+    k_lm_box_layout<<<((nleaf + ngroup) * LM_BOX + 255) / 256, 256, 0, s>>>(ix->lbox, ix->pbox, ix->gbox, ix->gpbox, nleaf, ngroup, ix->sleaf, ix->sgroup);
     TDV_CHECK_LAUNCH(ctx);
     TDV_HIP(ctx, hipStreamSynchronize(s));   // the pinned staging is reused by later calls; the scratch is released here
     ws_rewind(ctx, scratch);
@@ -1376,6 +1762,78 @@ static int launch_fm_query(tdv_ctx* ctx, const FmTables& t, const FmIndex& ix, i
     return TDV_OK;
 }
 
+// The leaf-major search (kernels above).  *done = false: the pair pool ran over (descriptors without structure) - the caller
+// runs k_fm_query and its fall-backs instead.  One synchronisation, like launch_fm_query.
+static int launch_fm_leafmajor(tdv_ctx* ctx, const FmTables& t, const FmIndex& ix, int* home_hist /* sources per home leaf: what the ordering counted */, int* d_corr, bool* done) {
+    hipStream_t s = ctx->stream;
+    *done = false;
+    const int nleaf = ix.nleaf;
+    const size_t pair_cap = (size_t)LM_PAIRS_PER_SOURCE * (size_t)t.ns + 4096;
+    const size_t pool_cap = ((size_t)t.ns + 4096) / LM_POOLS + 64;     // entries: one box x up to 64 sources each
+    if (pair_cap > (size_t)INT_MAX / 2) return TDV_OK;
+    const size_t unit_cap = pair_cap / 64 + (size_t)nleaf + 2, per_round = (size_t)LM_POOLS * nleaf + LM_POOLS + 1;
+    const int waves = (t.ns + 63) / 64;
+    int *zeroed, *sorted_src, *leaf_count, *pool_start, *leaf_start, *unit_start, *unit_leaf; unsigned long long* keys;
+    TDV_TRY(ws_alloc(ctx, 2 * per_round + 1, &zeroed));
+    int4* entries;
+    TDV_TRY(ws_alloc(ctx, pool_cap * LM_POOLS, &entries));
+    TDV_TRY(ws_alloc(ctx, pair_cap, &sorted_src));
+    TDV_TRY(ws_alloc(ctx, (size_t)nleaf, &leaf_count));
+    TDV_TRY(ws_alloc(ctx, (size_t)LM_POOLS * nleaf, &pool_start));
+    TDV_TRY(ws_alloc(ctx, (size_t)nleaf + 1, &leaf_start));
+    TDV_TRY(ws_alloc(ctx, (size_t)nleaf + 1, &unit_start));
+    TDV_TRY(ws_alloc(ctx, unit_cap, &unit_leaf));
+    TDV_TRY(ws_alloc(ctx, (size_t)t.ns, &keys));
+    TDV_TRY(pin_reserve(ctx, 256));
+    int* h_flag = reinterpret_cast<int*>(ctx->pin);
+    h_flag[0] = 1;
+    TDV_HIP(ctx, hipMemsetAsync(zeroed, 0, (2 * per_round + 1) * 4, s));
+    LmLists L[3];
+    for (int r = 0; r < 2; ++r) {
+        int* z = zeroed + r * per_round;
+        L[r + 1] = LmLists{z, z + (size_t)LM_POOLS * nleaf, z + (size_t)LM_POOLS * nleaf + LM_POOLS, leaf_count, pool_start, entries, (int)pool_cap, (int)pair_cap, leaf_start, unit_start, unit_leaf, sorted_src, keys};
+    }
+    // round 0: every source against its home leaf.  The search order is sorted by home leaf, so it IS the sorted pair list.
+    L[0] = LmLists{nullptr, nullptr, zeroed + 2 * per_round, home_hist, nullptr, nullptr, 0, INT_MAX, leaf_start, unit_start, unit_leaf, const_cast<int*>(t.sperm), keys};
+    unsigned long long* d_stats = nullptr;
+    if (getenv("TDV_FM_STATS")) { TDV_TRY(ws_alloc(ctx, 16, &d_stats)); TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, s)); }
+    static const int eval_blocks = getenv("TDV_LM_EVAL_BLOCKS") ? atoi(getenv("TDV_LM_EVAL_BLOCKS")) : 2048;   // tuning knob (a multiple of 8)
+    const char* rounds_env = getenv("TDV_LM_ROUNDS");          // study knob: 1 = every group in one round of box tests
+    const int rounds = ix.ngroup > 1 ? ((rounds_env && atoi(rounds_env) == 1) ? 1 : 2) : 1;
+    k_lm_plan<false><<<1, 1024, 0, s>>>(L[0], nleaf);
+    k_lm_eval<true><<<eval_blocks, 64 * LM_WAVES, 0, s>>>(t, L[0]);
+    for (int r = 1; r <= rounds; ++r) {
+        if (rounds == 1 && ix.ngroup > 1) k_lm_boxes<3><<<waves, 64 * LM_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats);
+        else if (r == 1) k_lm_boxes<1><<<waves, 64 * LM_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats);
+        else k_lm_boxes<2><<<waves, 64 * LM_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats ? d_stats + 8 : nullptr);
+        k_lm_plan<true><<<1, 1024, 0, s>>>(L[r], nleaf);
+        k_lm_scatter<<<LM_POOLS, 1024, (size_t)nleaf * 4, s>>>(L[r], nleaf);
+        k_lm_eval<false><<<eval_blocks, 64 * LM_WAVES, 0, s>>>(t, L[r]);
+    }
+    k_lm_finish<<<(t.ns + 255) / 256, 256, 0, s>>>(keys, t.ns, L[1].overflow, L[2].overflow, d_corr, h_flag);
+    TDV_CHECK_LAUNCH(ctx);
+    TDV_HIP(ctx, hipStreamSynchronize(s));
+    *done = h_flag[0] == 0;
+    if (d_stats) {                                           // study knob
+        int h[2][LM_POOLS + 1];
+        long long pairs[2] = {0, 0};
+        for (int r = 0; r < 2; ++r) {
+            TDV_HIP(ctx, hipMemcpy(h[r], L[r + 1].entry_cursor, (LM_POOLS + 1) * 4, hipMemcpyDeviceToHost));
+            for (int k = 0; k < LM_POOLS; ++k) pairs[r] += h[r][k];
+        }
+        fprintf(stderr, "[tdv] fm leaf-major: %d sources x %d leaves in %d groups: round 1 %lld entries (%.2f per source)%s, round 2 %lld entries (%.2f per source)%s\n",
+                t.ns, nleaf, ix.ngroup, pairs[0], (double)pairs[0] / t.ns, h[0][LM_POOLS] ? " OVERFLOW" : "", pairs[1], (double)pairs[1] / t.ns, h[1][LM_POOLS] ? " OVERFLOW" : "");
+        unsigned long long st[16];
+        TDV_HIP(ctx, hipMemcpy(st, d_stats, 128, hipMemcpyDeviceToHost));
+        for (int r = 0; r < 2; ++r) {
+            const unsigned long long* q = st + 8 * r; const double w = (double)std::max(1ull, q[0]);
+            fprintf(stderr, "[tdv]   boxes round %d: %llu waves, per wave %.1f us (max %.1f), %.1f us until the source is loaded, %.1f us last flush; %.1f 3-D tests, %.1f 33-D tests, %.1f boxes emitted\n",
+                    r + 1, q[0], q[1] / w * 0.01, q[7] * 0.01, q[2] / w * 0.01, q[3] / w * 0.01, q[4] / w, q[5] / w, q[6] / w);
+        }
+    }
+    return TDV_OK;
+}
+
 int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmIndex& ix, int* d_corr) {
     if (!ctx || !d_fs || !d_corr || ns < 0) return TDV_ERR_BAD_ARG;
     if (ns == 0) return TDV_OK;
@@ -1407,6 +1865,13 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     static const int force_k = getenv("TDV_FM_K") ? atoi(getenv("TDV_FM_K")) : 0;   // tuning knob (sources per wave)
     const int k = force_k ? force_k : 2;
     float* fs2 = nullptr;
+    const char* lm = getenv("TDV_FM_LEAFMAJOR");                  // A/B knob, read per call: 0 = round 2's walk (k_fm_query) for everything
+    if (!(lm && atoi(lm) == 0) && ix.sleaf && bucket_shift == 0) {     // (bucket_shift: more than 16,384 leaves - the ordering's histogram is then not per leaf)
+        FmTables t{d_fs, sperm, home, ns, nullptr, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, ix.pbox, ix.gpbox, sp, ix.amax, amax_s, ix.pscale};
+        bool done = false;
+        TDV_TRY(launch_fm_leafmajor(ctx, t, ix, hist, d_corr, &done));
+        if (done) return TDV_OK;
+    }
     if (k >= 2) {
         const int kk = k >= 4 ? 4 : 2;
         const size_t n2 = ((size_t)ns + kk - 1) / kk * kk * FD;

@@ -21,7 +21,8 @@ def test_c5_1024_instances_from_one_label_image(ctx, tdv, synth, orc):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     c5 = importlib.import_module("c5_tray")
     dev = torch.device("cuda", 0)
-    out, wl, res = c5.measure(tdv, synth, ctx, torch, dev, N_INST)
+    own = tdv.Context(0)         # a context of its own: the workspace figure below is then this workload's, not the test session's
+    out, wl, res = c5.measure(tdv, synth, own, torch, dev, N_INST)
     print(out)
     sc = wl["sc"]
     S, F, CX, CY, V, ZMAX = sc["scale"], sc["fx"], sc["cx"], sc["cy"], sc["voxel"], sc["zmax"]

@@ -269,10 +269,11 @@ def test_feature_match_pruned_degenerate_rows(ctx, orc, synth):
     assert got[3] == 0 and got[10] == 0 and not np.isin(got[np.arange(ns) != 3], [77]).any()
 
 
-def test_feature_match_three_paths_on_relief_descriptors(ctx, tdv, orc, synth):
+def test_feature_match_four_paths_on_relief_descriptors(ctx, tdv, orc, synth):
     """Descriptors of the relief part (the full-chain workload) at a size that takes the packed-index search: the
-    index search, round 1's key-ordered pruned scan (TDV_FM_KEYORDER) and the plain scan (TDV_FM_BRUTE) all return the
-    oracle's correspondences; so do non-finite rows, duplicated rows and a target set that is one repeated row."""
+    leaf-major index search (round 3, the default), round 2's walk over the same index (TDV_FM_LEAFMAJOR=0), round 1's
+    key-ordered pruned scan (TDV_FM_KEYORDER) and the plain scan (TDV_FM_BRUTE) all return the oracle's correspondences;
+    so do non-finite rows, duplicated rows and a target set that is one repeated row."""
     import os
     import chain_scene as cs
     sc = cs.build(synth, n_instances=1)
@@ -291,18 +292,22 @@ def test_feature_match_three_paths_on_relief_descriptors(ctx, tdv, orc, synth):
     ft[200, 0] = np.nan; ft[201, 5] = np.inf     # rows that are never chosen
     ref = orc.feature_match(fs, ft)
     try:
-        for knob in (None, "TDV_FM_KEYORDER", "TDV_FM_BRUTE"):
+        for knob, value in ((None, None), ("TDV_FM_LEAFMAJOR", "0"), ("TDV_FM_KEYORDER", "1"), ("TDV_FM_BRUTE", "1")):
             if knob:
-                os.environ[knob] = "1"
+                os.environ[knob] = value
             got = ctx.feature_match(fs, ft)
             assert np.array_equal(got, ref), (knob, int((got != ref).sum()))
             if knob:
                 del os.environ[knob]
     finally:
-        os.environ.pop("TDV_FM_KEYORDER", None); os.environ.pop("TDV_FM_BRUTE", None)
+        for knob in ("TDV_FM_LEAFMAJOR", "TDV_FM_KEYORDER", "TDV_FM_BRUTE"):
+            os.environ.pop(knob, None)
     assert ref[100] == 0 and ref[101] == 0 and (ref[:40] < 5000).all()
     one = np.repeat(ft[:1], 3000, 0)
     assert (ctx.feature_match(fs[:5000], one)[:99] == 0).all()
+    # a source far from every target needs every leaf: in the leaf-major search it simply owns one pair per leaf
+    far = fs[:5000].copy(); far[17] = 1e3; far[4000] = -50.0
+    assert np.array_equal(ctx.feature_match(far, ft), orc.feature_match(far, ft))
 
 
 def test_ransac_rejects_correspondences_outside_the_target(ctx, tdv, synth):

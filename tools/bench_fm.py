@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Descriptor match on the C4 workload's real FPFH descriptors (one instance vs the model), timed per path:
-packed-index search (index build and query separately), round 1's key-ordered pruned scan, the plain scan.
+packed-index search (leaf-major, the default; "walk" = round 2's k_fm_query; index build and query separately), round 1's
+key-ordered pruned scan, the plain scan.
     python tools/bench_fm.py [--voxel-px 1.2] [--reps 5] [--stats]"""
 import argparse
 import importlib
@@ -37,7 +38,7 @@ def main():
     ap.add_argument("--voxel-px", type=float, default=1.2)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--stats", action="store_true")
-    ap.add_argument("--paths", default="index,keyorder,brute")
+    ap.add_argument("--paths", default="index,walk,keyorder,brute")
     args = ap.parse_args()
     tdv = importlib.import_module("3dvision_amd"); synth = importlib.import_module("3dvision_amd.synth")
     dev = torch.device("cuda", 0)
@@ -47,10 +48,11 @@ def main():
     out = dict(ns=ns, nt=nt)
     ref = None
     for path in args.paths.split(","):
-        for k in ("TDV_FM_KEYORDER", "TDV_FM_BRUTE", "TDV_FM_STATS"):
+        for k in ("TDV_FM_KEYORDER", "TDV_FM_BRUTE", "TDV_FM_STATS", "TDV_FM_LEAFMAJOR"):
             os.environ.pop(k, None)
         if path == "keyorder": os.environ["TDV_FM_KEYORDER"] = "1"
         if path == "brute": os.environ["TDV_FM_BRUTE"] = "1"
+        if path == "walk": os.environ["TDV_FM_LEAFMAJOR"] = "0"     # round 2's search (k_fm_query): a wave walks its two sources' leaves
         if path == "index" and args.stats:
             os.environ["TDV_FM_STATS"] = "1"
             ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_corr.data_ptr())
