@@ -692,7 +692,6 @@ __device__ __forceinline__ float box_bound(const float (&f)[FD], const float* __
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v16f __attribute__((ext_vector_type(16)));
 
 // the descriptors of the K sources of every wave, interleaved: fsk[wave][d][k] = fs[sperm[K wave + k]][d] (a wave past the
 // end of an uneven count repeats the last source, as FmWave does): (q_k[d], q_k+1[d]) is then one aligned SGPR pair
@@ -1110,33 +1109,37 @@ void k_fm_query_overflow(FmTables t, const int* __restrict__ overflow_count, con
 
 // ---- leaf-major search (round 3; the default) --------------------------------------------------------------------------
 // k_fm_query spends 40 % of its instructions on box tests (lane = box, one or two sources per wave) and walks a source's
-// leaves one after the other, so a few sources that need hundreds of leaves decide when the call ends.  Here the roles are
-// swapped: LANE = SOURCE everywhere, boxes and target rows come through the scalar path, and the leaves are not walked
-// by the sources that need them but collected:
-//   k_lm_boxes<1>   a wave = 64 sources in home-leaf order.  Every lane evaluates the wave's distinct home leaves (1-3
-//                   of them: a first bound), then tests the leaf boxes of the wave's home group(s) - the 3-D principal
-//                   box first, the 33-D box where any lane passes it - and emits a (leaf, source) PAIR for every box a
-//                   source cannot exclude.  Pairs are buffered per wave in LDS (leaf, lane mask) and written with one
-//                   returning atomic per 96 boxes.
-//   k_lm_plan       one workgroup: scan of the per-leaf pair counts -> where each leaf's sources start, and the list of
-//                   work units (a leaf x up to 64 of its sources).
-//   k_lm_scatter    pairs to their leaf's stretch (one atomic per run of equal leaves inside a wave).
-//   k_lm_eval       one wave per unit: the leaf's 64 rows x 33 dimensions through the scalar path (16 rows of one dimension
-//                   per s_load_dwordx16), two rows per packed instruction: 3 x 33 x 32 v_pk_*_f32 per 64 sources x 64 rows,
-//                   the reference's operations in the reference's order (registration.cpp:222-224).  A lane that found a
-//                   smaller (distance, index) key lowers its source's key with a 64-bit atomic min.  Units of one leaf
-//                   run next to each other, so its 8.4 KB stay in the scalar cache.
-//   k_lm_boxes<2>   the same for every OTHER group, with the bounds round 1 left (group boxes first), then plan / scatter /
-//                   eval again, and k_lm_finish writes the correspondences.
+// leaves one after the other: 13 % of the lane-op peak, and a few sources that need hundreds of leaves decide when the call
+// ends.  Here the roles are swapped - LANE = SOURCE everywhere, boxes and target rows staged in LDS and read back as
+// broadcasts - and the leaves are not walked by the sources that need them but COLLECTED per leaf and evaluated with full waves:
+//   k_lm_plan<false> + k_lm_eval<true>   round 0: every source against its home leaf.  The search order is sorted by home
+//                   leaf, so it already is the per-leaf list; the histogram the ordering made gives the work units.
+//   k_lm_boxes<3>   a workgroup = 64 sources in home-leaf order, lane = source in each of its 4 waves.  Group boxes, then the
+//                   leaf boxes of every group some lane cannot exclude - the 3-D principal box first, the 33-D box where any
+//                   lane passes it - with the bound round 0 left.  A box a source cannot exclude is a (leaf, source) PAIR;
+//                   a wave records them as entries (leaf, first source, lane mask) and counts them per pool and leaf.
+//   k_lm_plan<true> one workgroup: sources per leaf (summed over the pools), exclusive scans -> where each leaf's sources go,
+//                   where each pool's share of a leaf goes, and the list of work units (a leaf x up to 64 of its sources).
+//   k_lm_scatter    one workgroup per pool, write positions in LDS: the entries' sources to their leaf's stretch.
+//   k_lm_eval<false> one wave per unit: the leaf (8.4 KB) staged in the wave's own LDS, 64 rows x 33 dimensions against 64
+//                   sources, two rows per packed instruction: 3 x 33 x 32 v_pk_*_f32 per unit, the reference's operations
+//                   in the reference's order (registration.cpp:222-224); 64 % of the nominal lane-op peak.  A lane that found
+//                   a smaller (distance, index) key lowers its source's key with a 64-bit atomic min.
+//   k_lm_finish     keys -> correspondences; the overflow flag straight into pinned host memory.
 // A source that needs hundreds of leaves simply owns hundreds of pairs spread over as many units: there is no tail and no
 // overflow pass.  Exactness as before: every row that is not evaluated lies in a box whose bound (same expression, same
 // order, monotone float operations) exceeds a distance the source had already reached; bounds only shrink, so a pair
 // emitted early is at worst superfluous.  The result is the minimum over 64-bit (distance bits : original index) keys,
-// which does not depend on the order of the atomics.  Descriptors without structure (every box passes) overflow the pair
-// pool (32 per source): the call then falls back to k_fm_query and its scan class.
-constexpr int LM_BOX = 72;        // floats per scalar-layout box: min[33] | max[33] | pmin[3] | pmax[3]
+// which does not depend on the order of the atomics.  Descriptors without structure (every box passes) overflow the entry
+// pools or the pair room (32 per source): the call then falls back to k_fm_query and its scan class.
+// What was measured on the way (143k x 151k relief descriptors; profiles/r3/history/feature_match_leaf_major.md): rows and boxes
+// through the scalar path 0.84 ms (a leaf is 8.4 KB, the scalar cache 16 KB per CU with a slow fill path); one global cursor for
+// the pairs / one global counter per leaf for the positions: 9,000 and ~20 same-address returning atomics wait for each other
+// (50 us / 45 us); two rounds of box tests (home groups first) 9.7 instead of 12.1 pairs per source but 0.525 instead of
+// 0.487 ms; two sources per lane in k_lm_eval (half the LDS reads) and the next group's boxes prefetched into registers: no gain.
+constexpr int LM_BOX = 72;        // floats per box as this search stores them: min[33] | max[33] | pmin[3] | pmax[3]
 constexpr int LM_WAVES = 4;       // waves per workgroup
-constexpr int LM_ENTRIES = 96;    // (leaf, lane mask) entries a wave buffers before it reserves room for their pairs
+constexpr int LM_ENTRIES = 96;    // (leaf, lane mask) entries a wave buffers in LDS before it reserves room for them in its pool
 constexpr int LM_PAIRS_PER_SOURCE = 32;
 constexpr int LM_POOLS = 64;
 constexpr unsigned long long LM_KEY_NONE = (unsigned long long)0x7f7fffffu << 32;   // FLT_MAX : 0 - only dist < FLT_MAX is ever taken (registration.cpp:218-219)
@@ -1153,11 +1156,9 @@ struct LmLists {
     unsigned long long* keys;                             // [ns]
 };
 struct LmSrc { v2f p[(FD + 1) / 2]; float pq[PD]; };     // a lane's source: descriptor as 17 register pairs, principal coordinates
-// Index tables as the kernels below read them: the "constant" address space tells the compiler that nothing in the kernel
-// writes them, which is what lets it use the scalar path (s_load) although the same kernels store pairs and keys.
-typedef const __attribute__((address_space(4))) float* lm_cfloat_p;
+// The original row indices of a leaf as k_lm_eval reads them (rarely: only where a lane can improve): the "constant" address space
+// tells the compiler that nothing in the kernel writes them, which lets it use the scalar path although the kernel stores keys.
 typedef const __attribute__((address_space(4))) int* lm_cint_p;
-typedef const __attribute__((address_space(4))) v16f* lm_cv16_p;
 
 __global__ void k_lm_box_layout(const float* __restrict__ lbox, const float* __restrict__ pbox, const float* __restrict__ gbox, const float* __restrict__ gpbox,
                                 int nleaf, int ngroup, float* __restrict__ sleaf, float* __restrict__ sgroup) {
@@ -1798,8 +1799,10 @@ static int launch_fm_leafmajor(tdv_ctx* ctx, const FmTables& t, const FmIndex& i
     unsigned long long* d_stats = nullptr;
     if (getenv("TDV_FM_STATS")) { TDV_TRY(ws_alloc(ctx, 16, &d_stats)); TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, s)); }
     static const int eval_blocks = getenv("TDV_LM_EVAL_BLOCKS") ? atoi(getenv("TDV_LM_EVAL_BLOCKS")) : 2048;   // tuning knob (a multiple of 8)
-    const char* rounds_env = getenv("TDV_LM_ROUNDS");          // study knob: 1 = every group in one round of box tests
-    const int rounds = ix.ngroup > 1 ? ((rounds_env && atoi(rounds_env) == 1) ? 1 : 2) : 1;
+    // One round of box tests after the home leaves (12.1 pairs per source at 143k x 151k).  TDV_LM_ROUNDS=2: the home groups first, the
+    // other groups with the bounds those left (9.7 pairs per source, but a second set of launches: 0.525 against 0.487 ms).
+    const char* rounds_env = getenv("TDV_LM_ROUNDS");
+    const int rounds = (ix.ngroup > 1 && rounds_env && atoi(rounds_env) == 2) ? 2 : 1;
     k_lm_plan<false><<<1, 1024, 0, s>>>(L[0], nleaf);
     k_lm_eval<true><<<eval_blocks, 64 * LM_WAVES, 0, s>>>(t, L[0]);
     for (int r = 1; r <= rounds; ++r) {

@@ -153,7 +153,7 @@ struct FmIndex {
     float* lbox = nullptr;                                          // leaf boxes [group][min | max][33][64 leaves]
     float* gbox = nullptr;                                          // group boxes [chunk of 64 groups][min | max][33][64 groups]
     float *pbox = nullptr, *gpbox = nullptr;                        // the same for the 3 principal coordinates: [..][min | max][3][64]
-    float *sleaf = nullptr, *sgroup = nullptr;                      // the same boxes once more, one box = 72 consecutive floats (min[33] | max[33] | pmin[3] | pmax[3]): read through the scalar path by the leaf-major search
+    float *sleaf = nullptr, *sgroup = nullptr;                      // the same boxes once more, one box = 72 consecutive floats (min[33] | max[33] | pmin[3] | pmax[3]): staged in LDS by the leaf-major search (k_lm_boxes)
     unsigned* amax = nullptr; float pscale = 0.f;                   // largest |x_d - mean_d| of the targets (float bits); 0 disables the 3-D boxes
     float *basis = nullptr, *b0 = nullptr, *b1 = nullptr, *leaf_p2 = nullptr; const int* col_leaf0 = nullptr;   // locating a source's cell
     int nt = 0, rows = 0, nleaf = 0, ngroup = 0, S0 = 1, S1 = 1;

@@ -53,11 +53,11 @@ def main():
         if path == "keyorder": os.environ["TDV_FM_KEYORDER"] = "1"
         if path == "brute": os.environ["TDV_FM_BRUTE"] = "1"
         if path == "walk": os.environ["TDV_FM_LEAFMAJOR"] = "0"     # round 2's search (k_fm_query): a wave walks its two sources' leaves
-        if path == "index" and args.stats:
+        ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_corr.data_ptr())   # warm-up
+        if path in ("index", "walk") and args.stats:
             os.environ["TDV_FM_STATS"] = "1"
             ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_corr.data_ptr())
             os.environ.pop("TDV_FM_STATS")
-        ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_corr.data_ptr())   # warm-up
         ctx.timing_enable(True)
         ctx.timing_read(tdv.TIMER_FEATURE_MATCH); ctx.timing_read(7)
         torch.cuda.synchronize(); t0 = time.perf_counter()
