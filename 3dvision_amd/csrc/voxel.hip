@@ -523,8 +523,8 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
         const int4* row = reinterpret_cast<const int4*>(members + (size_t)j * VH_K);
 #pragma unroll
         for (int q = 0; q < VH_K / 4; ++q) {
-            int4 r = make_int4(VH_EMPTY, VH_EMPTY, VH_EMPTY, VH_EMPTY);
-            if (4 * q < cnt) r = row[q];
+            int4 r = make_int4(q == 0 ? g : VH_EMPTY, VH_EMPTY, VH_EMPTY, VH_EMPTY);
+            if (4 * q < cnt && cnt > 1) r = row[q];          // (a voxel of one point - four of five in a depth-camera cloud - is that point: its row is never fetched)
             m[4 * q] = 4 * q < cnt ? r.x : VH_EMPTY; m[4 * q + 1] = 4 * q + 1 < cnt ? r.y : VH_EMPTY;
             m[4 * q + 2] = 4 * q + 2 < cnt ? r.z : VH_EMPTY; m[4 * q + 3] = 4 * q + 3 < cnt ? r.w : VH_EMPTY;
         }
