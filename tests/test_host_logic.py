@@ -383,3 +383,17 @@ def test_ransac_bailout_scheme_is_exact_on_simulated_counts():
         want = reference_loop(true, valid, ns, confidence)
         got = bailout_loop(inl, valid, ns, confidence, int(rng.integers(1, 40)), int(rng.integers(1, 120)), int(rng.choice([5, 100, 500])))
         assert got == want, (trial, got, want)
+
+
+def test_every_environment_switch_is_documented():
+    """INTEGRATION.md lists every TDV_* variable the library reads (A/B and study knobs included): a switch nobody can find is a trap."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    knobs = set()
+    for f in glob.glob(os.path.join(root, "3dvision_amd", "csrc", "*.h*")):
+        knobs.update(re.findall(r'getenv\("(TDV_[A-Z0-9_]+)"\)', open(f).read()))
+    assert len(knobs) > 20
+    missing = sorted(k for k in knobs if k not in doc)
+    assert not missing, missing

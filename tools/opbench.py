@@ -147,9 +147,18 @@ def relief_match(ctx, tdv, synth, torch, dev, voxel_px, reps=3):
     for _ in range(reps):
         ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_ix.data_ptr())
     q_ms = ctx.timing_read(tdv.TIMER_FEATURE_MATCH)[0] / reps; b_ms = ctx.timing_read(tdv.TIMER_FM_INDEX)[0] / reps
+    os.environ["TDV_FM_LEAFMAJOR"] = "0"          # round 2's search over the same index (a wave walks its two sources' leaves), for comparison
+    try:
+        ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_ix.data_ptr()); ctx.timing_read(tdv.TIMER_FEATURE_MATCH)
+        for _ in range(reps):
+            ctx.feature_match_dev(d_fs.data_ptr(), ns, d_ft.data_ptr(), nt, d_ix.data_ptr())
+        walk_ms = ctx.timing_read(tdv.TIMER_FEATURE_MATCH)[0] / reps
+    finally:
+        del os.environ["TDV_FM_LEAFMAJOR"]
     ctx.timing_enable(False)
     return [pruned(dict(op="feature_match", workload="%d x %d FPFH descriptors of the relief part (instance vs model), index build included" % (ns, nt), ms=wall,
-                        query_ms=q_ms, index_build_ms=b_ms, note="the batched chain builds the index once per model and pays query_ms per instance"),
+                        query_ms=q_ms, query_ms_round2_walk=walk_ms, index_build_ms=b_ms,
+                        note="leaf-major search (k_lm_*); the batched chain builds the index once per model and pays query_ms per instance"),
                    98.0 * ns * nt, wall, "packed index")]
 
 
