@@ -113,6 +113,39 @@ def test_feature_match_pruned_fuzz(ctx, orc):
         assert np.array_equal(ctx.feature_match(fs, ft), orc.feature_match(fs, ft)), trial
 
 
+def test_feature_match_leaf_major_fuzz(ctx, orc):
+    """The leaf-major index search at sizes with several groups of leaves (its group boxes, the per-pool lists, partly filled
+    waves and work units), against the plain scan on the same device (TDV_FM_BRUTE, itself held against the oracle above and in
+    test_gpu_ransac.py) and, on a sample of the sources, against the oracle; its two-round variant and round 2's walk over the
+    same index return the same correspondences.  Clustered rows, duplicates, non-finite rows, sources far from every target."""
+    import os
+    rng = np.random.default_rng(2025)
+    for trial, (ns, nt, ncl) in enumerate(((4097, 9001, 40), (20011, 16500, 300), (70001, 30000, 1500))):
+        centres = rng.random((ncl, 33)).astype(np.float32)
+        ft = centres[rng.integers(0, ncl, nt)] + rng.normal(0, 2e-2, (nt, 33)).astype(np.float32)
+        fs = centres[rng.integers(0, ncl, ns)] + rng.normal(0, 2e-2, (ns, 33)).astype(np.float32)
+        ft[nt // 2: nt // 2 + 300] = ft[:300]; fs[:200] = ft[nt // 2: nt // 2 + 200]     # duplicated targets: the lower index wins
+        fs[300] = 50.0; fs[301] = -7.0; fs[302, 4] = np.nan; fs[303, 9] = np.inf          # far away / match nothing
+        ft[17, 0] = np.nan; ft[18, 3] = np.inf                                            # never chosen
+        got = {}
+        try:
+            for name, knob, value in (("leaf-major", None, None), ("two rounds", "TDV_LM_ROUNDS", "2"), ("walk", "TDV_FM_LEAFMAJOR", "0"), ("scan", "TDV_FM_BRUTE", "1")):
+                if knob:
+                    os.environ[knob] = value
+                got[name] = ctx.feature_match(fs, ft)
+                if knob:
+                    del os.environ[knob]
+        finally:
+            for knob in ("TDV_LM_ROUNDS", "TDV_FM_LEAFMAJOR", "TDV_FM_BRUTE"):
+                os.environ.pop(knob, None)
+        for name in ("leaf-major", "two rounds", "walk"):
+            assert np.array_equal(got[name], got["scan"]), (trial, name, int((got[name] != got["scan"]).sum()))
+        pick = np.concatenate([np.arange(0, 320), rng.integers(0, ns, 700)])
+        assert np.array_equal(got["leaf-major"][pick], orc.feature_match(fs[pick], ft)), trial
+        low = np.delete(got["leaf-major"][:200], [17, 18])              # (targets 17 and 18 are the non-finite rows: their copies win)
+        assert got["leaf-major"][302] == 0 and got["leaf-major"][303] == 0 and (low < nt // 2).all() and (got["leaf-major"][17:19] >= nt // 2).all()
+
+
 @pytest.mark.parametrize("scale", [1e-4, 1.0, 3e4])
 def test_feature_match_principal_box_margins(ctx, orc, scale):
     """The packed-index search prunes with boxes in the targets' principal coordinates, a bound that is only safe with
