@@ -234,7 +234,9 @@ def main():
     # pass is repeated `regions` times inside ONE barrier/sync bracket; every figure below is per step over all K x regions steps.
     regions = 1
     if args.min_region_ms > 0 and region_est is not None:
-        regions = max(1, int(np.ceil(args.min_region_ms * 1e-3 / max(region_est, 1e-6))))
+        # (the estimate comes from W-step passes, whose per-call overheads weigh more than in a K-step pass: 25 % of margin, so that the
+        #  region does not end up a few milliseconds under the floor)
+        regions = max(1, int(np.ceil(1.25 * args.min_region_ms * 1e-3 / max(region_est, 1e-6))))
     rg = torch.tensor([regions], dtype=torch.int64, device=cdev)
     if distributed:
         dist.all_reduce(rg, op=dist.ReduceOp.MAX)      # same count on every rank
