@@ -1262,7 +1262,7 @@ template <int ROUND>
 __global__ __launch_bounds__(64 * LM_WAVES)
 void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __restrict__ sgroup, LmLists L, unsigned long long* __restrict__ stats) {
     const unsigned long long t_begin = stats ? wall_clock64() : 0ull;
-    unsigned n3 = 0, n33 = 0, nemit = 0; unsigned long long t_flush = 0;
+    unsigned n3 = 0, n33 = 0, nemit = 0;        // (TDV_FM_STATS: 3-D tests, 33-D tests, boxes emitted by this wave)
     __shared__ __attribute__((aligned(16))) float s_box[FX_GROUP * LM_BOX];
     __shared__ int s_leaf[LM_WAVES][LM_ENTRIES];
     __shared__ unsigned long long s_mask[LM_WAVES][LM_ENTRIES];
@@ -1287,7 +1287,7 @@ void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __rest
     const int home = min(t.nleaf - 1, max(0, t.home_of[src])), hg = home / FX_GROUP;
     const float pmargin = 3e-5f * fmaxf(__uint_as_float(__builtin_amdgcn_readfirstlane(*t.amax_t)), __uint_as_float(__builtin_amdgcn_readfirstlane(*t.amax_s)));
     const float bound = __uint_as_float((unsigned)(L.keys[src] >> 32));
-    const unsigned long long t_loaded = stats ? (bound == -1.f ? 1ull : wall_clock64()) : 0ull;
+    const unsigned long long t_loaded = stats ? (bound == -1.f ? 1ull : wall_clock64()) : 0ull;   // (reads `bound`: the clock is taken after the loads have landed)
     int n_ent = 0;
     auto stage = [&](const float* __restrict__ boxes, int count) {     // count boxes -> s_box, by the whole workgroup
         __syncthreads();
@@ -1366,7 +1366,6 @@ void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __rest
         atomicAdd(&stats[0], 1ull); atomicAdd(&stats[1], t_end - t_begin); atomicAdd(&stats[2], t_loaded - t_begin); atomicAdd(&stats[3], t_end - t_f0);
         atomicAdd(&stats[4], (unsigned long long)n3); atomicAdd(&stats[5], (unsigned long long)n33); atomicAdd(&stats[6], (unsigned long long)nemit); atomicMax(&stats[7], t_end - t_begin);
     }
-    (void)t_flush;
 }
 
 // leaf_start / unit_start: exclusive scans of the pair counts and of the unit counts (a unit = up to 64 sources of one leaf).
