@@ -591,6 +591,67 @@ void k_fpfh(const float* __restrict__ xyz, int n, const int* __restrict__ order,
     if (lane < 33) desc[(size_t)i * 33 + lane] = v;
 }
 
+// FPFH with TWO POINTS PER WAVE (round 3; the default): k_fpfh keeps 33 of 64 lanes busy and is bound by issuing its ~7 instructions
+// per neighbour.  Here each half of a wave owns a point - lane l of the half holds bin l, lane 0 also bin 32 - and a step adds one
+// neighbour to BOTH points: the per-neighbour (row offset, weight) pairs of either point are staged in LDS (a lane reads its own
+// half's entry: two addresses per wave), the two 128-byte row segments are one load.  Per bin the sum still runs over the point's
+// neighbours in list order with the same expression (registration.cpp:176-197): the outputs are k_fpfh's bit for bit.
+constexpr int FP2_WAVES = 4;
+__global__ __launch_bounds__(64 * FP2_WAVES)
+void k_fpfh_pairs(const float* __restrict__ xyz, int n, const int* __restrict__ order, const int* __restrict__ nbr,
+                  const int* __restrict__ nbr_cnt, const float* __restrict__ spfh, float* __restrict__ desc,
+                  int* __restrict__ nbr_out /* [n][100] or null */) {
+    __shared__ uint2 s_ent[FP2_WAVES][2][128];                  // (row offset in floats, weight bits) of neighbour r of either point; r >= cnt: (0, +0)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l = lane & 31;
+    const int t0 = (xcd_contiguous_block(blockIdx.x, gridDim.x) * FP2_WAVES + wave) * 2;
+    if (t0 >= n) return;                                          // wave-uniform
+    const int t = min(t0 + half, n - 1);                          // an odd n: the last wave's second half repeats its first (computed, not written)
+    const bool writes = t0 + half < n;
+    const int i = order[t];
+    const float px = xyz[3 * (size_t)i], py = xyz[3 * (size_t)i + 1], pz = xyz[3 * (size_t)i + 2];
+    const int cnt = nbr_cnt[i];
+    uint2* ent = s_ent[wave][half];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = q * 32 + l;
+        const int j = r < cnt ? nbr[(size_t)i * FP_MAXNN + r] : -1;
+        if (nbr_out && writes && r < FP_MAXNN) nbr_out[(size_t)i * FP_MAXNN + r] = j;
+        unsigned off = 0u; float w = 0.f;                         // not to be added (self, a coincident point, past the end): weight +0 on row 0 adds +0
+        if (j >= 0 && j != i) {
+            const float dx = xyz[3 * (size_t)j] - px, dy = xyz[3 * (size_t)j + 1] - py, dz = xyz[3 * (size_t)j + 2] - pz;
+            const float dist = sqrtf(dx * dx + (dy * dy + dz * dz));
+            if (!(dist < 1e-8f)) { off = (unsigned)j * 33u; w = 1.0f / dist; }
+        }
+        ent[r] = make_uint2(off, __float_as_uint(w));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float f = spfh[(size_t)i * 33 + l];
+    float f32 = spfh[(size_t)i * 33 + 32];                        // (every lane of the half carries bin 32; lane 0's copy is the one written)
+    const int steps = max(cnt, __shfl_xor(cnt, 32, 64));          // wave-uniform: the longer of the two lists
+    constexpr int FU = 8;
+    for (int r0 = 0; r0 < steps; r0 += FU) {
+        float val[FU], v32[FU], wr[FU];
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+            const uint2 e = ent[min(r0 + u, 127)];
+            wr[u] = __uint_as_float(e.y);
+            val[u] = spfh[e.x + (unsigned)l];
+            v32[u] = spfh[e.x + 32u];
+        }
+#pragma unroll
+        for (int u = 0; u < FU; ++u) { f = f + wr[u] * val[u]; f32 = f32 + wr[u] * v32[u]; }
+    }
+    float sum = 0.f;
+    for (int b = 0; b < 32; ++b) sum += __shfl(f, half * 32 + b, 64);   // d = 0..32 in order, as the CPU loop
+    sum += f32;
+    const bool norm = sum > 0.f;
+    if (writes) {
+        desc[(size_t)i * 33 + l] = norm ? f / sum : f;
+        if (l == 0) desc[(size_t)i * 33 + 32] = norm ? f32 / sum : f32;
+    }
+}
+
 namespace {
 
 struct ScanPlan { int n_pad, nt_pad, n_chunks, blocks_x; };
@@ -717,7 +778,9 @@ int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, in
     TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
     hipStream_t s = ctx->stream;
     k_spfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
-    k_fpfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
+    const char* pairs_env = getenv("TDV_FPFH_PAIRS");       // A/B knob, read per call: 0 = one point per wave (k_fpfh)
+    if (!(pairs_env && atoi(pairs_env) == 0)) k_fpfh_pairs<<<(n + 2 * FP2_WAVES - 1) / (2 * FP2_WAVES), 64 * FP2_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
+    else k_fpfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
     TDV_CHECK_LAUNCH(ctx);
     if (d_nbr_cnt) TDV_HIP(ctx, hipMemcpyAsync(d_nbr_cnt, cnt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return TDV_OK;
