@@ -591,6 +591,71 @@ void k_fpfh(const float* __restrict__ xyz, int n, const int* __restrict__ order,
     if (lane < 33) desc[(size_t)i * 33 + lane] = v;
 }
 
+// SPFH with TWO POINTS PER WAVE (round 3; the default): k_spfh gives a point's ~81 neighbours two passes of 64 lanes, the second
+// a quarter full.  Here a wave owns two points and lays their neighbour lists end to end over its lanes (three passes for ~162
+// pairs); a lane picks its point's position and normal by its place in the combined list.  Every pair's features are the same
+// expressions as in k_spfh and the histograms are integer counts, so the rows are k_spfh's bit for bit.
+__global__ __launch_bounds__(64 * FP_WAVES)
+void k_spfh_pairs(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, const int* __restrict__ order,
+                  const int* __restrict__ nbr, const int* __restrict__ nbr_cnt, float* __restrict__ spfh) {
+    const int lane = threadIdx.x & 63;
+    const int t0 = (xcd_contiguous_block(blockIdx.x, gridDim.x) * FP_WAVES + (threadIdx.x >> 6)) * 2;
+    if (t0 >= n) return;   // wave-uniform
+    const bool two = t0 + 1 < n;
+    const int iA = __builtin_amdgcn_readfirstlane(order[t0]), iB = __builtin_amdgcn_readfirstlane(order[two ? t0 + 1 : t0]);
+    const int cA = __builtin_amdgcn_readfirstlane(nbr_cnt[iA]), cB = two ? __builtin_amdgcn_readfirstlane(nbr_cnt[iB]) : 0;
+    __shared__ int hist[FP_WAVES][2][64];
+    int (*myhist)[64] = hist[threadIdx.x >> 6];
+    myhist[0][lane] = 0; myhist[1][lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const float pAx = xyz[3 * (size_t)iA], pAy = xyz[3 * (size_t)iA + 1], pAz = xyz[3 * (size_t)iA + 2];
+    const float uAx = nrm[3 * (size_t)iA], uAy = nrm[3 * (size_t)iA + 1], uAz = nrm[3 * (size_t)iA + 2];
+    const float pBx = xyz[3 * (size_t)iB], pBy = xyz[3 * (size_t)iB + 1], pBz = xyz[3 * (size_t)iB + 2];
+    const float uBx = nrm[3 * (size_t)iB], uBy = nrm[3 * (size_t)iB + 1], uBz = nrm[3 * (size_t)iB + 2];
+    const int total = cA + cB;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+        const int c = c0 + lane;
+        const bool sel = c >= cA;                                  // this lane's pair belongs to the second point
+        const int i = sel ? iB : iA, r = sel ? c - cA : c;
+        const float px = sel ? pBx : pAx, py = sel ? pBy : pAy, pz = sel ? pBz : pAz;
+        const float ux = sel ? uBx : uAx, uy = sel ? uBy : uAy, uz = sel ? uBz : uAz;
+        const int j = c < total ? nbr[(size_t)i * FP_MAXNN + r] : i;
+        bool valid = c < total && j != i;
+        int bin_a = 0, bin_p = 0, bin_t = 0;
+        if (valid) {
+            float dx = xyz[3 * (size_t)j] - px, dy = xyz[3 * (size_t)j + 1] - py, dz = xyz[3 * (size_t)j + 2] - pz;
+            float dist = sqrtf(dx * dx + (dy * dy + dz * dz));
+            valid = !(dist < 1e-8f);
+            if (valid) {
+                float ex = dx / dist, ey = dy / dist, ez = dz / dist;
+                float vx = uy * ez - uz * ey, vy = uz * ex - ux * ez, vz = ux * ey - uy * ex;   // v = u x d
+                float wx = uy * vz - uz * vy, wy = uz * vx - ux * vz, wz = ux * vy - uy * vx;   // w = u x v
+                float njx = nrm[3 * (size_t)j], njy = nrm[3 * (size_t)j + 1], njz = nrm[3 * (size_t)j + 2];
+                float alpha = vx * njx + (vy * njy + vz * njz);
+                float phi = ux * ex + (uy * ey + uz * ez);
+                float wn = wx * njx + (wy * njy + wz * njz);
+                float un = ux * njx + (uy * njy + uz * njz);
+                float theta = (float)atan2((double)wn, (double)un);
+                bin_a = min(max((int)((alpha + 1.0f) * 5.5f), 0), 10);
+                bin_p = min(max((int)((phi + 1.0f) * 5.5f), 0), 10);
+                bin_t = min(max((int)(((double)theta / 3.14159265358979323846 + (double)1.0f) * (double)5.5f), 0), 10);
+            }
+        }
+        if (valid) { int* h = myhist[sel ? 1 : 0]; atomicAdd(&h[bin_a], 1); atomicAdd(&h[11 + bin_p], 1); atomicAdd(&h[22 + bin_t], 1); }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (which == 1 && !two) break;
+        const float hv = (float)myhist[which][lane];   // lane b < 33: the count of bin b = the CPU's sum of 1.0f increments
+        float sum = 0.f;
+        for (int b = 0; b < 33; ++b) sum += __shfl(hv, b, 64);
+        float v = hv;
+        if (sum > 0.f) v /= sum;
+        if (lane < 33) spfh[(size_t)(which ? iB : iA) * 33 + lane] = v;
+    }
+}
+
 // FPFH with TWO POINTS PER WAVE (round 3; the default): k_fpfh keeps 33 of 64 lanes busy and is bound by issuing its ~7 instructions
 // per neighbour.  Here each half of a wave owns a point - lane l of the half holds bin l, lane 0 also bin 32 - and a step adds one
 // neighbour to BOTH points: the per-neighbour (row offset, weight) pairs of either point are staged in LDS (a lane reads its own
@@ -777,8 +842,9 @@ int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, in
     float* spfh;
     TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
     hipStream_t s = ctx->stream;
-    k_spfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
-    const char* pairs_env = getenv("TDV_FPFH_PAIRS");       // A/B knob, read per call: 0 = one point per wave (k_fpfh)
+    const char* pairs_env = getenv("TDV_FPFH_PAIRS");       // A/B knob, read per call: 0 = one point per wave (k_spfh, k_fpfh)
+    if (!(pairs_env && atoi(pairs_env) == 0)) k_spfh_pairs<<<(n + 2 * FP_WAVES - 1) / (2 * FP_WAVES), 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
+    else k_spfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
     if (!(pairs_env && atoi(pairs_env) == 0)) k_fpfh_pairs<<<(n + 2 * FP2_WAVES - 1) / (2 * FP2_WAVES), 64 * FP2_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
     else k_fpfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
     TDV_CHECK_LAUNCH(ctx);
