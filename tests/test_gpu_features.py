@@ -66,6 +66,28 @@ def test_fpfh(ctx, orc, synth, n, radius):
     assert np.abs(got_d - ref_d).max() < 0.05
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 65, 1001])
+def test_fpfh_two_points_per_wave_equals_one(ctx, orc, synth, n):
+    """k_spfh_pairs / k_fpfh_pairs (a wave owns two points; the default) against the one-point-per-wave kernels
+    (TDV_FPFH_PAIRS=0): identical descriptors and neighbour lists, bit for bit, for odd and tiny clouds too (a last wave with one
+    point, a cloud of one point: no neighbour but itself), and the neighbour lists are the oracle's."""
+    import os
+    pts = _cloud(synth, max(n, 40))[:n].copy()
+    nrm = orc.estimate_normals(_cloud(synth, max(n, 40)), 30)[:n].copy()
+    out = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["TDV_FPFH_PAIRS"] = mode
+            out[mode] = ctx.compute_fpfh(pts, nrm, 0.02, want_neighbors=True)
+    finally:
+        os.environ.pop("TDV_FPFH_PAIRS", None)
+    for a, b in zip(out["1"], out["0"]):
+        assert a.tobytes() == b.tobytes()
+    ref_d, ref_nb, ref_cnt = orc.compute_fpfh(pts, nrm, 0.02, want_neighbors=True)
+    assert np.array_equal(out["1"][2], ref_cnt) and np.array_equal(out["1"][1], ref_nb)
+    assert np.abs(out["1"][0] - ref_d).max() < 0.05
+
+
 def test_fpfh_demo_model(ctx, orc):
     """Demo model: neighbours at exactly radius = 5*voxel = 5 mm sit on the d2 <= r2 edge."""
     model, _ = orc.demo_model()
