@@ -287,7 +287,7 @@ int tdv_voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* 
  * The RANSAC index stream is seeded per instance exactly as the reference does (mt19937(42) restarted for every
  * ransacRegistration call).  Frames: as tdv_depth_to_cloud_batch_dev (n_frames, frame_of_instance).
  * The call spreads the instances over several lanes (the caller's thread plus helper threads, each with its own stream
- * and workspace owned by the ctx): 4 for large instances, 12 for small ones (under 8,192 points on average), never more than the
+ * and workspace owned by the ctx): 6 for large instances, 12 for small ones (under 8,192 points on average), never more than the
  * host has hardware threads; TDV_BATCH_LANES=n overrides (at most 16).  Stages that do not depend on an instance run once for the
  * whole batch: the clouds (2 launches), the voxels and their reference order (on the device: no leader leaves it) and, for
  * small instances, the descriptor match of all instances' points against the model. */
