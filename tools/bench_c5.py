@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order):
+def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev=None):
+    cdev = cdev or dev                                                 # where the collectives' tensors live (the CPU in a one-GPU rehearsal)
     c5 = importlib.import_module("c5_tray")
     B = args.instances_per_gpu
     wl = c5.build(tdv, synth, ctx, B, dev, order=order, hyps=args.hyps, icp_iters=args.icp_iters, pose_seed=1000 + rank)
@@ -38,8 +39,8 @@ def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order):
     d_mx, d_mn, d_mf, nm = wl["model"]
     pack = torch.cat([d_mx[:nm], d_mn[:nm], d_mf[:nm]], 1).contiguous() if rank == 0 else None
     if world > 1:
-        nmt = torch.tensor([nm if rank == 0 else 0], dtype=torch.int64, device=dev); dist.broadcast(nmt, src=0); nm = int(nmt.item())
-    model = sharding.broadcast_model(pack, nm, dev)
+        nmt = torch.tensor([nm if rank == 0 else 0], dtype=torch.int64, device=cdev); dist.broadcast(nmt, src=0); nm = int(nmt.item())
+    model = sharding.broadcast_model(pack.to(cdev) if pack is not None else None, nm, cdev).to(dev)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3
     wl["model"] = (model[:, 0:3].contiguous(), model[:, 3:6].contiguous(), model[:, 6:39].contiguous(), nm)
@@ -51,13 +52,13 @@ def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order):
     res = c5.run(ctx, wl)
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
-    tt = torch.tensor([t_local], dtype=torch.float64, device=dev)
+    tt = torch.tensor([t_local], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     t1 = time.perf_counter()
     ang = c5.angles(synth, wl, res).astype(np.float32)
     local = np.stack([sharding.encode_result(r["T"], r["fitness"], ang[i], r["coarse_inliers"]) for i, r in enumerate(res)])
-    allres = sharding.gather_results(local, B * world, dev)           # slot 17 carries the angle to the ground truth instead of the rmse
+    allres = sharding.gather_results(local, B * world, cdev)          # slot 17 carries the angle to the ground truth instead of the rmse
     gather_ms = (time.perf_counter() - t1) * 1e3
     ok = True
     if rank == 0:
@@ -95,11 +96,18 @@ def main():
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus and args.gpus != world:
         raise SystemExit("--gpus %d but %d rank(s) joined the job" % (args.gpus, world))
+    # TDV_BENCH_REHEARSE=1 (as in bench.py): on a ONE-GPU box the ranks share GPU 0 and rendezvous over gloo with host tensors, so
+    # that every line of the N > 1 path except RCCL itself has run before a multi-GPU node sees it.  Never the default.
+    rehearse = os.environ.get("TDV_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse: dist.init_process_group("gloo", rank=rank, world_size=world)
+        else: dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     tdv = importlib.import_module("3dvision_amd")
     synth = importlib.import_module("3dvision_amd.synth")
     sharding = importlib.import_module("3dvision_amd.sharding")
@@ -107,7 +115,7 @@ def main():
     ctx = tdv.Context(local_rank)
     order = tdv.TDV_VOXEL_ORDER_REFERENCE
     if args.workload == "tray":
-        return tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order)
+        return tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev)
 
     n_total = args.instances_per_gpu * world
     a, b = sharding.shard_range(n_total, world, rank)
