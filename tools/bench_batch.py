@@ -119,6 +119,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     res = [r for part in results for r in part]
+    rescore = ctx.last_ransac_rescore()   # share of the (wave, chunk) pairs the last RANSAC call on the caller's lane scored again exactly
     names = ["icp_nn", "ransac_score", "feature_match", "knn_scan", "radius_scan", "depth", "voxel"]
     stage = {n: ctx.timing_read(i)[0] / B for i, n in enumerate(names)}
     err = [synth.pose_error(r["T"], T) for r, T in zip(res, wl["T_gt"])]
@@ -133,7 +134,7 @@ def main():
                model_points=nm, hyps_per_instance=args.hyps, icp_max_iterations=args.icp_iters, icp_distance_factor=args.icp_factor,
                wall_s=dt, instances_per_s=B / dt, ms_per_instance=dt / B * 1e3,
                ransac_hyps_per_s=B * args.hyps / dt, icp_iterations_run=icp_total, icp_iterations_per_instance=icp_total / B,
-               icp_iters_per_s=icp_total / dt, kernel_ms_per_instance=stage,
+               icp_iters_per_s=icp_total / dt, kernel_ms_per_instance=stage, ransac_rescore_share_last_call=rescore,
                coarse_fitness=dict(min=float(min(r["coarse_fitness"] for r in res)), mean=float(np.mean([r["coarse_fitness"] for r in res]))),
                icp_fitness=dict(min=float(min(r["fitness"] for r in res)), mean=float(np.mean([r["fitness"] for r in res]))),
                angle_to_gt_rad=dict(max=float(ang.max()), mean=float(ang.mean())), translation_to_gt_m=dict(max=float(tr.max()), mean=float(tr.mean())),
