@@ -642,7 +642,9 @@ static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float*
     TDV_TRY(ws_alloc(ctx, (size_t)total, &voxel_of));
     TDV_HIP(ctx, hipMemsetAsync(fill, 0x7f, n_fill * 4, s));
     k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vcnt, members, voxel_of, overflow);
-    static const int split_from = getenv("TDV_VOXEL_SPLIT_FROM") ? atoi(getenv("TDV_VOXEL_SPLIT_FROM")) : 2048;   // tiles; tuning knob
+    // (measured, us per call one pass / split: 184k points in pixel order 65 / 76; random order 250k 82 / 74, 500k 138 / 103, 1M 233 / 160, 4M 858 / 550;
+    //  256 clouds of 184k 8,100 / 4,400 - tools/studies/voxel_split_threshold.py)
+    static const int split_from = getenv("TDV_VOXEL_SPLIT_FROM") ? atoi(getenv("TDV_VOXEL_SPLIT_FROM")) : 224;   // tiles; tuning knob
     if (tiles < split_from)
         k_vh_finalize<0><<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vcnt, members, desc, ticket,
                                                     d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, nullptr, nullptr);
