@@ -1138,7 +1138,11 @@ void k_fm_query_overflow(FmTables t, const int* __restrict__ overflow_count, con
 // (50 us / 45 us); two rounds of box tests (home groups first) 9.7 instead of 12.1 pairs per source but 0.525 instead of
 // 0.487 ms; two sources per lane in k_lm_eval (half the LDS reads) and the next group's boxes prefetched into registers: no gain.
 constexpr int LM_BOX = 72;        // floats per box as this search stores them: min[33] | max[33] | pmin[3] | pmax[3]
-constexpr int LM_WAVES = 4;       // waves per workgroup
+constexpr int LM_WAVES = 4;       // waves per workgroup of the evaluation
+#ifndef LM_BOX_WAVES_VALUE
+#define LM_BOX_WAVES_VALUE 4
+#endif
+constexpr int LM_BOX_WAVES = LM_BOX_WAVES_VALUE;   // waves that share the 64 sources of a box-test workgroup (query at 143k x 151k with 1 / 2 / 4 / 8: 0.67 / 0.55 / 0.49 / 0.55-0.63 ms)
 constexpr int LM_ENTRIES = 96;    // (leaf, lane mask) entries a wave buffers in LDS before it reserves room for them in its pool
 constexpr int LM_PAIRS_PER_SOURCE = 32;
 constexpr int LM_POOLS = 64;
@@ -1252,20 +1256,20 @@ __device__ __forceinline__ float lm_bound33(const float* box, const LmSrc& q) {
     return lb;
 }
 
-// Rounds 1 and 2: box tests.  A WORKGROUP = 64 sources in home-leaf order (lane = source in each of its LM_WAVES waves); the
+// Rounds 1 and 2: box tests.  A WORKGROUP = 64 sources in home-leaf order (lane = source in each of its LM_BOX_WAVES waves); the
 // boxes of a group are staged in LDS by the whole workgroup and its waves share the leaves between them (leaf i of the group
-// goes to wave i % LM_WAVES).  (First version: one wave per 64 sources, boxes through the scalar path - a chain of dependent
+// goes to wave i % LM_BOX_WAVES).  (First version: one wave per 64 sources, boxes through the scalar path - a chain of dependent
 // scalar loads with two waves per SIMD: 267 us for what is 20 us of instructions.)
 // ROUND 1: the leaves of the workgroup's home group(s); ROUND 2: every other group, group boxes first.  The four waves hold the
 // same sources, so every mask that steers the staging is the same in all of them: the barriers are reached together.
 template <int ROUND>
-__global__ __launch_bounds__(64 * LM_WAVES)
+__global__ __launch_bounds__(64 * LM_BOX_WAVES)
 void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __restrict__ sgroup, LmLists L, unsigned long long* __restrict__ stats) {
     const unsigned long long t_begin = stats ? wall_clock64() : 0ull;
     unsigned n3 = 0, n33 = 0, nemit = 0;        // (TDV_FM_STATS: 3-D tests, 33-D tests, boxes emitted by this wave)
     __shared__ __attribute__((aligned(16))) float s_box[FX_GROUP * LM_BOX];
-    __shared__ int s_leaf[LM_WAVES][LM_ENTRIES];
-    __shared__ unsigned long long s_mask[LM_WAVES][LM_ENTRIES];
+    __shared__ int s_leaf[LM_BOX_WAVES][LM_ENTRIES];
+    __shared__ unsigned long long s_mask[LM_BOX_WAVES][LM_ENTRIES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int s0 = blockIdx.x * 64;
     if (s0 >= t.ns) return;
@@ -1274,9 +1278,11 @@ void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __rest
     LmSrc q;
     {   // the workgroup's 64 descriptors: rows in (four threads per 132-B row), through LDS, a lane's own row out
         constexpr int PITCH = FD + 4;                            // 37 floats: a lane reading its row meets no bank twice
-        const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
-        const float* __restrict__ row = t.fs + (size_t)t.sperm[min(s0 + r, t.ns - 1)] * FD;
-        for (int d = part; d < FD; d += 4) s_box[r * PITCH + d] = row[d];
+        const int part = threadIdx.x & 3;
+        for (int r = threadIdx.x >> 2; r < 64; r += (64 * LM_BOX_WAVES) >> 2) {
+            const float* __restrict__ row = t.fs + (size_t)t.sperm[min(s0 + r, t.ns - 1)] * FD;
+            for (int d = part; d < FD; d += 4) s_box[r * PITCH + d] = row[d];
+        }
         __syncthreads();
 #pragma unroll
         for (int d = 0; d < FD; ++d) { if (d & 1) q.p[d >> 1].y = s_box[lane * PITCH + d]; else q.p[d >> 1].x = s_box[lane * PITCH + d]; }
@@ -1293,12 +1299,12 @@ void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __rest
         __syncthreads();
         const float4* __restrict__ from = reinterpret_cast<const float4*>(boxes);
         float4* to = reinterpret_cast<float4*>(s_box);
-        for (int e = threadIdx.x; e < count * (LM_BOX / 4); e += 64 * LM_WAVES) to[e] = from[e];
+        for (int e = threadIdx.x; e < count * (LM_BOX / 4); e += 64 * LM_BOX_WAVES) to[e] = from[e];
         __syncthreads();
     };
     auto flush = [&]() {
         if (n_ent == 0) return;
-        const int pool = (blockIdx.x * LM_WAVES + wave) % LM_POOLS;
+        const int pool = (blockIdx.x * LM_BOX_WAVES + wave) % LM_POOLS;
         int base = 0;
         if (lane == 0) base = atomicAdd(L.entry_cursor + pool, n_ent);
         __builtin_amdgcn_wave_barrier();
@@ -1317,7 +1323,7 @@ void k_lm_boxes(FmTables t, const float* __restrict__ sleaf, const float* __rest
     auto leaves_of_group = [&](int g) {
         const int l0 = g * FX_GROUP, cnt = min(FX_GROUP, t.nleaf - l0);
         stage(sleaf + (size_t)l0 * LM_BOX, cnt);
-        for (int i = wave; i < cnt; i += LM_WAVES) {
+        for (int i = wave; i < cnt; i += LM_BOX_WAVES) {
             const int l = l0 + i;
             const float* box = s_box + i * LM_BOX;
             const bool p3 = lm_pass3(box, q, pmargin, t.pscale, bound);
@@ -1805,9 +1811,9 @@ static int launch_fm_leafmajor(tdv_ctx* ctx, const FmTables& t, const FmIndex& i
     k_lm_plan<false><<<1, 1024, 0, s>>>(L[0], nleaf);
     k_lm_eval<true><<<eval_blocks, 64 * LM_WAVES, 0, s>>>(t, L[0]);
     for (int r = 1; r <= rounds; ++r) {
-        if (rounds == 1 && ix.ngroup > 1) k_lm_boxes<3><<<waves, 64 * LM_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats);
-        else if (r == 1) k_lm_boxes<1><<<waves, 64 * LM_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats);
-        else k_lm_boxes<2><<<waves, 64 * LM_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats ? d_stats + 8 : nullptr);
+        if (rounds == 1 && ix.ngroup > 1) k_lm_boxes<3><<<waves, 64 * LM_BOX_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats);
+        else if (r == 1) k_lm_boxes<1><<<waves, 64 * LM_BOX_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats);
+        else k_lm_boxes<2><<<waves, 64 * LM_BOX_WAVES, 0, s>>>(t, ix.sleaf, ix.sgroup, L[r], d_stats ? d_stats + 8 : nullptr);
         k_lm_plan<true><<<1, 1024, 0, s>>>(L[r], nleaf);
         k_lm_scatter<<<LM_POOLS, 1024, (size_t)nleaf * 4, s>>>(L[r], nleaf);
         k_lm_eval<false><<<eval_blocks, 64 * LM_WAVES, 0, s>>>(t, L[r]);
