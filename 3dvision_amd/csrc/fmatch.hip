@@ -1803,7 +1803,7 @@ static int launch_fm_leafmajor(tdv_ctx* ctx, const FmTables& t, const FmIndex& i
     L[0] = LmLists{nullptr, nullptr, zeroed + 2 * per_round, home_hist, nullptr, nullptr, 0, INT_MAX, leaf_start, unit_start, unit_leaf, const_cast<int*>(t.sperm), keys};
     unsigned long long* d_stats = nullptr;
     if (getenv("TDV_FM_STATS")) { TDV_TRY(ws_alloc(ctx, 16, &d_stats)); TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, s)); }
-    static const int eval_blocks = getenv("TDV_LM_EVAL_BLOCKS") ? atoi(getenv("TDV_LM_EVAL_BLOCKS")) : 2048;   // tuning knob (a multiple of 8)
+    static const int eval_blocks = getenv("TDV_LM_EVAL_BLOCKS") ? atoi(getenv("TDV_LM_EVAL_BLOCKS")) : 4096;   // tuning knob (a multiple of 8; 1024 / 2048 / 4096 / 8192: 0.51 / 0.49 / 0.477 / 0.478 ms at 143k x 151k)
     // One round of box tests after the home leaves (12.1 pairs per source at 143k x 151k).  TDV_LM_ROUNDS=2: the home groups first, the
     // other groups with the bounds those left (9.7 pairs per source, but a second set of launches: 0.525 against 0.487 ms).
     const char* rounds_env = getenv("TDV_LM_ROUNDS");
