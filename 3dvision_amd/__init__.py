@@ -42,7 +42,7 @@ DEPTH_BATCH_MASK_PASSES = 1   # the B masks cross HBM once in tdv_depth_to_cloud
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [
-    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_last_icp_search", "tdv_ctx_workspace_bytes", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_set_icp_accumulation", "tdv_ctx_last_icp_search", "tdv_ctx_workspace_bytes", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
@@ -201,6 +201,12 @@ class Context:
         with cells of 2.2 x the threshold; falls back to 'pruned' when the threshold is large against the spacing); same results."""
         _check(self._h, lib().tdv_ctx_set_icp_search(self._h, self.ICP_SEARCH[mode]), "tdv_ctx_set_icp_search")
         self.icp_search_name = mode
+
+    def set_icp_accumulation(self, mode):
+        """'tree' (default: f64 sums in a fixed tree, transform within tolerance of the CPU path) or 'reference' (f32 sums in
+        ascending source index as registration.cpp:340-358,374-386: transform, rmse, fitness and iteration count equal the
+        CPU path's bit for bit; a serial chain per iteration)."""
+        _check(self._h, lib().tdv_ctx_set_icp_accumulation(self._h, {"tree": 0, "reference": 1}[mode]), "tdv_ctx_set_icp_accumulation")
 
     def set_ransac_score(self, mode):
         """'fast' (default: FMA pass, chunks inside the rounding band re-scored with the reference arithmetic) or 'exact'

@@ -238,7 +238,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         std::vector<std::thread> workers;
         for (int l = 1; l < L; ++l) {
             tdv_ctx* h = lane_ctx[l];
-            h->timing = ctx->timing; h->icp_search = ctx->icp_search; h->ransac_score_mode = ctx->ransac_score_mode; h->err[0] = 0;
+            h->timing = ctx->timing; h->icp_search = ctx->icp_search; h->icp_accumulate = ctx->icp_accumulate; h->ransac_score_mode = ctx->ransac_score_mode; h->err[0] = 0;
             workers.emplace_back([&, h, l]() {
                 try {
                     if (hipSetDevice(h->device) != hipSuccess) { status[l] = TDV_ERR_NO_DEVICE; return; }

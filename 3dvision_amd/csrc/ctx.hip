@@ -203,7 +203,16 @@ int tdv_ctx_create(int device, tdv_ctx** out) {
         else if (!strcmp(e, "pruned")) c->icp_search = TDV_ICP_SEARCH_PRUNED;
         else if (!strcmp(e, "grid")) c->icp_search = TDV_ICP_SEARCH_GRID;
     }
+    if (const char* e = getenv("TDV_ICP_ACCUMULATE")) {
+        if (!strcmp(e, "reference")) c->icp_accumulate = TDV_ICP_ACCUMULATE_REFERENCE;
+    }
     *out = c;
+    return TDV_OK;
+}
+
+int tdv_ctx_set_icp_accumulation(tdv_ctx* ctx, int mode) {
+    if (!ctx || (mode != TDV_ICP_ACCUMULATE_TREE && mode != TDV_ICP_ACCUMULATE_REFERENCE)) return TDV_ERR_BAD_ARG;
+    ctx->icp_accumulate = mode;
     return TDV_OK;
 }
 

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include "libm_f32.hpp"
 
 namespace tdv {
 namespace dl {
@@ -408,11 +409,13 @@ __device__ __forceinline__ void ldlt6_solve(const float* Ain, const float* b, fl
     ldlt6_solve(Ain, b, x);
 }
 
-// Rx(a) * Ry(b) * Rz(g) through quaternions.
+// Rx(a) * Ry(b) * Rz(g) through quaternions.  The half-angle sines and cosines are glibc's sinf / cosf (libm_f32.hpp), the
+// functions the reference's AngleAxisf -> Quaternionf conversion calls on the host: the update rotation, and with it the
+// refined transform, can then equal the CPU path's bit for bit.
 __device__ inline Mat3 euler_xyz(float a, float b, float g) {
-    float qxw = cosf(0.5f * a), qxx = sinf(0.5f * a);
-    float qyw = cosf(0.5f * b), qyy = sinf(0.5f * b);
-    float qzw = cosf(0.5f * g), qzz = sinf(0.5f * g);
+    float qxw = lm::cosf_glibc(0.5f * a), qxx = lm::sinf_glibc(0.5f * a);
+    float qyw = lm::cosf_glibc(0.5f * b), qyy = lm::sinf_glibc(0.5f * b);
+    float qzw = lm::cosf_glibc(0.5f * g), qzz = lm::sinf_glibc(0.5f * g);
     // q1 = qx * qy  (qx = (w,x,0,0), qy = (w,0,y,0))
     float w1 = qxw * qyw - qxx * 0.f - 0.f * qyy - 0.f * 0.f;
     float x1 = qxw * 0.f + qxx * qyw + 0.f * 0.f - 0.f * qyy;

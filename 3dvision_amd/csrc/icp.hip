@@ -411,7 +411,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // The update of one iteration from the folded sums tot[] (thread 0 of the folding block): registration.cpp:361-411.
 // (iter, prev_rmse, Tcur: the state as the kernel read it at its start - no other launch writes it in between - so that the
 // tail of the iteration does not begin with another round trip to memory)
-template <int MODE>
+// REF (reference-order accumulation, below): tot[] holds float sums; in point-to-point mode tot[2..4] / tot[5..7] are the two
+// MEANS (already divided, registration.cpp:380-381) and tot[8..16] the centred cross-covariance of :383-386.
+template <int MODE, bool REF = false>
 __device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_iterations, int iter, float prev_rmse, const float* Tcur, float* solve_ws /* LDS, 54 words */) {
     const int n_corr = (int)(tot[0] + 0.5);
     st->iter = iter + 1;
@@ -435,11 +437,12 @@ __device__ void icp_update(const double* tot, int ns, IcpState* st, int fixed_it
         delta[12] = x[3]; delta[13] = x[4]; delta[14] = x[5];
     } else {
         const double n = (double)n_corr;
-        double sm[3] = {tot[2] / n, tot[3] / n, tot[4] / n};
-        double tm[3] = {tot[5] / n, tot[6] / n, tot[7] / n};
+        double sm[3] = {tot[2], tot[3], tot[4]};
+        double tm[3] = {tot[5], tot[6], tot[7]};
+        if (!REF) for (int a = 0; a < 3; ++a) { sm[a] /= n; tm[a] /= n; }
         dl::Mat3 H;
         for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) dl::el(H, a, b) = (float)(tot[8 + a * 3 + b] - n * sm[a] * tm[b]);
+            for (int b = 0; b < 3; ++b) dl::el(H, a, b) = REF ? (float)tot[8 + a * 3 + b] : (float)(tot[8 + a * 3 + b] - n * sm[a] * tm[b]);
         dl::Mat3 dR = dl::kabsch_rotation(H);
         float smf[3] = {(float)sm[0], (float)sm[1], (float)sm[2]};
         float tmf[3] = {(float)tm[0], (float)tm[1], (float)tm[2]};
@@ -600,6 +603,184 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
     }
 }
 
+// ---- reference-order accumulation (round 4; TDV_ICP_ACCUMULATE_REFERENCE) ------------------------------------------------
+// The CPU path adds every accepted correspondence to its sums one after the other, in float, in ascending source index
+// (/root/reference/src/registration.cpp:340-341 n_corr and total_error, :353-354 ATA and ATb; point-to-point: the two means
+// :376-381, then the centred cross-covariance :383-386).  A float sum depends on its order, so the f64 tree above agrees with
+// it to ~1e-7 only - which once moved a translation by 1.27e-6 m on a 5-iteration C5 instance (round 3's log) and could, in
+// principle, flip the stopping rule |delta rmse| < 1e-6 (:406).  In this mode the sums ARE the reference's, bit for bit:
+//   k_icp_rows   one lane per source point evaluates its terms (the same expressions as k_icp_accumulate: J = [p x n | n],
+//                r = (p - q).n, products unfused) and stores them as ROWS, one row per accumulator: rows[k][i], zero where
+//                the point is not accepted (s + 0 == s for every float s a sum started at +0 can hold: it is never -0).
+//                The accepted COUNT is an integer and needs no order: ballot + one atomicAdd per wave.
+//   k_icp_fold_ref  ONE workgroup: lane k of wave 0 owns accumulator k and adds row k's entries in index order - a chain of
+//                n dependent v_add_f32, which is what "the reference's rounding" means; nothing shortens it.  All 16 waves
+//                stage the rows through LDS (global -> registers one tile ahead -> LDS, double buffered) so that the chain never
+//                waits for memory: per point it costs one add and a quarter of a 16-byte LDS read.  Then the same
+//                one-thread solve / update / stopping rule as the tree mode, on float sums.
+// Cost: the chain, ~n x 5-6 cycles (200k points: ~0.5 ms per iteration against 25 us for the tree) - a parity mode, selectable
+// per ctx like the search; the tree stays the default.
+constexpr int REF_NR_PLANE = 28;     // rows, point-to-plane: d2, 21 upper-triangular J^T J, 6 J^T r
+constexpr int REF_NR_POINT = 8;      // rows, point-to-point: d2, p.xyz, q.xyz, accepted (1 / 0)
+constexpr int REF_TILE = 512;        // points per LDS tile
+constexpr int REF_LD = REF_TILE + 4; // row pitch in LDS (floats): lane k's 16-byte reads start 4 banks after lane k-1's
+
+// the terms of one source point (zeros unless accepted)
+template <int MODE>
+__device__ __forceinline__ void ref_terms(bool acc, float best, float px, float py, float pz,
+                                          const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int idx,
+                                          float (&v)[MODE == 0 ? REF_NR_PLANE : REF_NR_POINT]) {
+    constexpr int NR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) v[k] = 0.f;
+    if (!acc) return;
+    v[0] = best;
+    const float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
+    if (MODE == 0) {
+        const float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
+        const float J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+        const float ex = px - qx, ey = py - qy, ez = pz - qz;
+        const float r = ex * nx + (ey * ny + ez * nz);
+        int k = 1;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) v[k++] = J[a] * J[b];       // J[b] * J[a] is the same float: ATA stays symmetric bit for bit
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[k++] = J[a] * r;
+    } else {
+        v[1] = px; v[2] = py; v[3] = pz; v[4] = qx; v[5] = qy; v[6] = qz; v[7] = 1.f;
+    }
+}
+
+// rows[k][i] for i < row_pitch (a multiple of 256; entries from ns on are zero); *count += accepted points
+template <int MODE>
+__global__ __launch_bounds__(256)
+void k_icp_rows(const float* __restrict__ src, int ns, int ns_pad, int row_pitch,
+                const float* __restrict__ tgt, const float* __restrict__ tgt_normals,
+                const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk, int direct,
+                const IcpState* __restrict__ st, float tau_accept, float* __restrict__ rows, int* __restrict__ count) {
+    if (st->done) return;
+    constexpr int NR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
+    const int i = blockIdx.x * 256 + threadIdx.x;      // < row_pitch by the launch
+    float v[NR];
+    bool acc = false;
+    if (i < ns) {
+        float px, py, pz;
+        transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+        float best = FLT_MAX; int bc = 0;
+        for (int s = 0; s < nsplit; ++s) {
+            const float d = pd2[(size_t)s * ns_pad + i];
+            const int c = pchunk[(size_t)s * ns_pad + i];
+            if (d < best) { best = d; bc = c; }
+        }
+        int idx = 0;
+        if (direct) idx = bc;
+        else if (best < FLT_MAX) {
+            idx = bc;
+#pragma unroll
+            for (int t = NN_CH - 1; t >= 0; --t) {
+                const float dx = px - tx[bc + t], dy = py - ty[bc + t], dz = pz - tz[bc + t];
+                if (dx * dx + (dy * dy + dz * dz) == best) idx = bc + t;
+            }
+        }
+        acc = best <= tau_accept;
+        ref_terms<MODE>(acc, best, px, py, pz, tgt, tgt_normals, idx, v);
+    } else {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) v[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rows[(size_t)k * row_pitch + i] = v[k];
+    const unsigned long long m = __ballot(acc);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+
+// lane's running sum += the entries [0, m) of its LDS row, in order (m a multiple of 4)
+__device__ __forceinline__ float ref_chain(float s, const float* __restrict__ row, int m) {
+    const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
+    int q = 0;
+    for (; q + 8 <= m / 4; q += 8) {
+        float4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = r4[q + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s += a[j].x; s += a[j].y; s += a[j].z; s += a[j].w; }
+    }
+    for (; q < m / 4; ++q) { const float4 a = r4[q]; s += a.x; s += a.y; s += a.z; s += a.w; }
+    return s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024)
+void k_icp_fold_ref(const float* __restrict__ rows, int ns, int row_pitch, int* count, IcpState* st, int fixed_iterations) {
+    if (st->done) return;
+    constexpr int NR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
+    constexpr int F4_PER_TILE = NR * REF_TILE / 4;
+    constexpr int PER = (F4_PER_TILE + 1023) / 1024;
+    __shared__ __attribute__((aligned(16))) float buf[2][NR][REF_LD];
+    __shared__ double tot[ACC_NV];
+    __shared__ float means[6];
+    __shared__ float solve_ws[56];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ntiles = (ns + REF_TILE - 1) / REF_TILE;
+    float4 reg[PER];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = threadIdx.x + q * 1024;
+            const int row = e / (REF_TILE / 4), c = (e % (REF_TILE / 4)) * 4;
+            const int p = t * REF_TILE + c;
+            reg[q] = (e < F4_PER_TILE && p < row_pitch) ? *reinterpret_cast<const float4*>(rows + (size_t)row * row_pitch + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int b) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = threadIdx.x + q * 1024;
+            const int row = e / (REF_TILE / 4), c = (e % (REF_TILE / 4)) * 4;
+            if (e < F4_PER_TILE) *reinterpret_cast<float4*>(&buf[b][row][c]) = reg[q];
+        }
+    };
+    if (threadIdx.x < ACC_NV) tot[threadIdx.x] = 0.0;
+    const int n_corr = *count;
+    // pass 0: the plain sums (point-to-plane: all 28; point-to-point: d2, p, q).  pass 1 (point-to-point only): the centred products.
+    constexpr int NPASS = MODE == 0 ? 1 : 2;
+    for (int pass = 0; pass < NPASS; ++pass) {
+        const int nsum = MODE == 0 ? REF_NR_PLANE : (pass == 0 ? 7 : 9);
+        float s = 0.f;
+        float ma = 0.f, mb = 0.f; int ra = 0, rb = 0;
+        if (MODE == 1 && pass == 1) { ra = 1 + lane / 3; rb = 4 + lane % 3; if (lane < 9) { ma = means[lane / 3]; mb = means[3 + lane % 3]; } }
+        gload(0); lstore(0);
+        __syncthreads();
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + 1 < ntiles) gload(t + 1);
+            if (wave == 0 && lane < nsum) {
+                const int m = (min(REF_TILE, ns - t * REF_TILE) + 3) & ~3;
+                if (MODE == 0 || pass == 0) s = ref_chain(s, buf[t & 1][lane], m);
+                else {
+                    const float* __restrict__ A = buf[t & 1][ra]; const float* __restrict__ B = buf[t & 1][rb]; const float* __restrict__ F = buf[t & 1][7];
+                    for (int q = 0; q < m; ++q) { const float term = (A[q] - ma) * (B[q] - mb); s += F[q] != 0.f ? term : 0.f; }     // registration.cpp:385
+                }
+            }
+            if (t + 1 < ntiles) lstore((t + 1) & 1);
+            __syncthreads();
+        }
+        if (wave == 0 && lane < nsum) {
+            if (MODE == 0) tot[1 + lane] = (double)s;
+            else if (pass == 0) { if (lane == 0) tot[1] = (double)s; else means[lane - 1] = s / static_cast<float>(n_corr); }    // :380-381 (n_corr == 0: unused below)
+            else tot[8 + lane] = (double)s;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    *count = 0;      // ready for the next iteration's k_icp_rows (stream order)
+    tot[0] = (double)n_corr;
+    if (MODE == 1) for (int a = 0; a < 6; ++a) tot[2 + a] = (double)means[a];
+    icp_update<MODE, true>(tot, ns, st, fixed_iterations, st->iter, st->rmse, st->T, solve_ws);
+}
+
 // ---- the whole loop in ONE launch, for small problems (round 3) ----------------------------------------------------------
 // A 400 x 400 instance (config C5's size) spent 13 iterations' worth of launches - two per iteration, each 9-12 us of pure
 // latency - and a state read-back per burst: 140 us of an instance's 340 us of kernels.  Here one workgroup of 16 waves keeps
@@ -615,9 +796,8 @@ constexpr long long SM_MAX_PAIRS_SINGLE = 1ll << 18;    // ... in a single call 
 constexpr long long SM_MAX_PAIRS_BATCH = 1ll << 20;     // ... per problem of a batch
 // A grid of several workgroups runs one problem each (the batch's small instances against the shared model): problem b takes the
 // source points [src_off[b], src_off[b + 1]) of src0 and the states st_in[b] / st_out[b]; src_off == nullptr: one problem.
-// Two shapes: 1,024 lanes and room for 2,048 x 2,048 points (the default), or 256 lanes and 1,024 x 1,024 - a quarter of the LDS and
-// of the wave slots, so that more problems of a batch run at once (an A/B variant: measured slower, see icp_small_batch_dev).
-template <int MODE, int SM_THREADS, int SM_CAP>
+// 1,024 lanes and room for 2,048 x 2,048 points.
+template <int MODE, int SM_THREADS, int SM_CAP, bool REF = false>   // REF: reference-order accumulation (see k_icp_fold_ref), tile by tile in LDS
 __global__ __launch_bounds__(SM_THREADS)
 void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict__ src_off, const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int nt,
                  const IcpState* __restrict__ st_in0, float tau_accept, int max_iterations, int fixed_iterations,
@@ -637,6 +817,10 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
     __shared__ double tot[ACC_NV];
     __shared__ float solve_ws[56];
     __shared__ IcpState st;
+    constexpr int NRR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
+    __shared__ __attribute__((aligned(16))) float rrows[REF ? NRR : 1][REF ? REF_LD : 4];
+    __shared__ float rmeans[6];
+    static_assert(!REF || SM_THREADS >= REF_TILE, "one point per thread and tile");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt4 = (nt + 3) / 4;                          // targets in chunks of four, the last one padded with +inf (never a minimum)
     for (int j = threadIdx.x; j < nt4 * 4; j += SM_THREADS) {
@@ -687,6 +871,62 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
             sbest[i] = best; sidx[i] = best < FLT_MAX ? bi : 0;
         }
         __syncthreads();
+        if constexpr (REF) {
+            // (b') the reference's sums: tiles of REF_TILE points - every thread writes its point's terms as LDS rows, lane k of wave 0
+            // adds row k in index order (k_icp_fold_ref's chain; the tile loop continues it from tile to tile)
+            int n_acc = 0;
+            constexpr int NPASS = MODE == 0 ? 1 : 2;
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int nsum = MODE == 0 ? REF_NR_PLANE : (pass == 0 ? 7 : 9);
+                float s = 0.f, ma = 0.f, mb = 0.f;
+                const int ra = 1 + (lane % 9) / 3, rb = 4 + lane % 3;
+                if (MODE == 1 && pass == 1 && lane < 9) { ma = rmeans[lane / 3]; mb = rmeans[3 + lane % 3]; }
+                for (int base = 0; base < ns; base += REF_TILE) {
+                    bool acc = false;
+                    if (threadIdx.x < REF_TILE) {
+                        const int i = base + threadIdx.x;
+                        float v[NRR];
+                        if (i < ns) {
+                            float px, py, pz;
+                            transform_point(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+                            const float best = sbest[i];
+                            acc = best <= tau_accept;
+                            ref_terms<MODE>(acc, best, px, py, pz, tgt, tgt_normals, sidx[i], v);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NRR; ++k) v[k] = 0.f;
+                        }
+#pragma unroll
+                        for (int k = 0; k < NRR; ++k) rrows[k][threadIdx.x] = v[k];
+                    }
+                    const int c = __syncthreads_count(acc);
+                    if (pass == 0) n_acc += c;
+                    if (wave == 0 && lane < nsum) {
+                        const int m = (min(REF_TILE, ns - base) + 3) & ~3;
+                        if (MODE == 0 || pass == 0) s = ref_chain(s, rrows[lane], m);
+                        else {
+                            const float* __restrict__ A = rrows[ra]; const float* __restrict__ Bq = rrows[rb]; const float* __restrict__ F = rrows[7];
+                            for (int q = 0; q < m; ++q) { const float term = (A[q] - ma) * (Bq[q] - mb); s += F[q] != 0.f ? term : 0.f; }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (wave == 0 && lane < nsum) {
+                    if (MODE == 0) tot[1 + lane] = (double)s;
+                    else if (pass == 0) { if (lane == 0) tot[1] = (double)s; else rmeans[lane - 1] = s / static_cast<float>(n_acc); }
+                    else tot[8 + lane] = (double)s;
+                }
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                tot[0] = (double)n_acc;
+                if (MODE == 1) for (int a = 0; a < 6; ++a) tot[2 + a] = (double)rmeans[a];
+                icp_update<MODE, true>(tot, ns, &st, fixed_iterations, iter0, rmse0, T, solve_ws);
+            }
+            __syncthreads();
+            if (st.done) break;
+            continue;
+        }
         // (b) slabs: virtual block B = points [256 B, 256 B + 256), one point per lane
         for (int B0 = 0; B0 < nblocks; B0 += SM_THREADS / 256) {
             const int B = B0 + (threadIdx.x >> 8);
@@ -860,6 +1100,7 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     NnPlan p = make_plan(ns, nt);
     if (pruned) p.nsplit = 1;
     else if (!getenv("TDV_ICP_PPT")) { p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256; }   // measured: 50k x 10k brute 7.6k vs 6.4k iters/s
+    const bool ref_acc = ctx->icp_accumulate == TDV_ICP_ACCUMULATE_REFERENCE;
     TDV_TRY(pin_reserve(ctx, 2 * sizeof(IcpState)));
     IcpState* h = reinterpret_cast<IcpState*>(ctx->pin);
     std::memset(h, 0, sizeof(IcpState));
@@ -878,10 +1119,13 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
         TDV_HIP(ctx, hipMemcpyAsync(d_st, h, sizeof(IcpState), hipMemcpyHostToDevice, s));
         {
             ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
-            if (point_to_plane && d_tgt_normals)
-                k_icp_small<0, 1024, SM_MAX_N><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
-            else
-                k_icp_small<1, 1024, SM_MAX_N><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+            if (point_to_plane && d_tgt_normals) {
+                if (ref_acc) k_icp_small<0, 1024, SM_MAX_N, true><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+                else k_icp_small<0, 1024, SM_MAX_N><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+            } else {
+                if (ref_acc) k_icp_small<1, 1024, SM_MAX_N, true><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+                else k_icp_small<1, 1024, SM_MAX_N><<<1, 1024, 0, s>>>(d_src, ns, nullptr, d_tgt, nullptr, nt, d_st, tau, max_iterations, fixed_iterations, d_st + 1, h_res);
+            }
         }
         TDV_CHECK_LAUNCH(ctx);
         TDV_HIP(ctx, hipStreamSynchronize(s));
@@ -905,6 +1149,14 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     TDV_CHECK_LAUNCH(ctx);
     const bool p2pl = point_to_plane && d_tgt_normals;
     const int direct = pruned ? 1 : 0;
+    // reference-order accumulation: per-point rows + one-workgroup ordered fold instead of k_icp_accumulate
+    const int row_pitch = (int)align_up((size_t)ns, 256);
+    float* ref_rows = nullptr; int* ref_count = nullptr;
+    if (ref_acc) {
+        TDV_TRY(ws_alloc(ctx, (size_t)(p2pl ? REF_NR_PLANE : REF_NR_POINT) * row_pitch, &ref_rows));
+        TDV_TRY(ws_alloc(ctx, 1, &ref_count));
+        TDV_HIP(ctx, hipMemsetAsync(ref_count, 0, sizeof(int), s));
+    }
     const GridEntry* gtable = cg.usable ? reinterpret_cast<const GridEntry*>(cg.table) : nullptr;
     const float4* gnode = cg.usable ? reinterpret_cast<const float4*>(cg.node) : nullptr;
     const dim3 grid(p.blocks_x, p.nsplit);
@@ -927,7 +1179,15 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
                     k_icp_nn_scan<<<grid, NN_BLOCK, 0, s>>>(d_src, ns, p.ns_pad, b.tx, b.ty, b.tz, p.n_chunks,
                                                             p.chunks_per_split, b.st, b.pd2, b.pchunk);
             }
-            if (p2pl) {
+            if (ref_acc) {
+                if (p2pl) {
+                    k_icp_rows<0><<<row_pitch / 256, 256, 0, s>>>(d_src, ns, p.ns_pad, row_pitch, d_tgt, d_tgt_normals, b.tx, b.ty, b.tz, p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, ref_rows, ref_count);
+                    k_icp_fold_ref<0><<<1, 1024, 0, s>>>(ref_rows, ns, row_pitch, ref_count, b.st, fixed_iterations);
+                } else {
+                    k_icp_rows<1><<<row_pitch / 256, 256, 0, s>>>(d_src, ns, p.ns_pad, row_pitch, d_tgt, nullptr, b.tx, b.ty, b.tz, p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, ref_rows, ref_count);
+                    k_icp_fold_ref<1><<<1, 1024, 0, s>>>(ref_rows, ns, row_pitch, ref_count, b.st, fixed_iterations);
+                }
+            } else if (p2pl) {
 #define TDV_ACC1(MM, PP, NRM) k_icp_accumulate<MM, PP><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \
                                    p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, fixed_iterations, b.slabs, b.ticket, nullptr, nullptr, nullptr)
 #define TDV_ACC(MM, NRM) do { if (p.acc_ppt == 8) TDV_ACC1(MM, 8, NRM); else if (p.acc_ppt == 4) TDV_ACC1(MM, 4, NRM); else if (p.acc_ppt == 2) TDV_ACC1(MM, 2, NRM); else TDV_ACC1(MM, 1, NRM); } while (0)
@@ -969,13 +1229,13 @@ int icp_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* d_src_off, 
     if (max_iterations > 0) {
         ScopedTimer tm(ctx, TDV_TIMER_ICP_NN);
         const bool p2pl = point_to_plane && d_tgt_normals;
-        // The quarter-size shape (256 lanes: more problems resident at once) was measured against the full one on C5's 1,024 instances:
-        // 1.59 ms against 1.33 ms.  The pass lasts as long as its slowest problem (the few that run all 50 iterations), and a lone
-        // workgroup iterates faster with 16 waves.  Kept behind TDV_ICP_TINY=1 (same results: the same reduction tree).
-        const bool tiny = ns_max > 0 && ns_max <= 1024 && nt <= 1024 && getenv("TDV_ICP_TINY") && atoi(getenv("TDV_ICP_TINY")) == 1;
-        if (tiny) {
-            if (p2pl) k_icp_small<0, 256, 1024><<<n_prob, 256, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
-            else k_icp_small<1, 256, 1024><<<n_prob, 256, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+        // (A quarter-size shape - 256 lanes, more problems resident at once - was measured against this one on C5's 1,024 instances in
+        // round 3: 1.59 ms against 1.33 ms.  The pass lasts as long as its slowest problem and a lone workgroup iterates faster with
+        // 16 waves; the variant is gone, profiles/r3/history keeps the numbers.)
+        (void)ns_max;
+        if (ctx->icp_accumulate == TDV_ICP_ACCUMULATE_REFERENCE) {
+            if (p2pl) k_icp_small<0, 1024, SM_MAX_N, true><<<n_prob, 1024, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
+            else k_icp_small<1, 1024, SM_MAX_N, true><<<n_prob, 1024, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
         } else {
             if (p2pl) k_icp_small<0, 1024, SM_MAX_N><<<n_prob, 1024, 0, s>>>(d_src, 0, d_src_off, d_tgt, d_tgt_normals, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);
             else k_icp_small<1, 1024, SM_MAX_N><<<n_prob, 1024, 0, s>>>(d_src, 0, d_src_off, d_tgt, nullptr, nt, d_st, tau, max_iterations, 0, d_st + n_prob, nullptr);

@@ -33,6 +33,7 @@ struct tdv_ctx {
     char err[512] = {0};
     bool timing = false;
     int icp_search = 0;      // TDV_ICP_SEARCH_AUTO / _BRUTE / _PRUNED / _GRID (tdv_ctx_set_icp_search)
+    int icp_accumulate = 0;  // TDV_ICP_ACCUMULATE_TREE (f64 fixed tree) / _REFERENCE (f32, ascending source index: the CPU path's sums bit for bit)
     int ransac_score_mode = 0;    // TDV_RANSAC_SCORE_FAST (FMA pass + exact band) / _EXACT (the reference arithmetic only) / _MATRIX (tdv_ctx_set_ransac_score)
     double last_ransac_rescore = -1.0;   // fraction of (wave, 8-point chunk) pairs of the last RANSAC call that the fast pass scored again exactly (-1: exact mode)
     double last_ransac_scored = 1.0;     // share of the (hypothesis, point) tests the last RANSAC call evaluated (< 1: the exact bail-out left the rest out)

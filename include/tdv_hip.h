@@ -65,6 +65,20 @@ void tdv_ctx_destroy(tdv_ctx* ctx);
 #define TDV_ICP_SEARCH_PRUNED 2
 #define TDV_ICP_SEARCH_GRID 3
 int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode);
+/* ICP accumulation of the per-iteration sums (n_corr, total_error, ATA, ATb resp. the means and the cross-covariance of the
+ * point-to-point branch; src/registration.cpp:340-358,374-386).  The reference adds one correspondence after the other in
+ * float, in ascending source index; a float sum depends on its order.
+ *   TREE (default)  double accumulators in a fixed tree over the whole chip: ~25 us per iteration at 200k points, the same
+ *                   bits run to run, and within ~1e-7 (relative) of the reference's sums - the refined transform agrees with
+ *                   the CPU path to the tolerances of DESIGN.md 2, not to the bit.
+ *   REFERENCE       the reference's own order and precision: every accepted correspondence's terms are stored as rows and one
+ *                   workgroup adds them in index order, one lane per accumulator.  With it transformation, fitness, rmse and
+ *                   the iteration count EQUAL the CPU path's (tests/test_gpu_icp_reference_order.py); the cost is a chain of
+ *                   n dependent additions per iteration (~0.5 ms at 200k points).  Env TDV_ICP_ACCUMULATE=reference selects
+ *                   it at ctx creation; tdv_register_batch_dev honours it for every instance. */
+#define TDV_ICP_ACCUMULATE_TREE 0
+#define TDV_ICP_ACCUMULATE_REFERENCE 1
+int tdv_ctx_set_icp_accumulation(tdv_ctx* ctx, int mode);
 /* RANSAC hypothesis scoring.  FAST (default; env TDV_RANSAC_SCORE=exact overrides) evaluates every (hypothesis, point) with
  * fused multiply-adds and re-scores, with the reference's unfused arithmetic, every chunk of points in which a distance
  * falls inside the rounding band where the two could disagree: the inlier counts are those of EXACT, which runs the
