@@ -42,7 +42,7 @@ DEPTH_BATCH_MASK_PASSES = 1   # the B masks cross HBM once in tdv_depth_to_cloud
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [
-    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_set_icp_accumulation", "tdv_ctx_last_icp_search", "tdv_ctx_workspace_bytes", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_set_icp_accumulation", "tdv_ctx_last_icp_search", "tdv_ctx_last_batch_lanes", "tdv_ctx_last_feature_match_path", "tdv_ctx_workspace_bytes", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
@@ -221,6 +221,14 @@ class Context:
         """Share of the (hypothesis, point) tests the last RANSAC call evaluated (< 1: calls without a trace stop scoring a
         hypothesis that can no longer beat the best count of the earlier batches; same result)."""
         return float(lib().tdv_ctx_last_ransac_scored(self._h))
+
+    def last_feature_match_path(self):
+        """'scan', 'leaf_major' or 'walk': the search the last feature_match call on this context ran."""
+        return {0: "none", 1: "scan", 2: "leaf_major", 3: "walk"}[int(lib().tdv_ctx_last_feature_match_path(self._h))]
+
+    def last_batch_lanes(self):
+        """Host lanes the last register_batch_dev call on this context used."""
+        return int(lib().tdv_ctx_last_batch_lanes(self._h))
 
     def last_icp_search(self):
         """Name of the search the last ICP / correspondence call ran ('brute', 'pruned', 'grid'; 'auto' before any)."""

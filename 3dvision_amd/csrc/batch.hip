@@ -214,7 +214,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // launch-bound kernels and host read-backs and still gain from more lanes (C5, 1,024 instances of ~400 voxels:
     // 5,650 / 6,550 / 6,790 instances/s with 8 / 12 / 16): they take 12.  Never more than the host has hardware threads;
     // TDV_BATCH_LANES overrides (1 = the caller's thread only, at most 16).
-    static const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;
+    const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;   // read per call, like the other knobs (the tests switch it)
     const int hw_threads = std::max(1u, std::thread::hardware_concurrency());
     const bool small_instances = off[n_instances] / std::max(n_instances, 1) < 8192;      // points per instance, on average
     const int lanes_default = std::min(small_instances ? 12 : 6, hw_threads);
@@ -225,6 +225,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         lane_ctx.push_back(c->helper);
     }
     const int L = (int)lane_ctx.size();
+    ctx->last_batch_lanes = L;
     // fn(lane ctx, instance) over all instances, dealt to the lanes in turn; returns when every lane's stream has drained
     auto for_all_instances = [&](const std::function<int(tdv_ctx*, int)>& fn) -> int {
         if (L == 1) {

@@ -98,18 +98,18 @@ int tdv_broadcast_model(tdv_ctx* ctx, void* rccl_comm, int root, float* d_xyz, f
     TDV_TRY(tdv::ws_reset(ctx));
     hipStream_t s = ctx->stream;
     Header mine;
-    mine.ok = (n_model && capacity >= 0 && d_xyz && d_fpfh && (rank != root || (*n_model >= 0 && *n_model <= capacity))) ? 1 : 0;
+    mine.ok = (n_model && capacity >= 0 && (rank != root || (*n_model >= 0 && *n_model <= capacity))) ? 1 : 0;
     mine.a = (rank == root && n_model) ? *n_model : 0;          // the point count travels in the root's header
     mine.b = capacity;
-    mine.c = d_normals ? 1 : 0;
+    mine.c = (d_normals ? 1 : 0) | ((d_xyz && d_fpfh) ? 2 : 0); // bit 1: this rank passed the two mandatory buffers (needed only if the model is not empty)
     Header* all;
     TDV_TRY(exchange_header(ctx, rccl_comm, world, rank, mine, &all));
     const int n = all[root].a;
     int bad_rank = -1, min_cap = all[0].b, with_normals = 1;
     for (int r = 0; r < world; ++r) {
-        if (!all[r].ok && bad_rank < 0) bad_rank = r;
+        if ((!all[r].ok || (n > 0 && !(all[r].c & 2))) && bad_rank < 0) bad_rank = r;     // an empty model needs no buffers anywhere
         if (all[r].b < min_cap) min_cap = all[r].b;
-        with_normals &= all[r].c;
+        with_normals &= all[r].c & 1;
     }
     if (bad_rank >= 0) { std::snprintf(ctx->err, sizeof(ctx->err), "tdv_broadcast_model: invalid arguments on rank %d (no payload was sent)", bad_rank); return TDV_ERR_BAD_ARG; }
     if (n_model) *n_model = n;

@@ -1158,6 +1158,7 @@ struct LmLists {
     int *unit_leaf;                                       // [pair_cap / 64 + nleaf + 2]
     int *sorted_src;                                      // [pair_cap]
     unsigned long long* keys;                             // [ns]
+    int unit_cap;                                         // room in unit_leaf
 };
 struct LmSrc { v2f p[(FD + 1) / 2]; float pq[PD]; };     // a lane's source: descriptor as 17 register pairs, principal coordinates
 // The original row indices of a leaf as k_lm_eval reads them (rarely: only where a lane can improve): the "constant" address space
@@ -1408,7 +1409,9 @@ void k_lm_plan(LmLists L, int nleaf) {
         const int pc = bc + ic - c, pu = bu + iu - u;
         if (l < nleaf) {
             L.leaf_start[l] = pc; L.unit_start[l] = pu;
-            for (int k = 0; k < u; ++k) L.unit_leaf[pu + k] = l;
+            // (the entry pools admit up to 64 sources per entry, i.e. more units than unit_leaf holds when the descriptors have no
+            //  structure: such a call falls back below - and must not have written past the array on its way there)
+            for (int k = 0; k < u && pu + k < L.unit_cap; ++k) L.unit_leaf[pu + k] = l;
             if (POOLS && !dead) {
                 int run = pc;
 #pragma unroll
@@ -1420,7 +1423,7 @@ void k_lm_plan(LmLists L, int nleaf) {
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const bool fits = s_carry[0] <= L.pair_cap;          // (round 0: the sources themselves)
+        const bool fits = s_carry[0] <= L.pair_cap && s_carry[1] <= L.unit_cap;          // (round 0: the sources themselves)
         if (!fits) *L.overflow = 1;
         L.leaf_start[nleaf] = s_carry[0]; L.unit_start[nleaf] = fits ? s_carry[1] : 0;
     }
@@ -1797,10 +1800,10 @@ static int launch_fm_leafmajor(tdv_ctx* ctx, const FmTables& t, const FmIndex& i
     LmLists L[3];
     for (int r = 0; r < 2; ++r) {
         int* z = zeroed + r * per_round;
-        L[r + 1] = LmLists{z, z + (size_t)LM_POOLS * nleaf, z + (size_t)LM_POOLS * nleaf + LM_POOLS, leaf_count, pool_start, entries, (int)pool_cap, (int)pair_cap, leaf_start, unit_start, unit_leaf, sorted_src, keys};
+        L[r + 1] = LmLists{z, z + (size_t)LM_POOLS * nleaf, z + (size_t)LM_POOLS * nleaf + LM_POOLS, leaf_count, pool_start, entries, (int)pool_cap, (int)pair_cap, leaf_start, unit_start, unit_leaf, sorted_src, keys, (int)unit_cap};
     }
     // round 0: every source against its home leaf.  The search order is sorted by home leaf, so it IS the sorted pair list.
-    L[0] = LmLists{nullptr, nullptr, zeroed + 2 * per_round, home_hist, nullptr, nullptr, 0, INT_MAX, leaf_start, unit_start, unit_leaf, const_cast<int*>(t.sperm), keys};
+    L[0] = LmLists{nullptr, nullptr, zeroed + 2 * per_round, home_hist, nullptr, nullptr, 0, INT_MAX, leaf_start, unit_start, unit_leaf, const_cast<int*>(t.sperm), keys, (int)unit_cap};
     unsigned long long* d_stats = nullptr;
     if (getenv("TDV_FM_STATS")) { TDV_TRY(ws_alloc(ctx, 16, &d_stats)); TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, s)); }
     static const int eval_blocks = getenv("TDV_LM_EVAL_BLOCKS") ? atoi(getenv("TDV_LM_EVAL_BLOCKS")) : 4096;   // tuning knob (a multiple of 8; 1024 / 2048 / 4096 / 8192: 0.51 / 0.49 / 0.477 / 0.478 ms at 143k x 151k)
@@ -1878,8 +1881,9 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
         FmTables t{d_fs, sperm, home, ns, nullptr, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, ix.pbox, ix.gpbox, sp, ix.amax, amax_s, ix.pscale};
         bool done = false;
         TDV_TRY(launch_fm_leafmajor(ctx, t, ix, hist, d_corr, &done));
-        if (done) return TDV_OK;
+        if (done) { ctx->last_fm_path = TDV_FM_PATH_LEAF_MAJOR; return TDV_OK; }
     }
+    ctx->last_fm_path = TDV_FM_PATH_WALK;
     if (k >= 2) {
         const int kk = k >= 4 ? 4 : 2;
         const size_t n2 = ((size_t)ns + kk - 1) / kk * kk * FD;
@@ -1897,6 +1901,7 @@ int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft
     if (ns == 0) return TDV_OK;
     hipStream_t s = ctx->stream;
     if (nt == 0) { TDV_HIP(ctx, hipMemsetAsync(d_corr, 0, (size_t)ns * 4, s)); return TDV_OK; }
+    ctx->last_fm_path = TDV_FM_PATH_SCAN;
     const char* brute = getenv("TDV_FM_BRUTE");         // A/B knobs: same results every way
     const char* keyorder = getenv("TDV_FM_KEYORDER");
     if (!brute && ns >= 4096 && nt >= 2048) {

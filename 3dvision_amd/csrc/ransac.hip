@@ -1147,9 +1147,10 @@ int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, c
     TDV_TRY(ws_alloc(ctx, (size_t)total_pos * 6, &pq2));
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds * 14 * h_pad, &hyp));
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds * h_pad, &counts));
-    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 8, &d_pmax));                     // pmax[clouds] | bad | fail | (pad) | rescored, scored (u64 each)
+    TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_pmax));                     // pmax[clouds] | bad | fail
     d_flags = reinterpret_cast<int*>(d_pmax + n_clouds);
-    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(d_pmax + ((n_clouds + 2 + 1) & ~1) + 2);
+    unsigned long long* d_stats;                                               // rescored, scored (their own allocation: 8-byte aligned whatever n_clouds is)
+    TDV_TRY(ws_alloc(ctx, 2, &d_stats));
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds, &d_res));
     const size_t pin_raw = align_up((size_t)n_raw * 4, 64), pin_res = align_up((size_t)n_clouds * sizeof(RbResult), 64);
     TDV_TRY(pin_reserve(ctx, pin_raw + pin_res + 64 + ((size_t)n_clouds + 1) * 4));
@@ -1161,7 +1162,8 @@ int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, c
     std::memcpy(h_pos, pos_off.data(), ((size_t)n_clouds + 1) * 4);
     TDV_HIP(ctx, hipMemcpyAsync(d_raw, h_raw, (size_t)n_raw * 4, hipMemcpyHostToDevice, s));
     TDV_HIP(ctx, hipMemcpyAsync(d_pos_off, h_pos, ((size_t)n_clouds + 1) * 4, hipMemcpyHostToDevice, s));
-    TDV_HIP(ctx, hipMemsetAsync(d_pmax, 0, ((size_t)n_clouds + 8) * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(d_pmax, 0, ((size_t)n_clouds + 2) * 4, s));
+    TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 2 * sizeof(unsigned long long), s));
     k_rb_sample<<<n_clouds, 1024, 0, s>>>(d_raw, n_raw, d_off, H, d_idx, d_flags + 1);
     k_rb_gather_pq<<<(total_pos + 255) / 256, 256, 0, s>>>(d_src, d_tgt, d_corr, d_off, d_pos_off, n_clouds, total_pos, nt, pq, d_flags, d_pmax);
     k_pack_pq2<<<(total_pos / 2 + 255) / 256, 256, 0, s>>>(pq, total_pos, pq2);

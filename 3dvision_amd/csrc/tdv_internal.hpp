@@ -37,6 +37,8 @@ struct tdv_ctx {
     int ransac_score_mode = 0;    // TDV_RANSAC_SCORE_FAST (FMA pass + exact band) / _EXACT (the reference arithmetic only) / _MATRIX (tdv_ctx_set_ransac_score)
     double last_ransac_rescore = -1.0;   // fraction of (wave, 8-point chunk) pairs of the last RANSAC call that the fast pass scored again exactly (-1: exact mode)
     double last_ransac_scored = 1.0;     // share of the (hypothesis, point) tests the last RANSAC call evaluated (< 1: the exact bail-out left the rest out)
+    int last_fm_path = 0;      // TDV_FM_PATH_* of the last descriptor match on this ctx (tdv_ctx_last_feature_match_path)
+    int last_batch_lanes = 0;  // host lanes the last tdv_register_batch_dev call on this ctx spread its instances over (tdv_ctx_last_batch_lanes)
     int last_icp_search = 0; // the search the last ICP / correspondence call on this ctx actually ran (tdv_ctx_last_icp_search)
     unsigned* scan_ticket = nullptr;  // persistent device word of exclusive_scan_dev (last-workgroup ticket)
     uint16_t* depth_bits = nullptr;   // validity bitmap between the two passes of the batched depth -> cloud (workspace memory of the current call)

@@ -98,6 +98,15 @@ double tdv_ctx_last_ransac_rescore(tdv_ctx* ctx);
 double tdv_ctx_last_ransac_scored(tdv_ctx* ctx);
 /* The search the last tdv_icp* / tdv_icp_correspondences call on this ctx ran (BRUTE, PRUNED or GRID; 0 before any). */
 int tdv_ctx_last_icp_search(tdv_ctx* ctx);
+/* The search the last tdv_feature_match* call on this ctx ran (0 before any): the reference's scan (small sets), the leaf-major
+ * search over the packed index, or the per-source walk of that index the leaf-major search hands over to when the descriptors
+ * have no structure (its pair pool would run over).  Same correspondences every way. */
+#define TDV_FM_PATH_SCAN 1
+#define TDV_FM_PATH_LEAF_MAJOR 2
+#define TDV_FM_PATH_WALK 3
+int tdv_ctx_last_feature_match_path(tdv_ctx* ctx);
+/* Host lanes (the caller's thread + helper threads) the last tdv_register_batch_dev call on this ctx used (0 before any). */
+int tdv_ctx_last_batch_lanes(tdv_ctx* ctx);
 /* Device memory this ctx holds in its grow-only workspace arenas, its batch lanes' included: the high-water mark of every
  * call made on it so far (the arena never shrinks; steady state allocates nothing). */
 unsigned long long tdv_ctx_workspace_bytes(tdv_ctx* ctx);

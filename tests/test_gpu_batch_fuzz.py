@@ -116,4 +116,8 @@ def test_batch_shapes_agree(ctx, tdv, synth, seed, with_big, model_n):
         ]
         for what, fmt, env in variants:
             _same(_run(ctx, tdv, d_depth, formats[fmt], fmt, n_inst, model, voxel, order, env), base, "%s (order %d, seed %d)" % (what, order, seed))
+            if "TDV_BATCH_LANES" in env:
+                assert ctx.last_batch_lanes() == int(env["TDV_BATCH_LANES"]), (what, ctx.last_batch_lanes())     # the knob took effect
+            elif n_inst > 1:
+                assert ctx.last_batch_lanes() > 1, (what, ctx.last_batch_lanes())
         print("seed %d order %d: %d instances %s, model %d pts: %d variants equal; voxels %s" % (seed, order, n_inst, kinds, nm, len(variants), [r["n_voxels"] for r in base]))

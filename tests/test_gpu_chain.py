@@ -65,6 +65,14 @@ def test_stagewise_chain_equals_oracle_chain(ctx, tdv, synth, scene):
         ang, tr = synth.pose_error(fine.transformation, o["fine"]["T"])
         assert fine.iterations == o["fine"]["iterations"] and ang <= 1e-4 and tr <= 1e-6, (fine.iterations, o["fine"]["iterations"], ang, tr)
         assert abs(float(fine.fitness) - float(o["fine"]["fitness"])) < 1e-6
+        ctx.set_icp_accumulation("reference")                         # the reference's accumulation order: the oracle's bits
+        try:
+            fine_ref = ctx.icp(src, mx, mn, coarse.transformation, cs.VOXEL * 0.4, cs.ICP_ITERS, True)
+        finally:
+            ctx.set_icp_accumulation("tree")
+        assert fine_ref.transformation.tobytes() == o["fine"]["T"].tobytes() and fine_ref.iterations == o["fine"]["iterations"]
+        assert np.float32(fine_ref.rmse).tobytes() == np.float32(o["fine"]["rmse"]).tobytes()
+        assert np.float32(fine_ref.fitness).tobytes() == np.float32(o["fine"]["fitness"]).tobytes()
         ang_gt, tr_gt = synth.pose_error(fine.transformation, sc["T_gt"][b])
         print("instance %d: %d voxels, FPFH rows bit-equal %.4f, coarse inliers %d @%d, ICP %d iterations; vs oracle %.1e rad %.1e m; "
               "vs ground truth %.1e rad %.1e m" % (b, len(src), same.mean(), coarse.inliers, coarse.best_iteration, fine.iterations, ang, tr, ang_gt, tr_gt))
@@ -110,6 +118,16 @@ def test_batched_chain_equals_oracle_chain(ctx, tdv, synth, scene):
         assert r["T"].tobytes() == fine.transformation.tobytes() and r["fitness"] == fine.fitness and r["rmse"] == fine.rmse
         ang_gt, tr_gt = synth.pose_error(r["T"], sc["T_gt"][b])
         assert ang_gt < 1e-2 and tr_gt < 1e-3
+    # the whole batched chain with the reference's accumulation order: every instance's refined transform IS the oracle's
+    ctx.set_icp_accumulation("reference")
+    try:
+        res_ref = _batch(ctx, tdv, sc, tdv.TDV_VOXEL_ORDER_REFERENCE, d_model)
+    finally:
+        ctx.set_icp_accumulation("tree")
+    for b, r in enumerate(res_ref):
+        o = inst[b]["fine"]
+        assert r["T"].tobytes() == o["T"].tobytes() and r["icp_iterations"] == o["iterations"]
+        assert np.float32(r["rmse"]).tobytes() == np.float32(o["rmse"]).tobytes() and np.float32(r["fitness"]).tobytes() == np.float32(o["fitness"]).tobytes()
 
 
 def test_batched_chain_first_occurrence_order_registers_too(ctx, tdv, synth, scene):

@@ -84,6 +84,15 @@ def test_c1_features_ransac_icp(ctx, orc, synth, demo):
         assert g.iterations == min(k, n_o), (k, g.iterations, n_o)
         assert g.n_corr == int(row[18]) and g.fitness == row[17]
         assert da <= 1e-4 and dt <= 1e-6 and abs(float(g.rmse) - float(row[16])) <= 1e-7
+        # ... and with the reference's accumulation order (round 4) the state after iteration k IS the oracle's row k, bit for bit
+        ctx.set_icp_accumulation("reference")
+        try:
+            e = ctx.icp(src, ref, ref_n_o, rs_o["T"], VOXEL * 0.4, k, True)
+        finally:
+            ctx.set_icp_accumulation("tree")
+        assert e.iterations == min(k, n_o) and e.n_corr == int(row[18])
+        assert e.transformation.T.astype(np.float32).tobytes() == row[:16].tobytes(), k
+        assert np.float32(e.rmse).tobytes() == row[16].tobytes() and np.float32(e.fitness).tobytes() == row[17].tobytes()
     icp = ctx.icp(src, ref, ref_n_o, rs_o["T"], VOXEL * 0.4, 30, True)
     assert icp.iterations == n_o and float(icp.fitness) == float(icp_o["fitness"])
 

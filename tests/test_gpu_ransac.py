@@ -59,6 +59,23 @@ def test_feature_match_pruned_path_random(ctx, orc, synth):
     assert (got[:200] < 2000).all()
 
 
+@pytest.mark.parametrize("ns,nt", [(9000, 2048), (20000, 4096)])
+def test_feature_match_unstructured_descriptors_hand_over_to_the_walk(ctx, orc, synth, ns, nt):
+    """Descriptors without structure: every source passes 33-64 leaf boxes, the leaf-major search's pair / unit pools cannot hold
+    that and the call hands over to the per-source walk (round 3's advisor: k_lm_plan then wrote unit_leaf past its end on the way -
+    now bounded by unit_cap and counted as an overflow).  Same correspondences as the oracle; the path taken is asserted, and a
+    structured call right after still takes the leaf-major search on the same ctx."""
+    fs = synth.random_features(ns, 11); ft = synth.random_features(nt, 12)
+    got = ctx.feature_match(fs, ft)
+    assert ctx.last_feature_match_path() == "walk"
+    sel = np.arange(0, ns, 7)
+    assert np.array_equal(got[sel], orc.feature_match(fs[sel], ft))
+    fr = _real_fpfh(orc, synth, 5000, 42, scene=True); tr = _real_fpfh(orc, synth, 3000, 7)
+    assert np.array_equal(ctx.feature_match(fr, tr), orc.feature_match(fr, tr))
+    assert ctx.last_feature_match_path() == "leaf_major"
+    assert np.array_equal(ctx.feature_match(fs[:500], ft[:300]), orc.feature_match(fs[:500], ft[:300])) and ctx.last_feature_match_path() == "scan"
+
+
 def test_feature_match_pruned_path_real_fpfh(ctx, orc, synth):
     """Real (strongly clustered, many near-ties) FPFH descriptors of the synthetic part: scene vs model."""
     fs = _real_fpfh(orc, synth, 7000, 42, scene=True)
