@@ -11,7 +11,15 @@ GPU box, "gloo" in CPU tests):
   * gather_results  : ONE gather of 19 floats per instance (16 T + fitness + rmse + inliers) to rank 0.
 
 No collective sits on the data path of an instance; a single cloud pair is never split across GPUs.
+
+The same two steps exist below Python, in the C ABI (tdv_broadcast_model / tdv_gather_results, csrc/comm.hip), for hosts
+without torch: they take the caller's ncclComm_t.  `rccl_comm_from_process_group` makes one for a job that already has a
+torch.distributed group (the id travels over that group), so that a Python job can move the model and the results through the
+C ABI as well - what bench.py's N > 1 line does for config C5.
 """
+import ctypes as C
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -74,3 +82,59 @@ def gather_results(local, n_items, device, dst=0):
         a, b = shard_range(n_items, world, r)
         parts.append(out[r][: b - a].cpu().numpy())
     return np.concatenate(parts, 0)
+
+
+# ---- an ncclComm_t for the C ABI's collectives -------------------------------------------------------------------------------
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_ubyte * 128)]
+
+
+_rccl = None
+
+
+def rccl_library():
+    """The RCCL this process should talk to: the copy torch already loaded (found in /proc/self/maps and re-opened RTLD_GLOBAL,
+    so that csrc/comm.hip's dlsym(RTLD_DEFAULT, "ncclBroadcast") resolves to the SAME library that creates the communicator),
+    else librccl.so.1."""
+    global _rccl
+    if _rccl is None:
+        path = None
+        try:
+            for line in open("/proc/self/maps"):
+                f = line.split()[-1]
+                if os.path.basename(f).startswith("librccl.so"):
+                    path = f
+                    break
+        except OSError:
+            pass
+        _rccl = C.CDLL(path or "librccl.so.1", mode=C.RTLD_GLOBAL)
+        _rccl.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        _rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        _rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    return _rccl
+
+
+def rccl_comm_from_process_group(device):
+    """One ncclComm_t (as an int) spanning the ranks of the default torch.distributed group (backend nccl = RCCL), one rank per
+    process: rank 0 draws the unique id, the group broadcasts its 128 bytes, every rank calls ncclCommInitRank.  The caller
+    must have set the HIP device (torch.cuda.set_device).  Destroy with rccl_comm_destroy."""
+    lib = rccl_library()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    uid = _NcclUniqueId()
+    if rank == 0:
+        rc = lib.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+    t = torch.frombuffer(bytearray(C.string_at(C.byref(uid), 128)), dtype=torch.uint8).to(device)     # zeros except on rank 0
+    dist.broadcast(t, src=0)
+    C.memmove(C.byref(uid), t.cpu().numpy().tobytes(), 128)
+    comm = C.c_void_p()
+    rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+    return comm.value
+
+
+def rccl_comm_destroy(comm):
+    if comm:
+        rccl_library().ncclCommDestroy(C.c_void_p(comm))

@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--points", type=int, default=200000, help="N_s = N_t (headline: 200000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-operators", action="store_true", help="skip the per-operator block measured after the timed region")
+    ap.add_argument("--c5-instances", type=int, default=1024, help="N > 1: instances per rank of the C5 tray measured after the timed region")
     ap.add_argument("--cpu-budget-s", type=float, default=16.0)
     ap.add_argument("--min-region-ms", type=float, default=100.0,
                     help="the timed region is repeated (whole multiples of K steps) until it is at least this long; 0 = exactly K steps once")
@@ -288,8 +289,20 @@ def main():
     ctx.timing_read(tdv.TIMER_ICP_NN)
     ctx.icp_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), d_nrm.data_ptr(), n, T0, icp_thr, 3, True, fixed_iterations=True)
     bf_ms, bf_launches = ctx.timing_read(tdv.TIMER_ICP_NN)
-    ctx.set_icp_search("auto")
     ctx.timing_enable(False)
+    BF_ITERS = 10                                     # whole iterations with the reference's scan (search + sums + solve), wall clock
+    torch.cuda.synchronize(); t_bf0 = time.perf_counter()
+    ctx.icp_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), d_nrm.data_ptr(), n, T0, icp_thr, BF_ITERS, True, fixed_iterations=True)
+    torch.cuda.synchronize(); bf_iters_per_s = BF_ITERS / (time.perf_counter() - t_bf0)
+    ctx.set_icp_search("auto")
+    # supplementary: the same ICP call with the reference's accumulation order (bit-equal to the CPU path; a serial chain per iteration)
+    REF_ITERS = 10
+    ctx.set_icp_accumulation("reference")
+    ctx.icp_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), d_nrm.data_ptr(), n, T0, icp_thr, 2, True, fixed_iterations=True)
+    torch.cuda.synchronize(); t_r0 = time.perf_counter()
+    ctx.icp_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), d_nrm.data_ptr(), n, T0, icp_thr, REF_ITERS, True, fixed_iterations=True)
+    torch.cuda.synchronize(); ref_iters_per_s = REF_ITERS / (time.perf_counter() - t_r0)
+    ctx.set_icp_accumulation("tree")
 
     # supplementary: RANSAC with EVERY (hypothesis, point) test evaluated (a traced call: the exact bail-out is off), outside `value`
     full_hyps = 4 * 65536
@@ -299,6 +312,18 @@ def main():
     torch.cuda.synchronize(); t_full = time.perf_counter() - t_f0
     full_ms, full_launches = ctx.timing_read(tdv.TIMER_RANSAC_SCORE); ctx.timing_enable(False)
     full_rescore = ctx.last_ransac_rescore(); full_scored = ctx.last_ransac_scored()
+
+    # N > 1: config C5 (BASELINE.json configs[4]) rides in the same line - every rank registers its own 1,024-instance tray, the model
+    # moved once by tdv_broadcast_model and the results gathered once by tdv_gather_results (C ABI, ncclComm_t over RCCL); in the one-GPU
+    # rehearsal (gloo) the same two steps go through torch.distributed.  Outside `value`.
+    c5_out = None
+    if distributed and not args.no_operators:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_c5
+        c5_ctx = tdv.Context(local_rank)
+        c5_out, c5_ok = bench_c5.tray_share(tdv, synth, sharding, c5_ctx, torch, dist, dev, rank, world, tdv.TDV_VOXEL_ORDER_REFERENCE, cdev,
+                                            instances_per_gpu=args.c5_instances)
+        c5_ctx.close()
 
     if rank == 0:
         steps_total = steps_timed * world
@@ -410,6 +435,23 @@ def main():
             if roofline.get("traffic") is not None else None
         roofline["second_kernel"] = other
         roofline["icp_nn_bruteforce_scan"] = brute
+        # BASELINE.json's metric, flat, in the dict the driver keeps: hypotheses/s and iterations/s at 200k points (whole job), each from
+        # its own synchronized sub-region of the timed steps; beside them the figures the docs promise next to every headline number
+        hyps_per_s = steps_timed * HYPS_PER_STEP * world / t_rs
+        iters_per_s = steps_timed * world / t_icp
+        roofline.update({
+            "ransac_hyps_per_s": hyps_per_s, "icp_iters_per_s": iters_per_s,
+            "ransac_hyps_per_s_every_test_scored": full_hyps / t_full,
+            "icp_iters_per_s_bruteforce_scan": bf_iters_per_s,
+            "icp_iters_per_s_reference_order_sums": ref_iters_per_s,
+            "icp_search": icp_search_used,
+            "target_ransac_hyps_per_s": 1e6, "target_icp_iters_per_s": 50,
+            "hbm_algorithmic_bytes_per_launch": score["hbm"]["algorithmic_bytes_per_launch"] if dominant is score else nn["hbm"]["algorithmic_bytes_per_launch"],
+            "hbm_achieved_GBps": dominant["hbm"]["achieved"], "hbm_frac": dominant["hbm"]["frac"],
+            "every_test_scored_frac": score["every_test_scored"]["frac"], "every_test_scored_avg_launch_ms": score["every_test_scored"]["avg_launch_ms"],
+            "bruteforce_scan_frac": brute["frac"], "bruteforce_scan_avg_launch_ms": brute["avg_launch_ms"],
+            "second_kernel_name": other["kernel"], "second_kernel_avg_launch_ms": other["avg_launch_ms"],
+        })
         out = {
             "metric": "RANSAC hyps/s + ICP iters/s @ 200k-pt clouds",
             "value": steps_total / elapsed,
@@ -419,8 +461,10 @@ def main():
             "ms_per_step": elapsed / steps_timed * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "icp_iters_per_s": steps_timed * world / t_icp,
-            "ransac_hyps_per_s": steps_timed * HYPS_PER_STEP * world / t_rs,
+            "icp_iters_per_s": iters_per_s,
+            "ransac_hyps_per_s": hyps_per_s,
+            "icp_iters_per_s_bruteforce_scan": bf_iters_per_s,
+            "icp_iters_per_s_reference_order_sums": ref_iters_per_s,
             "targets": {"icp_iters_per_s": 50, "ransac_hyps_per_s": 1e6},
             "config": {"workload": "headline: N_s=N_t=%d, point-to-plane ICP (fixed %d iterations per call, %s correspondence search) + RANSAC scoring (%d hyps per call), "
                                    "%d call(s) of each in the timed region, one instance pair per GPU"
@@ -428,7 +472,8 @@ def main():
                        "n_src": n, "n_tgt": n, "hyps_per_step": HYPS_PER_STEP, "parallelism": "instances sharded, %d rank(s)%s" % (world, " - REHEARSAL: all ranks on GPU 0, gloo" if rehearse else ""),
                        "icp_start": "0.3 deg / 0.5 mm from the ground truth (inside the basin of the reference's 0.4-voxel threshold; SURVEY 8d's 3 deg / 5 mm start "
                                     "lies outside it and every iteration count is fixed, so the start only decides how many correspondences are accepted)",
-                       "model_bcast_ms": bcast_ms if distributed else None},
+                       "model_bcast_ms": bcast_ms if distributed else None,
+                       "ransac_hyps_per_s": hyps_per_s, "icp_iters_per_s": iters_per_s},
             "model_bcast_ms": bcast_ms if distributed else None,
             "per_rank": [{"rank": int(x[0]), "steps_per_s": x[1], "dominant_kernel_avg_ms": x[2], "dominant_kernel_frac": x[3], "model_bcast_ms": x[4] if distributed else None}
                          for x in per_rank],
@@ -436,6 +481,10 @@ def main():
             "result_check": {"icp_fitness": float(r_icp.fitness), "icp_rmse": float(r_icp.rmse), "ransac_inliers": int(r_rs.inliers),
                              "ransac_iterations_run": int(r_rs.iterations_run)},
         }
+        if c5_out is not None:
+            out["c5"] = c5_out
+            out["config"].update({"c5_instances_per_s": c5_out["instances_per_s"], "c5_instances": c5_out["instances"], "c5_model_bcast_ms": c5_out["model_bcast_ms"],
+                                  "c5_gather_ms": c5_out["gather_ms"], "c5_registered_share": c5_out["registered_share"], "c5_collectives": c5_out["collectives"]})
         if not args.no_operators and world == 1:
             # every other stage of the path, measured after the timed region (outside `value`): median of 3 repetitions each
             sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -443,6 +492,12 @@ def main():
             t_ops = time.perf_counter()
             out["operators"] = opbench.measure_all(ctx, tdv, synth, torch, dev)
             out["operators_wall_s"] = time.perf_counter() - t_ops
+            # C4 / C5 flat, in a dict the driver keeps
+            for row in out["operators"] if isinstance(out["operators"], list) else []:
+                if not isinstance(row, dict): continue
+                if row.get("op") == "register_batch_c5": out["config"]["c5_one_rank_instances_per_s"] = row.get("instances_per_s")
+                if row.get("op", "").startswith("register_batch") and "instances_per_s" in row and "c4" in json.dumps(row.get("workload", "")).lower():
+                    out["config"].setdefault("c4_instances_per_s", row.get("instances_per_s"))
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a single-GPU-run item (rank 0, N = 1)
             from oracle import pyoracle as orc
             out["cpu_baseline"] = cpu_baseline(orc, src_np, model[:, :3].cpu().numpy(), model[:, 3:6].cpu().numpy(), corr_np, T0, icp_thr, voxel, args.cpu_budget_s)

@@ -29,21 +29,40 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev=None):
-    cdev = cdev or dev                                                 # where the collectives' tensors live (the CPU in a one-GPU rehearsal)
+def tray_share(tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev=None, instances_per_gpu=1024, hyps=10000, icp_iters=50, c_abi=None):
+    """One rank's 1,024-instance tray through ONE tdv_register_batch_dev call, the model moved once from rank 0 and the results
+    gathered once.  c_abi (default: whenever the job is a real RCCL job, i.e. world > 1 and the collectives' tensors live on the
+    GPU): the two steps go through the C ABI - tdv_broadcast_model / tdv_gather_results on an ncclComm_t made from the
+    process group (sharding.rccl_comm_from_process_group) - else through torch.distributed (sharding.broadcast_model /
+    gather_results: the one-GPU gloo rehearsal, where RCCL cannot hold two ranks on one device).  Returns (dict for rank 0 | None, ok)."""
+    cdev = cdev or dev                                                 # where torch's collectives' tensors live (the CPU in a one-GPU rehearsal)
+    if c_abi is None:
+        c_abi = world > 1 and cdev.type == "cuda"
     c5 = importlib.import_module("c5_tray")
-    B = args.instances_per_gpu
-    wl = c5.build(tdv, synth, ctx, B, dev, order=order, hyps=args.hyps, icp_iters=args.icp_iters, pose_seed=1000 + rank)
+    B = instances_per_gpu
+    wl = c5.build(tdv, synth, ctx, B, dev, order=order, hyps=hyps, icp_iters=icp_iters, pose_seed=1000 + rank)
     # the model: prepared on rank 0 (every rank's build made one of the same part; only rank 0's is used), broadcast once
-    t0 = time.perf_counter()
     d_mx, d_mn, d_mf, nm = wl["model"]
-    pack = torch.cat([d_mx[:nm], d_mn[:nm], d_mf[:nm]], 1).contiguous() if rank == 0 else None
+    comm = sharding.rccl_comm_from_process_group(dev) if c_abi else None
     if world > 1:
-        nmt = torch.tensor([nm if rank == 0 else 0], dtype=torch.int64, device=cdev); dist.broadcast(nmt, src=0); nm = int(nmt.item())
-    model = sharding.broadcast_model(pack.to(cdev) if pack is not None else None, nm, cdev).to(dev)
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if c_abi:
+        cap = int(d_mx.shape[0])                                       # every rank built the same part: same capacity everywhere
+        if rank != 0:
+            d_mx.zero_(); d_mn.zero_(); d_mf.zero_()                   # what arrives is rank 0's model, not this rank's own copy
+            torch.cuda.synchronize()
+        nm = ctx.broadcast_model(comm, 0, d_mx.data_ptr(), d_mn.data_ptr(), d_mf.data_ptr(), cap, nm if rank == 0 else 0)
+        wl["model"] = (d_mx, d_mn, d_mf, nm)
+    else:
+        pack = torch.cat([d_mx[:nm], d_mn[:nm], d_mf[:nm]], 1).contiguous() if rank == 0 else None
+        if world > 1:
+            nmt = torch.tensor([nm if rank == 0 else 0], dtype=torch.int64, device=cdev); dist.broadcast(nmt, src=0); nm = int(nmt.item())
+        model = sharding.broadcast_model(pack.to(cdev) if pack is not None else None, nm, cdev).to(dev)
+        wl["model"] = (model[:, 0:3].contiguous(), model[:, 3:6].contiguous(), model[:, 6:39].contiguous(), nm)
     torch.cuda.synchronize()
     bcast_ms = (time.perf_counter() - t0) * 1e3
-    wl["model"] = (model[:, 0:3].contiguous(), model[:, 3:6].contiguous(), model[:, 6:39].contiguous(), nm)
     c5.run(ctx, wl)                                                    # warm-up
     if world > 1:
         dist.barrier()
@@ -55,21 +74,47 @@ def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, 
     tt = torch.tensor([t_local], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    t1 = time.perf_counter()
     ang = c5.angles(synth, wl, res).astype(np.float32)
-    local = np.stack([sharding.encode_result(r["T"], r["fitness"], ang[i], r["coarse_inliers"]) for i, r in enumerate(res)])
-    allres = sharding.gather_results(local, B * world, cdev)          # slot 17 carries the angle to the ground truth instead of the rmse
-    gather_ms = (time.perf_counter() - t1) * 1e3
-    ok = True
+    t1 = time.perf_counter()
+    if c_abi:
+        local = []
+        for i, r in enumerate(res):
+            c = tdv.InstanceResultC()
+            tc = tdv.to_colmajor16(r["T"])
+            for k in range(16): c.T[k] = float(tc[k])
+            c.fitness = float(r["fitness"]); c.rmse = float(ang[i])   # the rmse slot carries the angle to the ground truth
+            c.coarse_fitness = float(r["coarse_fitness"]); c.coarse_inliers = int(r["coarse_inliers"]); c.icp_iterations = int(r["icp_iterations"])
+            c.n_points = int(r["n_points"]); c.n_voxels = int(r["n_voxels"]); c.status = int(r["status"])
+            local.append(c)
+        allc = ctx.gather_results(comm, local, B, world)
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        assert len(allc) == B * world and all(a.status >= 0 for a in allc)
+        angles = np.array([a.rmse for a in allc], np.float32); n_results = len(allc)
+        sharding.rccl_comm_destroy(comm)
+    else:
+        local = np.stack([sharding.encode_result(r["T"], r["fitness"], ang[i], r["coarse_inliers"]) for i, r in enumerate(res)])
+        allres = sharding.gather_results(local, B * world, cdev)      # slot 17 carries the angle to the ground truth instead of the rmse
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        angles = allres[:, 17] if rank == 0 else None; n_results = len(allres) if rank == 0 else 0
+    if rank != 0:
+        return None, True
+    elapsed = float(tt.item())
+    share = float((angles <= c5.MAX_ANGLE).mean())
+    out = dict(config="C5: %d GPU(s) x %d instances, each rank one %dx%d frame cut by a uint16 label image (scene cloud %d points) vs one %d-pt model broadcast once"
+                      % (world, B, wl["sc"]["width"], wl["sc"]["height"], int(sum(r["n_points"] for r in res)), nm),
+               n_gpus=world, instances=B * world, wall_s=elapsed, instances_per_s=B * world / elapsed, per_gpu_instances_per_s=B / t_local,
+               model_bcast_ms=bcast_ms, gather_ms=gather_ms, results_gathered=n_results, registered_share=share,
+               collectives="tdv_broadcast_model + tdv_gather_results (C ABI) on an ncclComm_t over RCCL" if c_abi else
+                           ("torch.distributed (%s)" % dist.get_backend() if world > 1 else "none (one rank)"),
+               max_angle_rad=c5.MAX_ANGLE, median_angle_to_gt_rad=float(np.median(angles)), scaling="weak")
+    return out, share >= 0.88
+
+
+def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev=None):
+    out, ok = tray_share(tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev, args.instances_per_gpu, args.hyps, args.icp_iters,
+                         c_abi=False if args.torch_collectives else None)
     if rank == 0:
-        elapsed = float(tt.item()); angles = allres[:, 17]
-        share = float((angles <= c5.MAX_ANGLE).mean())
-        ok = share >= 0.88
-        print(json.dumps(dict(config="C5: %d GPU(s) x %d instances, each rank one %dx%d frame cut by a uint16 label image (scene cloud %d points) vs one %d-pt model broadcast once"
-                                     % (world, B, wl["sc"]["width"], wl["sc"]["height"], int(sum(r["n_points"] for r in res)), nm),
-                              n_gpus=world, instances=B * world, wall_s=elapsed, instances_per_s=B * world / elapsed, per_gpu_instances_per_s=B / t_local,
-                              model_bcast_ms=bcast_ms, gather_ms=gather_ms, results_shape=list(allres.shape), registered_share=share,
-                              max_angle_rad=c5.MAX_ANGLE, median_angle_to_gt_rad=float(np.median(angles)), scaling="weak")))
+        print(json.dumps(out))
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
@@ -87,6 +132,7 @@ def main():
     ap.add_argument("--icp-iters", type=int, default=50)
     ap.add_argument("--voxel-px", type=float, default=1.2)
     ap.add_argument("--max-angle", type=float, default=1e-2)
+    ap.add_argument("--torch-collectives", action="store_true", help="tray workload: move the model and the results with torch.distributed instead of the C ABI's collectives")
     args = ap.parse_args()
     launch = importlib.import_module("3dvision_amd.launch")
     if args.gpus > 1 and not launch.in_rendezvous():      # same self-launch as bench.py: the parent never touches HIP
