@@ -7,8 +7,10 @@
 //   PointCloud GPUPointCloud::generate(depth, rgb, fx,fy,cx,cy)  src/gpu_impl.cpp:69-128
 //   bool    GPURegistration::isCudaAvailable()                   src/gpu_impl.cpp:131-139
 //   RegistrationResult GPURegistration::icpRefine(...)           src/gpu_impl.cpp:141-260
-// NOT COMPILED IN THIS REPOSITORY'S CI: the image has neither Eigen nor OpenCV.  The same calls are
-// exercised through ../tdv_registration.cpp (layout-compatible plain types) on the GPU box.
+// Not BUILT in this repository (the image has neither Eigen nor OpenCV); PARSED by tests/test_adapter_syntax.py against the
+// reference's own headers (g++ -fsyntax-only -Werror, stand-in Eigen / cv::Mat declarations): a signature that drifts from
+// include/gpu_depth.hpp / include/gpu_registration.hpp fails that test.  The same calls are exercised through
+// ../tdv_registration.cpp (layout-compatible plain types) on the GPU box.
 #include "gpu_depth.hpp"
 #include "gpu_registration.hpp"
 #include "tdv_hip.h"

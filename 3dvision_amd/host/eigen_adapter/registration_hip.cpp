@@ -3,7 +3,8 @@
 // src/pipeline.cpp (which calls them directly, :92-102, :291-294) runs the non-ICP stages on the GPU too.
 // Link EITHER src/registration.cpp OR this file: every static of the class is defined here, including
 // Registration::loadReferenceModel (registration.hpp:59, called at src/pipeline.cpp:284) on tdv_load_ply_ascii.
-// NOT COMPILED IN THIS REPOSITORY'S CI (no Eigen in the image); mirrors ../tdv_registration.cpp.
+// Not BUILT in this repository (no Eigen in the image); PARSED against include/registration.hpp by tests/test_adapter_syntax.py
+// (g++ -fsyntax-only -Werror with stand-in Eigen declarations); mirrors ../tdv_registration.cpp, which runs on the GPU box.
 #include "registration.hpp"
 #include "tdv_hip.h"
 
