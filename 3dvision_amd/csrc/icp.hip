@@ -608,174 +608,240 @@ void k_icp_accumulate(const float* __restrict__ src, int ns, int ns_pad,
 // (/root/reference/src/registration.cpp:340-341 n_corr and total_error, :353-354 ATA and ATb; point-to-point: the two means
 // :376-381, then the centred cross-covariance :383-386).  A float sum depends on its order, so the f64 tree above agrees with
 // it to ~1e-7 only - which once moved a translation by 1.27e-6 m on a 5-iteration C5 instance (round 3's log) and could, in
-// principle, flip the stopping rule |delta rmse| < 1e-6 (:406).  In this mode the sums ARE the reference's, bit for bit:
-//   k_icp_rows   one lane per source point evaluates its terms (the same expressions as k_icp_accumulate: J = [p x n | n],
-//                r = (p - q).n, products unfused) and stores them as ROWS, one row per accumulator: rows[k][i], zero where
-//                the point is not accepted (s + 0 == s for every float s a sum started at +0 can hold: it is never -0).
-//                The accepted COUNT is an integer and needs no order: ballot + one atomicAdd per wave.
-//   k_icp_fold_ref  ONE workgroup: lane k of wave 0 owns accumulator k and adds row k's entries in index order - a chain of
-//                n dependent v_add_f32, which is what "the reference's rounding" means; nothing shortens it.  All 16 waves
-//                stage the rows through LDS (global -> registers one tile ahead -> LDS, double buffered) so that the chain never
-//                waits for memory: per point it costs one add and a quarter of a 16-byte LDS read.  Then the same
-//                one-thread solve / update / stopping rule as the tree mode, on float sums.
-// Cost: the chain, ~n x 5-6 cycles (200k points: ~0.5 ms per iteration against 25 us for the tree) - a parity mode, selectable
-// per ctx like the search; the tree stays the default.
-constexpr int REF_NR_PLANE = 28;     // rows, point-to-plane: d2, 21 upper-triangular J^T J, 6 J^T r
-constexpr int REF_NR_POINT = 8;      // rows, point-to-point: d2, p.xyz, q.xyz, accepted (1 / 0)
-constexpr int REF_TILE = 512;        // points per LDS tile
+// principle, flip the stopping rule |delta rmse| < 1e-6 (:406).  In this mode the sums ARE the reference's, bit for bit.
+//
+// What bounds it: a sum in the reference's rounding is ONE chain of dependent float additions - lane k of one wave owns
+// accumulator k, and a wave issues a VALU instruction every 4 cycles whatever else the chip does.  Everything is arranged so
+// that this wave executes one v_add_f32 and a quarter of a 16-byte LDS read per ACCEPTED correspondence and nothing else:
+//   k_icp_flags / k_icp_scan_counts / k_icp_rows   (whole chip) the accepted correspondences, in source order, as dense 32-byte
+//                records {d2, J[6], r} resp. {d2, p, q}: block counts, their exclusive scan, then every block writes its
+//                records at its offset (order-preserving compaction: rejected points - 3 of 4 at the pipeline's 0.4-voxel
+//                threshold - cost the chain nothing).  n_corr is the scan's total.
+//   k_icp_fold_ref  ONE workgroup of 9 waves.  Waves 1-8 are loaders, one record slot per lane: they fetch tile t + 4 (512
+//                records) into a 3-deep register ring, expand tile t + 1 into the 28 per-accumulator term rows
+//                (J[a] * J[b], J[a] * r: the products the CPU forms, unfused) in LDS, double buffered; wave 0 adds tile t, lane
+//                k walking row k in order.  A first version streamed 28 precomputed floats per point: 924 us per fold at
+//                200k points, bound by what ONE CU can pull from HBM (~11 B per cycle, MI355X_MICROARCH.md) - hence the
+//                8-float records and the expansion on the CU.  Then the one-thread solve / update / stopping rule of the
+//                tree mode, on float sums.
+// Selectable per ctx like the search; the f64 tree stays the default.
+constexpr int REF_NR_PLANE = 28;     // term rows, point-to-plane: d2, 21 upper-triangular J^T J, 6 J^T r
+constexpr int REF_NR_POINT = 9;      // term rows, point-to-point: pass 0 d2, p.xyz, q.xyz (7); pass 1 the 9 centred products
+constexpr int REF_TILE = 512;        // records per LDS tile
 constexpr int REF_LD = REF_TILE + 4; // row pitch in LDS (floats): lane k's 16-byte reads start 4 banks after lane k-1's
+constexpr int REF_RING = 3;          // register stages of a loader lane (tiles in flight ahead of the expansion)
 
-// the terms of one source point (zeros unless accepted)
-template <int MODE>
-__device__ __forceinline__ void ref_terms(bool acc, float best, float px, float py, float pz,
-                                          const float* __restrict__ tgt, const float* __restrict__ tgt_normals, int idx,
-                                          float (&v)[MODE == 0 ? REF_NR_PLANE : REF_NR_POINT]) {
-    constexpr int NR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
+// nearest target of source i from the search's output: (best d2, index) - what k_icp_accumulate does in line
+__device__ __forceinline__ void resolve_nn(int i, int ns_pad, int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk, int direct,
+                                           const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
+                                           float px, float py, float pz, float& best, int& idx) {
+    best = FLT_MAX; int bc = 0;
+    for (int s = 0; s < nsplit; ++s) {
+        const float d = pd2[(size_t)s * ns_pad + i];
+        const int c = pchunk[(size_t)s * ns_pad + i];
+        if (d < best) { best = d; bc = c; }
+    }
+    idx = 0;
+    if (direct) idx = bc;
+    else if (best < FLT_MAX) {
+        idx = bc;
 #pragma unroll
-    for (int k = 0; k < NR; ++k) v[k] = 0.f;
-    if (!acc) return;
-    v[0] = best;
-    const float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
-    if (MODE == 0) {
-        const float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
-        const float J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
-        const float ex = px - qx, ey = py - qy, ez = pz - qz;
-        const float r = ex * nx + (ey * ny + ez * nz);
-        int k = 1;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b) v[k++] = J[a] * J[b];       // J[b] * J[a] is the same float: ATA stays symmetric bit for bit
-#pragma unroll
-        for (int a = 0; a < 6; ++a) v[k++] = J[a] * r;
-    } else {
-        v[1] = px; v[2] = py; v[3] = pz; v[4] = qx; v[5] = qy; v[6] = qz; v[7] = 1.f;
+        for (int t = NN_CH - 1; t >= 0; --t) {
+            const float dx = px - tx[bc + t], dy = py - ty[bc + t], dz = pz - tz[bc + t];
+            if (dx * dx + (dy * dy + dz * dz) == best) idx = bc + t;
+        }
     }
 }
 
-// rows[k][i] for i < row_pitch (a multiple of 256; entries from ns on are zero); *count += accepted points
+// accepted correspondences per block of 256 source points
+__global__ __launch_bounds__(256)
+void k_icp_flags(int ns, int ns_pad, int nsplit, const float* __restrict__ pd2, const IcpState* __restrict__ st, float tau_accept, int* __restrict__ cnt) {
+    if (st->done) return;
+    __shared__ int s_c;
+    if (threadIdx.x == 0) s_c = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float best = FLT_MAX;
+    if (i < ns) for (int s = 0; s < nsplit; ++s) best = fminf(best, pd2[(size_t)s * ns_pad + i]);
+    const unsigned long long m = __ballot(i < ns && best <= tau_accept);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&s_c, __popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0) cnt[blockIdx.x] = s_c;
+}
+
+// off[b] = cnt[0] + ... + cnt[b - 1], off[nblocks] = the total (n_corr); one workgroup, chunks of 1024 counts
+__global__ __launch_bounds__(1024)
+void k_icp_scan_counts(const int* __restrict__ cnt, int nblocks, const IcpState* __restrict__ st, int* __restrict__ off) {
+    if (st->done) return;
+    __shared__ int s_w[16], s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblocks; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const int c = b < nblocks ? cnt[b] : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int a = __shfl_up(inc, o, 64); if (lane >= o) inc += a; }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        int base = s_carry;
+        for (int w = 0; w < wave; ++w) base += s_w[w];
+        if (b < nblocks) off[b] = base + inc - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) off[nblocks] = s_carry;
+}
+
+// the accepted correspondences as records rec[2 * pos], rec[2 * pos + 1] (pos ascending with the source index):
+//   point-to-plane {d2, J0, J1, J2 | J3, J4, J5, r}     point-to-point {d2, px, py, pz | qx, qy, qz, 0}
 template <int MODE>
 __global__ __launch_bounds__(256)
-void k_icp_rows(const float* __restrict__ src, int ns, int ns_pad, int row_pitch,
+void k_icp_rows(const float* __restrict__ src, int ns, int ns_pad,
                 const float* __restrict__ tgt, const float* __restrict__ tgt_normals,
                 const float* __restrict__ tx, const float* __restrict__ ty, const float* __restrict__ tz,
                 int nsplit, const float* __restrict__ pd2, const int* __restrict__ pchunk, int direct,
-                const IcpState* __restrict__ st, float tau_accept, float* __restrict__ rows, int* __restrict__ count) {
+                const IcpState* __restrict__ st, float tau_accept, const int* __restrict__ off, float4* __restrict__ rec) {
     if (st->done) return;
-    constexpr int NR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
-    const int i = blockIdx.x * 256 + threadIdx.x;      // < row_pitch by the launch
-    float v[NR];
-    bool acc = false;
+    __shared__ int s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool acc = false; float best = FLT_MAX; int idx = 0; float px = 0.f, py = 0.f, pz = 0.f;
     if (i < ns) {
-        float px, py, pz;
         transform_point(st->T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
-        float best = FLT_MAX; int bc = 0;
-        for (int s = 0; s < nsplit; ++s) {
-            const float d = pd2[(size_t)s * ns_pad + i];
-            const int c = pchunk[(size_t)s * ns_pad + i];
-            if (d < best) { best = d; bc = c; }
-        }
-        int idx = 0;
-        if (direct) idx = bc;
-        else if (best < FLT_MAX) {
-            idx = bc;
-#pragma unroll
-            for (int t = NN_CH - 1; t >= 0; --t) {
-                const float dx = px - tx[bc + t], dy = py - ty[bc + t], dz = pz - tz[bc + t];
-                if (dx * dx + (dy * dy + dz * dz) == best) idx = bc + t;
-            }
-        }
+        resolve_nn(i, ns_pad, nsplit, pd2, pchunk, direct, tx, ty, tz, px, py, pz, best, idx);
         acc = best <= tau_accept;
-        ref_terms<MODE>(acc, best, px, py, pz, tgt, tgt_normals, idx, v);
-    } else {
-#pragma unroll
-        for (int k = 0; k < NR; ++k) v[k] = 0.f;
     }
-#pragma unroll
-    for (int k = 0; k < NR; ++k) rows[(size_t)k * row_pitch + i] = v[k];
     const unsigned long long m = __ballot(acc);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    if (!acc) return;
+    int pos = off[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_w[w];
+    const float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
+    if (MODE == 0) {
+        const float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
+        const float ex = px - qx, ey = py - qy, ez = pz - qz;
+        rec[2 * (size_t)pos] = make_float4(best, py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx);      // J = [p x n | n], registration.cpp:346-349
+        rec[2 * (size_t)pos + 1] = make_float4(nx, ny, nz, ex * nx + (ey * ny + ez * nz));                      // r = (p - q) . n, :351
+    } else {
+        rec[2 * (size_t)pos] = make_float4(best, px, py, pz);
+        rec[2 * (size_t)pos + 1] = make_float4(qx, qy, qz, 0.f);
+    }
 }
 
-// lane's running sum += the entries [0, m) of its LDS row, in order (m a multiple of 4)
+// lane's running sum += the entries [0, m) of its LDS row, in order (m a multiple of 4): REF_CHAIN_G x 16 bytes of LDS reads, then
+// 4 x REF_CHAIN_G dependent adds with the waits counted down (the compiler's schedule, checked in the ISA).  Reading one group
+// AHEAD of the adds (two register groups) was measured slower at every group size (173 us per fold at 200k points -> 237-325).
+#ifndef REF_CHAIN_G
+#define REF_CHAIN_G 8
+#endif
 __device__ __forceinline__ float ref_chain(float s, const float* __restrict__ row, int m) {
+    constexpr int G = REF_CHAIN_G;
     const float4* __restrict__ r4 = reinterpret_cast<const float4*>(row);
     int q = 0;
-    for (; q + 8 <= m / 4; q += 8) {
-        float4 a[8];
+    for (; q + G <= m / 4; q += G) {
+        float4 a[G];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = r4[q + j];
+        for (int j = 0; j < G; ++j) a[j] = r4[q + j];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s += a[j].x; s += a[j].y; s += a[j].z; s += a[j].w; }
+        for (int j = 0; j < G; ++j) { s += a[j].x; s += a[j].y; s += a[j].z; s += a[j].w; }
     }
     for (; q < m / 4; ++q) { const float4 a = r4[q]; s += a.x; s += a.y; s += a.z; s += a.w; }
     return s;
 }
 
+// the per-accumulator terms of one record into column `col` of an LDS tile (rows[k][col]); PASS 1 (point-to-point): centred products
+template <int MODE, int PASS>
+__device__ __forceinline__ void ref_expand(float (*rows)[REF_LD], int col, const float4 a, const float4 b, bool live, const float* __restrict__ means) {
+    if (MODE == 0) {
+        const float J[6] = {a.y, a.z, a.w, b.x, b.y, b.z};
+        rows[0][col] = a.x;
+        int k = 1;
+#pragma unroll
+        for (int u = 0; u < 6; ++u)
+#pragma unroll
+            for (int v = u; v < 6; ++v) rows[k++][col] = J[u] * J[v];       // J[v] * J[u] is the same float: ATA stays symmetric bit for bit
+#pragma unroll
+        for (int u = 0; u < 6; ++u) rows[k++][col] = J[u] * b.w;
+    } else if (PASS == 0) {
+        rows[0][col] = a.x; rows[1][col] = a.y; rows[2][col] = a.z; rows[3][col] = a.w; rows[4][col] = b.x; rows[5][col] = b.y; rows[6][col] = b.z;
+    } else {
+        const float P[3] = {a.y - means[0], a.z - means[1], a.w - means[2]}, Q[3] = {b.x - means[3], b.y - means[4], b.z - means[5]};
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) rows[u * 3 + v][col] = live ? P[u] * Q[v] : 0.f;      // registration.cpp:385 (a padding slot adds +0)
+    }
+}
+
+template <int MODE, int PASS>
+__device__ __forceinline__ float ref_fold_pass(const float4* __restrict__ rec, int n_corr, float (*buf)[REF_NR_PLANE][REF_LD], const float* __restrict__ means) {
+    constexpr int NSUM = MODE == 0 ? REF_NR_PLANE : (PASS == 0 ? 7 : 9);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool loader = wave >= 1;
+    const int slot = (int)threadIdx.x - 64;                   // a loader lane's record slot inside a tile
+    const int ntiles = (n_corr + REF_TILE - 1) / REF_TILE;
+    float ring[REF_RING][8];                                   // a loader lane's records in flight (compile-time indices only)
+    float s = 0.f;
+#define TDV_REF_ISSUE(X, D) do { const long long pos__ = (long long)(X) * REF_TILE + slot;                                                   \
+        float4 a__ = make_float4(0.f, 0.f, 0.f, 0.f), b__ = a__;           /* zeros past the end: their terms are +0 */                       \
+        if ((X) < ntiles && pos__ < n_corr) { a__ = rec[2 * pos__]; b__ = rec[2 * pos__ + 1]; }                                               \
+        ring[D][0] = a__.x; ring[D][1] = a__.y; ring[D][2] = a__.z; ring[D][3] = a__.w; ring[D][4] = b__.x; ring[D][5] = b__.y; ring[D][6] = b__.z; ring[D][7] = b__.w; } while (0)
+#define TDV_REF_EXPAND(X, D) do { if ((X) < ntiles) ref_expand<MODE, PASS>(buf[(X) & 1], slot, make_float4(ring[D][0], ring[D][1], ring[D][2], ring[D][3]),   \
+        make_float4(ring[D][4], ring[D][5], ring[D][6], ring[D][7]), (long long)(X) * REF_TILE + slot < n_corr, means); } while (0)
+    if (loader) {
+        TDV_REF_ISSUE(0, 0); TDV_REF_ISSUE(1, 1); TDV_REF_ISSUE(2, 2);
+        TDV_REF_EXPAND(0, 0);
+        TDV_REF_ISSUE(3, 0);
+    }
+    __syncthreads();
+    // period x: loaders expand tile x + 1 out of ring[(x + 1) % 3] and refill that stage with tile x + 4; wave 0 adds tile x.
+    // Unrolled by the ring's depth so that every register stage is a compile-time index.
+    static_assert(REF_RING == 3, "the period loop below is written for three stages");
+    for (int t = 0; t < ntiles; t += REF_RING) {
+        if (loader) { TDV_REF_EXPAND(t + 1, 1); TDV_REF_ISSUE(t + 4, 1); }
+        else if (wave == 0 && lane < NSUM && t < ntiles) s = ref_chain(s, buf[t & 1][lane], (min(REF_TILE, n_corr - t * REF_TILE) + 3) & ~3);
+        __syncthreads();
+        if (loader) { TDV_REF_EXPAND(t + 2, 2); TDV_REF_ISSUE(t + 5, 2); }
+        else if (wave == 0 && lane < NSUM && t + 1 < ntiles) s = ref_chain(s, buf[(t + 1) & 1][lane], (min(REF_TILE, n_corr - (t + 1) * REF_TILE) + 3) & ~3);
+        __syncthreads();
+        if (loader) { TDV_REF_EXPAND(t + 3, 0); TDV_REF_ISSUE(t + 6, 0); }
+        else if (wave == 0 && lane < NSUM && t + 2 < ntiles) s = ref_chain(s, buf[(t + 2) & 1][lane], (min(REF_TILE, n_corr - (t + 2) * REF_TILE) + 3) & ~3);
+        __syncthreads();
+    }
+#undef TDV_REF_ISSUE
+#undef TDV_REF_EXPAND
+    return s;
+}
+
 template <int MODE>
-__global__ __launch_bounds__(1024)
-void k_icp_fold_ref(const float* __restrict__ rows, int ns, int row_pitch, int* count, IcpState* st, int fixed_iterations) {
+__global__ __launch_bounds__(64 + REF_TILE)
+void k_icp_fold_ref(const float4* __restrict__ rec, const int* __restrict__ d_total, int ns, IcpState* st, int fixed_iterations) {
     if (st->done) return;
-    constexpr int NR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
-    constexpr int F4_PER_TILE = NR * REF_TILE / 4;
-    constexpr int PER = (F4_PER_TILE + 1023) / 1024;
-    __shared__ __attribute__((aligned(16))) float buf[2][NR][REF_LD];
+    __shared__ __attribute__((aligned(16))) float buf[2][REF_NR_PLANE][REF_LD];      // (point-to-point uses 9 of the 28 rows)
     __shared__ double tot[ACC_NV];
     __shared__ float means[6];
     __shared__ float solve_ws[56];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ntiles = (ns + REF_TILE - 1) / REF_TILE;
-    float4 reg[PER];
-    auto gload = [&](int t) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int e = threadIdx.x + q * 1024;
-            const int row = e / (REF_TILE / 4), c = (e % (REF_TILE / 4)) * 4;
-            const int p = t * REF_TILE + c;
-            reg[q] = (e < F4_PER_TILE && p < row_pitch) ? *reinterpret_cast<const float4*>(rows + (size_t)row * row_pitch + p) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto lstore = [&](int b) {
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int e = threadIdx.x + q * 1024;
-            const int row = e / (REF_TILE / 4), c = (e % (REF_TILE / 4)) * 4;
-            if (e < F4_PER_TILE) *reinterpret_cast<float4*>(&buf[b][row][c]) = reg[q];
-        }
-    };
+    const int n_corr = *d_total;
     if (threadIdx.x < ACC_NV) tot[threadIdx.x] = 0.0;
-    const int n_corr = *count;
-    // pass 0: the plain sums (point-to-plane: all 28; point-to-point: d2, p, q).  pass 1 (point-to-point only): the centred products.
-    constexpr int NPASS = MODE == 0 ? 1 : 2;
-    for (int pass = 0; pass < NPASS; ++pass) {
-        const int nsum = MODE == 0 ? REF_NR_PLANE : (pass == 0 ? 7 : 9);
-        float s = 0.f;
-        float ma = 0.f, mb = 0.f; int ra = 0, rb = 0;
-        if (MODE == 1 && pass == 1) { ra = 1 + lane / 3; rb = 4 + lane % 3; if (lane < 9) { ma = means[lane / 3]; mb = means[3 + lane % 3]; } }
-        gload(0); lstore(0);
-        __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            if (t + 1 < ntiles) gload(t + 1);
-            if (wave == 0 && lane < nsum) {
-                const int m = (min(REF_TILE, ns - t * REF_TILE) + 3) & ~3;
-                if (MODE == 0 || pass == 0) s = ref_chain(s, buf[t & 1][lane], m);
-                else {
-                    const float* __restrict__ A = buf[t & 1][ra]; const float* __restrict__ B = buf[t & 1][rb]; const float* __restrict__ F = buf[t & 1][7];
-                    for (int q = 0; q < m; ++q) { const float term = (A[q] - ma) * (B[q] - mb); s += F[q] != 0.f ? term : 0.f; }     // registration.cpp:385
-                }
-            }
-            if (t + 1 < ntiles) lstore((t + 1) & 1);
-            __syncthreads();
-        }
-        if (wave == 0 && lane < nsum) {
-            if (MODE == 0) tot[1 + lane] = (double)s;
-            else if (pass == 0) { if (lane == 0) tot[1] = (double)s; else means[lane - 1] = s / static_cast<float>(n_corr); }    // :380-381 (n_corr == 0: unused below)
-            else tot[8 + lane] = (double)s;
-        }
+    __syncthreads();
+    float s = ref_fold_pass<MODE, 0>(rec, n_corr, buf, means);
+    if (wave == 0) {
+        if (MODE == 0) { if (lane < REF_NR_PLANE) tot[1 + lane] = (double)s; }
+        else if (lane == 0) tot[1] = (double)s;
+        else if (lane < 7) means[lane - 1] = s / static_cast<float>(n_corr);          // registration.cpp:380-381 (n_corr < 3: unused below)
+    }
+    __syncthreads();
+    if (MODE == 1) {
+        s = ref_fold_pass<MODE, 1>(rec, n_corr, buf, means);
+        if (wave == 0 && lane < 9) tot[8 + lane] = (double)s;
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
-    *count = 0;      // ready for the next iteration's k_icp_rows (stream order)
     tot[0] = (double)n_corr;
     if (MODE == 1) for (int a = 0; a < 6; ++a) tot[2 + a] = (double)means[a];
     icp_update<MODE, true>(tot, ns, st, fixed_iterations, st->iter, st->rmse, st->T, solve_ws);
@@ -818,7 +884,7 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
     __shared__ float solve_ws[56];
     __shared__ IcpState st;
     constexpr int NRR = MODE == 0 ? REF_NR_PLANE : REF_NR_POINT;
-    __shared__ __attribute__((aligned(16))) float rrows[REF ? NRR : 1][REF ? REF_LD : 4];
+    __shared__ __attribute__((aligned(16))) float rrows[REF ? NRR : 1][REF_LD];
     __shared__ float rmeans[6];
     static_assert(!REF || SM_THREADS >= REF_TILE, "one point per thread and tile");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -872,43 +938,41 @@ void k_icp_small(const float* __restrict__ src0, int ns0, const int* __restrict_
         }
         __syncthreads();
         if constexpr (REF) {
-            // (b') the reference's sums: tiles of REF_TILE points - every thread writes its point's terms as LDS rows, lane k of wave 0
-            // adds row k in index order (k_icp_fold_ref's chain; the tile loop continues it from tile to tile)
+            // (b') the reference's sums: tiles of REF_TILE points - every thread expands its point's record into the per-accumulator term
+            // rows in LDS (k_icp_fold_ref's ref_expand; a rejected point's terms are +0: s + 0 == s), lane k of wave 0 adds row k in
+            // index order, the chain continuing from tile to tile
             int n_acc = 0;
             constexpr int NPASS = MODE == 0 ? 1 : 2;
             for (int pass = 0; pass < NPASS; ++pass) {
                 const int nsum = MODE == 0 ? REF_NR_PLANE : (pass == 0 ? 7 : 9);
-                float s = 0.f, ma = 0.f, mb = 0.f;
-                const int ra = 1 + (lane % 9) / 3, rb = 4 + lane % 3;
-                if (MODE == 1 && pass == 1 && lane < 9) { ma = rmeans[lane / 3]; mb = rmeans[3 + lane % 3]; }
+                float s = 0.f;
                 for (int base = 0; base < ns; base += REF_TILE) {
                     bool acc = false;
                     if (threadIdx.x < REF_TILE) {
                         const int i = base + threadIdx.x;
-                        float v[NRR];
+                        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
                         if (i < ns) {
-                            float px, py, pz;
-                            transform_point(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
                             const float best = sbest[i];
                             acc = best <= tau_accept;
-                            ref_terms<MODE>(acc, best, px, py, pz, tgt, tgt_normals, sidx[i], v);
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < NRR; ++k) v[k] = 0.f;
+                            if (acc) {
+                                float px, py, pz;
+                                transform_point(T, src[3 * i], src[3 * i + 1], src[3 * i + 2], px, py, pz);
+                                const int idx = sidx[i];
+                                const float qx = tgt[3 * idx], qy = tgt[3 * idx + 1], qz = tgt[3 * idx + 2];
+                                if (MODE == 0) {
+                                    const float nx = tgt_normals[3 * idx], ny = tgt_normals[3 * idx + 1], nz = tgt_normals[3 * idx + 2];
+                                    const float ex = px - qx, ey = py - qy, ez = pz - qz;
+                                    ra = make_float4(best, py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx);
+                                    rb = make_float4(nx, ny, nz, ex * nx + (ey * ny + ez * nz));
+                                } else { ra = make_float4(best, px, py, pz); rb = make_float4(qx, qy, qz, 0.f); }
+                            }
                         }
-#pragma unroll
-                        for (int k = 0; k < NRR; ++k) rrows[k][threadIdx.x] = v[k];
+                        if (pass == 0) ref_expand<MODE, 0>(rrows, threadIdx.x, ra, rb, acc, rmeans);
+                        else ref_expand<MODE, 1>(rrows, threadIdx.x, ra, rb, acc, rmeans);
                     }
                     const int c = __syncthreads_count(acc);
                     if (pass == 0) n_acc += c;
-                    if (wave == 0 && lane < nsum) {
-                        const int m = (min(REF_TILE, ns - base) + 3) & ~3;
-                        if (MODE == 0 || pass == 0) s = ref_chain(s, rrows[lane], m);
-                        else {
-                            const float* __restrict__ A = rrows[ra]; const float* __restrict__ Bq = rrows[rb]; const float* __restrict__ F = rrows[7];
-                            for (int q = 0; q < m; ++q) { const float term = (A[q] - ma) * (Bq[q] - mb); s += F[q] != 0.f ? term : 0.f; }
-                        }
-                    }
+                    if (wave == 0 && lane < nsum) s = ref_chain(s, rrows[lane], (min(REF_TILE, ns - base) + 3) & ~3);
                     __syncthreads();
                 }
                 if (wave == 0 && lane < nsum) {
@@ -1149,13 +1213,13 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     TDV_CHECK_LAUNCH(ctx);
     const bool p2pl = point_to_plane && d_tgt_normals;
     const int direct = pruned ? 1 : 0;
-    // reference-order accumulation: per-point rows + one-workgroup ordered fold instead of k_icp_accumulate
-    const int row_pitch = (int)align_up((size_t)ns, 256);
-    float* ref_rows = nullptr; int* ref_count = nullptr;
+    // reference-order accumulation: dense records of the accepted correspondences + one-workgroup ordered fold instead of k_icp_accumulate
+    const int ref_blocks = (ns + 255) / 256;
+    float4* ref_rec = nullptr; int *ref_cnt = nullptr, *ref_off = nullptr;
     if (ref_acc) {
-        TDV_TRY(ws_alloc(ctx, (size_t)(p2pl ? REF_NR_PLANE : REF_NR_POINT) * row_pitch, &ref_rows));
-        TDV_TRY(ws_alloc(ctx, 1, &ref_count));
-        TDV_HIP(ctx, hipMemsetAsync(ref_count, 0, sizeof(int), s));
+        TDV_TRY(ws_alloc(ctx, (size_t)2 * ns, &ref_rec));
+        TDV_TRY(ws_alloc(ctx, (size_t)ref_blocks, &ref_cnt));
+        TDV_TRY(ws_alloc(ctx, (size_t)ref_blocks + 1, &ref_off));
     }
     const GridEntry* gtable = cg.usable ? reinterpret_cast<const GridEntry*>(cg.table) : nullptr;
     const float4* gnode = cg.usable ? reinterpret_cast<const float4*>(cg.node) : nullptr;
@@ -1180,12 +1244,14 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
                                                             p.chunks_per_split, b.st, b.pd2, b.pchunk);
             }
             if (ref_acc) {
+                k_icp_flags<<<ref_blocks, 256, 0, s>>>(ns, p.ns_pad, p.nsplit, b.pd2, b.st, tau, ref_cnt);
+                k_icp_scan_counts<<<1, 1024, 0, s>>>(ref_cnt, ref_blocks, b.st, ref_off);
                 if (p2pl) {
-                    k_icp_rows<0><<<row_pitch / 256, 256, 0, s>>>(d_src, ns, p.ns_pad, row_pitch, d_tgt, d_tgt_normals, b.tx, b.ty, b.tz, p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, ref_rows, ref_count);
-                    k_icp_fold_ref<0><<<1, 1024, 0, s>>>(ref_rows, ns, row_pitch, ref_count, b.st, fixed_iterations);
+                    k_icp_rows<0><<<ref_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, d_tgt_normals, b.tx, b.ty, b.tz, p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, ref_off, ref_rec);
+                    k_icp_fold_ref<0><<<1, 64 + REF_TILE, 0, s>>>(ref_rec, ref_off + ref_blocks, ns, b.st, fixed_iterations);
                 } else {
-                    k_icp_rows<1><<<row_pitch / 256, 256, 0, s>>>(d_src, ns, p.ns_pad, row_pitch, d_tgt, nullptr, b.tx, b.ty, b.tz, p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, ref_rows, ref_count);
-                    k_icp_fold_ref<1><<<1, 1024, 0, s>>>(ref_rows, ns, row_pitch, ref_count, b.st, fixed_iterations);
+                    k_icp_rows<1><<<ref_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, nullptr, b.tx, b.ty, b.tz, p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, ref_off, ref_rec);
+                    k_icp_fold_ref<1><<<1, 64 + REF_TILE, 0, s>>>(ref_rec, ref_off + ref_blocks, ns, b.st, fixed_iterations);
                 }
             } else if (p2pl) {
 #define TDV_ACC1(MM, PP, NRM) k_icp_accumulate<MM, PP><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \

@@ -23,8 +23,9 @@
 // by (d2, idx), so its first k entries are the k nearest neighbours wherever it holds >= k; only the deficient
 // points go through the kNN search as a subset.
 // Per-point estimators run one lane per point with sequential sums in neighbour order, i.e. the same f32
-// expression trees as the CPU loops; atan2 is evaluated in f64 and rounded once.
+// expression trees as the CPU loops; atan2 is glibc's atan2f restated (libm_f32.hpp): the same theta, the same histogram bin.
 #include "tdv_internal.hpp"
+#include "libm_f32.hpp"
 #include "device_linalg.hpp"
 #include <cfloat>
 #include <climits>
@@ -476,7 +477,7 @@ constexpr int FP_MAXNN = 100;
 constexpr int FP_WAVES = FP_WAVES_VALUE;   // points (waves) per workgroup of k_spfh / k_fpfh
 
 // SPFH (registration.cpp:137-170), ONE WAVE PER POINT in curve order, one neighbour per lane: the pair features
-// (incl. the f64 atan2) are computed in parallel, and the histogram is counted with ballots — the CPU loop adds 1.0f
+// (incl. atan2f) are computed in parallel, and the histogram is counted with ballots — the CPU loop adds 1.0f
 // per pair, and sums of ones are exact in any order, so counting is the same arithmetic.
 __global__ __launch_bounds__(64 * FP_WAVES)
 void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, const int* __restrict__ order,
@@ -512,7 +513,7 @@ void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n,
                 float phi = ux * ex + (uy * ey + uz * ez);
                 float wn = wx * njx + (wy * njy + wz * njz);
                 float un = ux * njx + (uy * njy + uz * njz);
-                float theta = (float)atan2((double)wn, (double)un);
+                float theta = lm::atan2f_glibc(wn, un);      // glibc's atan2f, the function registration.cpp:154 calls (libm_f32.hpp)
                 bin_a = min(max((int)((alpha + 1.0f) * 5.5f), 0), 10);
                 bin_p = min(max((int)((phi + 1.0f) * 5.5f), 0), 10);
                 bin_t = min(max((int)(((double)theta / 3.14159265358979323846 + (double)1.0f) * (double)5.5f), 0), 10);
@@ -635,7 +636,7 @@ void k_spfh_pairs(const float* __restrict__ xyz, const float* __restrict__ nrm, 
                 float phi = ux * ex + (uy * ey + uz * ez);
                 float wn = wx * njx + (wy * njy + wz * njz);
                 float un = ux * njx + (uy * njy + uz * njz);
-                float theta = (float)atan2((double)wn, (double)un);
+                float theta = lm::atan2f_glibc(wn, un);      // glibc's atan2f, the function registration.cpp:154 calls (libm_f32.hpp)
                 bin_a = min(max((int)((alpha + 1.0f) * 5.5f), 0), 10);
                 bin_p = min(max((int)((phi + 1.0f) * 5.5f), 0), 10);
                 bin_t = min(max((int)(((double)theta / 3.14159265358979323846 + (double)1.0f) * (double)5.5f), 0), 10);

@@ -1,4 +1,6 @@
-// sinf / cosf as glibc 2.35 computes them on x86-64 (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h,
+// sinf / cosf / atanf / atan2f as glibc 2.35 computes them on x86-64.
+//
+// sinf / cosf (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h,
 // s_sincosf_data.c: the Arm "optimized routines" algorithm — a degree-7 / degree-8 polynomial in DOUBLE on [-pi/4, pi/4],
 // rounded once to float; below 2^-12 the argument itself resp. 1).
 //
@@ -100,6 +102,81 @@ TDV_LIBM_HD float cosf_glibc(float y) {
         return sincos_poly(x * s, x * x, n ^ 1, (m & 2) != 0);
     }
     return (float)cos((double)y);
+}
+
+// ---- atanf / atan2f: glibc's sysdeps/ieee754/flt-32/s_atanf.c and e_atan2f.c (the fdlibm float algorithms: argument reduction
+// to [0, 7/16) around atan(0.5), atan(1), atan(1.5), atan(inf) kept as hi + lo floats, an odd / even split degree-11 polynomial; atan2f =
+// atanf(|y / x|) moved to the quadrant with pi - (z - pi_lo)).  FLOAT arithmetic throughout - glibc 2.35 has no FMA variant of
+// these two on x86-64 - so every operation below must stay an IEEE single-precision operation in this order: the file is compiled
+// with -ffp-contract=off and correctly rounded division.  Why the product restates them: the reference's SPFH bins
+// theta = atan2(w . n_j, u . n_j) (/root/reference/src/registration.cpp:154-160) and a last-bit difference in theta can move a pair
+// into the neighbouring histogram bin - integer work.  Checked against the running libm by tests/test_libm_restatement.py:
+// atanf on all 2^32 floats and atan2f on 3e8 pairs (uniform bit patterns, uniform values, near-unit vectors): 0 differences on glibc 2.35.
+TDV_LIBM_HD float f32_from_bits(uint32_t u) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(u);
+#else
+    float f; std::memcpy(&f, &u, 4); return f;
+#endif
+}
+
+TDV_LIBM_HD float atanf_glibc(float x) {
+    const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f, aT4 = 9.0908870101e-02f,
+                aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f, aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f,
+                aT10 = 1.6285819933e-02f;
+    const int32_t hx = (int32_t)f32_bits(x), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {                                  // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;                   // NaN
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {                                   // |x| < 0.4375
+        if (ix < 0x31000000) return x;                       // |x| < 2^-29
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {                               // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }     // 7/16 <= |x| < 11/16
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }                            // 11/16 <= |x| < 19/16
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }     // |x| < 2.4375
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const float s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float hi = id == 0 ? atanhi[0] : id == 1 ? atanhi[1] : id == 2 ? atanhi[2] : atanhi[3];
+    const float lo = id == 0 ? atanlo[0] : id == 1 ? atanlo[1] : id == 2 ? atanlo[2] : atanlo[3];
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+
+TDV_LIBM_HD float atan2f_glibc(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const int32_t hx = (int32_t)f32_bits(x), ix = hx & 0x7fffffff, hy = (int32_t)f32_bits(y), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;   // NaN
+    if (hx == 0x3f800000) return atanf_glibc(y);            // x = 1
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);      // 2 * sign(x) + sign(y)
+    if (iy == 0) { if (m < 2) return y; return m == 2 ? pi + tiny : -pi - tiny; }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) return m == 0 ? pi_o_4 + tiny : m == 1 ? -pi_o_4 - tiny : m == 2 ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+        return m == 0 ? 0.0f : m == 1 ? -0.0f : m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;                  // |y / x| > 2^60
+    else if (hx < 0 && k < -60) z = 0.0f;                   // |y| / x < -2^60
+    else z = atanf_glibc(fabsf(y / x));
+    if (m == 0) return z;
+    if (m == 1) return f32_from_bits(f32_bits(z) ^ 0x80000000u);
+    if (m == 2) return pi - (z - pi_lo);
+    return (z - pi_lo) - pi;
 }
 
 }  // namespace lm

@@ -43,7 +43,7 @@ def test_c1_features_ransac_icp(ctx, orc, synth, demo):
     assert ref_n.tobytes() == ref_n_o.tobytes()
     ref_f_o = orc.compute_fpfh(ref, ref_n_o, VOXEL * 5.0)
     ref_f = ctx.compute_fpfh(ref, ref_n, VOXEL * 5.0)
-    assert np.abs(ref_f - ref_f_o).max() < 1e-6
+    assert ref_f.tobytes() == ref_f_o.tobytes()
     # scene side (32,129 points): normals + FPFH on the GPU, the oracle on a 4,000-point prefix sample
     # would change neighbourhoods, so the oracle runs the full cloud too (O(N^2), ~20 s of host time)
     src_n_o, knn_o = orc.estimate_normals(src, 30, want_knn=True)
@@ -54,7 +54,7 @@ def test_c1_features_ransac_icp(ctx, orc, synth, demo):
     assert np.array_equal(cnt, cnt_o) and np.array_equal(nb, nb_o)
     same = (src_f.view(np.uint32) == src_f_o.view(np.uint32)).all(1)
     print("C1 scene FPFH rows bitwise equal: %d / %d" % (same.sum(), len(src)))
-    assert same.mean() > 0.995
+    assert same.all()                    # glibc's atan2f on the device (round 4): no bin can differ
     # feature correspondences from identical descriptors
     corr_o = orc.feature_match(src_f_o, ref_f_o)
     corr = ctx.feature_match(src_f_o, ref_f_o)
