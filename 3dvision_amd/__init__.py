@@ -30,7 +30,10 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib3dvision_hip.so")
+# TDV_LIB_VARIANT=study (tests marked `study`, tools/studies): the -DTDV_STUDY build, which keeps the A/B variants that lost their
+# measurement and the tuning knobs (csrc/tdv_internal.hpp: study_env).  Anything else: the product library.
+STUDY_BUILD = os.environ.get("TDV_LIB_VARIANT") == "study"
+LIB_PATH = os.path.join(_HERE, "lib3dvision_hip_study.so" if STUDY_BUILD else "lib3dvision_hip.so")
 
 TDV_MASK_THRESHOLD10 = 0
 TDV_MASK_NONZERO = 1

@@ -1,4 +1,6 @@
-"""Build lib3dvision_hip.so (hand-written HIP for gfx950 + the extern "C" dispatch layer).
+"""Build lib3dvision_hip.so (hand-written HIP for gfx950 + the extern "C" dispatch layer) and, beside it, lib3dvision_hip_study.so:
+the same sources with -DTDV_STUDY, which keeps the A/B variants that lost their measurement and the tuning knobs (csrc/tdv_internal.hpp:
+study_env).  The study library is test / tools infrastructure: the package loads it only when TDV_LIB_VARIANT=study.
 
 hipcc cross-compiles without a GPU.  The library is built IN-TREE (3dvision_amd/lib3dvision_hip.so)
 so that it travels to the GPU box with the repo snapshot.
@@ -19,7 +21,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(SRC, "_obj")
+OBJ_STUDY = os.path.join(SRC, "_obj_study")
 LIB = os.path.join(HERE, "lib3dvision_hip.so")
+LIB_STUDY = os.path.join(HERE, "lib3dvision_hip_study.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function",
@@ -37,35 +41,44 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(job):
+    src, obj_dir, extra = job
+    obj = os.path.join(obj_dir, src[:-4] + ".o")
     headers = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "tdv_hip.h")]
     if not _stale(obj, [os.path.join(SRC, src)] + headers + [os.path.abspath(__file__)]):
         return obj, ""
-    r = subprocess.run([HIPCC] + FLAGS + ["-c", os.path.join(SRC, src), "-o", obj], capture_output=True, text=True)
+    r = subprocess.run([HIPCC] + FLAGS + extra + ["-c", os.path.join(SRC, src), "-o", obj], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr))
     return obj, r.stderr
 
 
-def build(verbose=False, jobs=6):
-    os.makedirs(OBJ, exist_ok=True)
+def _link(lib, objs):
+    if _stale(lib, objs):
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-lz", "-ldl"], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stderr)
+
+
+def build(verbose=False, jobs=6, study=True):
+    """Returns the path of the product library; study=True also builds lib3dvision_hip_study.so (-DTDV_STUDY)."""
+    variants = [(OBJ, [], LIB)] + ([(OBJ_STUDY, ["-DTDV_STUDY"], LIB_STUDY)] if study else [])
     srcs = _sources()
+    for d, _, _ in variants:
+        os.makedirs(d, exist_ok=True)
+    work = [(s, d, extra) for d, extra, _ in variants for s in srcs]
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        results = list(ex.map(_compile, srcs))
-    objs = [o for o, _ in results]
+        results = list(ex.map(_compile, work))
     if verbose:
         for _, err in results:
             if err.strip():
                 sys.stderr.write(err)
-    # drop objects of sources that no longer exist
-    for f in os.listdir(OBJ):
-        if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
-            os.remove(os.path.join(OBJ, f))
-    if _stale(LIB, objs):
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-ldl"], capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("link failed:\n" + r.stderr)
+    for d, _, lib in variants:
+        objs = [o for o, _ in results if os.path.dirname(o) == d]
+        for f in os.listdir(d):          # drop objects of sources that no longer exist
+            if f.endswith(".o") and os.path.join(d, f) not in objs:
+                os.remove(os.path.join(d, f))
+        _link(lib, objs)
     return LIB
 
 

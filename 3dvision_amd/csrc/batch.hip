@@ -75,7 +75,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     (void)d_bgr;  // colours do not enter the registration chain (voxelDownsample keeps them, nothing downstream reads them)
     // the model's descriptors are packed once; every instance, on either lane, searches the same read-only index
     FmIndex model_index; bool have_index = false;
-    if (n_model >= 2048 && !getenv("TDV_FM_BRUTE") && !getenv("TDV_FM_KEYORDER")) {
+    if (n_model >= 2048 && !getenv("TDV_FM_BRUTE") && !study_env("TDV_FM_KEYORDER")) {
         TDV_TRY(fm_index_build(ctx, d_model_fpfh, n_model, &model_index));
         have_index = true;
     }
@@ -94,7 +94,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
             have_sorted = true;
         }
     }
-    const bool coherent_stages = !(getenv("TDV_BATCH_COHERENT") && atoi(getenv("TDV_BATCH_COHERENT")) == 0);   // A/B knob (read per call: the tests switch it)
+    const bool coherent_stages = !(study_env("TDV_BATCH_COHERENT") && atoi(study_env("TDV_BATCH_COHERENT")) == 0);   // A/B knob (read per call: the tests switch it)
     // voxels of ALL instances in first-occurrence order with one memset + two launches (voxel.hip, hash-table path); a lane then
     // only finishes its instance's reference order.  A voxel too full for the table's member rows (a very coarse grid) sends the
     // whole batch back to per-instance calls.
@@ -107,7 +107,7 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     int* d_voff = nullptr;                                      // voxel offsets of the instances on the device (n_instances + 2 ints)
     bool batched_voxel = false;
     const int total_pts = off[n_instances];
-    if (batched_voxel_env && total_pts > 0 && !getenv("TDV_VOXEL_LEGACY") && !getenv("TDV_VOXEL_SORT")) {
+    if (batched_voxel_env && total_pts > 0 && !study_env("TDV_VOXEL_LEGACY") && !study_env("TDV_VOXEL_SORT")) {
         TDV_TRY(ws_alloc(ctx, (size_t)total_pts * 3, &vox_first_all));
         if (want_ref) { TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_rank_all)); TDV_TRY(ws_alloc(ctx, (size_t)total_pts, &vox_leaders_all)); }
         int* d_off_inst;

@@ -223,7 +223,7 @@ int tdv_ctx_set_icp_search(tdv_ctx* ctx, int mode) {
 }
 
 int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode) {
-    if (!ctx || (mode != TDV_RANSAC_SCORE_FAST && mode != TDV_RANSAC_SCORE_EXACT && mode != TDV_RANSAC_SCORE_MATRIX)) return TDV_ERR_BAD_ARG;
+    if (!ctx || (mode != TDV_RANSAC_SCORE_FAST && mode != TDV_RANSAC_SCORE_EXACT && !(tdv::kStudyBuild && mode == TDV_RANSAC_SCORE_MATRIX))) return TDV_ERR_BAD_ARG;   // MATRIX: study build only
     ctx->ransac_score_mode = mode;
     return TDV_OK;
 }

@@ -151,6 +151,7 @@ constexpr int FMP_BUCKETS = 1 << (2 * FMP_KEY_BITS);   // 16384 (64 KB of LDS co
 constexpr int FMP_BOX = 64;
 constexpr int FMP_TWO_KEYS_MAX_TARGETS = 32768;
 
+#ifdef TDV_STUDY
 __device__ __forceinline__ int fm_bucket(const float* __restrict__ f, int two_keys) {
     // key 1: the three centre bins (descriptors sum to 1, so it lies in [0, 1]); key 2: the first moment of the phi
     // sub-histogram (in [0, 10]).  two_keys: FMP_KEY_BITS bits each, interleaved (a 128 x 128 Morton grid) — measured
@@ -175,9 +176,11 @@ __device__ __forceinline__ int fm_bucket(const float* __restrict__ f, int two_ke
     for (int i = 0; i < FMP_KEY_BITS; ++i) m |= (((a >> i) & 1u) << (2 * i + 1)) | (((c >> i) & 1u) << (2 * i));
     return (int)m;
 }
+#endif  // TDV_STUDY
 // Real descriptors crowd a few buckets, so both passes count in an LDS histogram first (one global atomic per
 // non-empty bucket and workgroup instead of one per row).
 constexpr int FMP_SORT_BLOCK = 1024;
+#ifdef TDV_STUDY
 __global__ __launch_bounds__(FMP_SORT_BLOCK)
 void k_fm_hist(const float* __restrict__ f, int n, int two_keys, int* __restrict__ bucket_of, int* __restrict__ hist) {
     __shared__ int h[FMP_BUCKETS];
@@ -192,6 +195,7 @@ void k_fm_hist(const float* __restrict__ f, int n, int two_keys, int* __restrict
     __syncthreads();
     for (int b = threadIdx.x; b < FMP_BUCKETS; b += FMP_SORT_BLOCK) if (h[b]) atomicAdd(&hist[b], h[b]);
 }
+#endif  // TDV_STUDY
 __global__ __launch_bounds__(FMP_SORT_BLOCK)
 void k_fm_scatter(const int* __restrict__ bucket_of, int n, const int* __restrict__ start, int* __restrict__ cursor,
                   int* __restrict__ perm) {
@@ -206,6 +210,7 @@ void k_fm_scatter(const int* __restrict__ bucket_of, int n, const int* __restric
     __syncthreads();
     if (i < n) perm[start[b] + h[b] + local] = i;   // order inside a bucket is irrelevant to the result
 }
+#ifdef TDV_STUDY
 __global__ void k_fm_gather_targets(const float* __restrict__ ft, const int* __restrict__ perm, int nt, int nt_pad,
                                     float* __restrict__ T, int* __restrict__ torig) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,6 +227,7 @@ __global__ void k_fm_boxes(const float* __restrict__ T, int nt, int nbox, float*
     for (int r = b * FMP_BOX; r < min(nt, (b + 1) * FMP_BOX); ++r) { float v = T[(size_t)r * FD + d]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
     bmin[e] = mn; bmax[e] = mx;
 }
+#endif  // TDV_STUDY
 
 // The set bit of m nearest to position c, the higher one on a tie (the inside-out order c, c+1, c-1, c+2, ... restricted to
 // the set bits), or -1: two shifts, a find-first and a count-leading on the wave's scalar unit instead of walking the
@@ -243,6 +249,7 @@ __device__ __forceinline__ int visit_inside_out(int v, int c, int nbox) {
     return R > L ? c + (v - m) : c - (v - m);
 }
 
+#ifdef TDV_STUDY
 template <int SPL>
 __global__ __launch_bounds__(FM_BLOCK)
 void k_feature_match_pruned(const float* __restrict__ fs, const int* __restrict__ sperm, int ns, int ns_pad,
@@ -321,8 +328,10 @@ __global__ void k_feature_match_combine_lex(int ns, int ns_pad, int nparts, cons
     }
     corr[i] = bj == INT_MAX ? 0 : bj;   // nothing finite: the CPU loop keeps its initial index 0
 }
+#endif  // TDV_STUDY
 
 namespace {
+#ifdef TDV_STUDY
 // counting sort of n descriptors by key bucket: perm (ordered position -> row) and, optionally, the bucket starts
 int fm_order(tdv_ctx* ctx, const float* d_f, int n, int two_keys, int* perm, int* start /* FMP_BUCKETS + 1 */) {
     hipStream_t s = ctx->stream;
@@ -340,9 +349,11 @@ int fm_order(tdv_ctx* ctx, const float* d_f, int n, int two_keys, int* perm, int
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
+#endif  // TDV_STUDY
 
 constexpr int FMP_SPL = 1;   // 1 measured better than 2 (C4: 0.84 vs 0.93 ms)
 
+#ifdef TDV_STUDY
 int feature_match_keyorder_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
     hipStream_t s = ctx->stream;
     const int nt_pad = (int)align_up((size_t)nt, FMP_BOX);
@@ -375,6 +386,7 @@ int feature_match_keyorder_dev(tdv_ctx* ctx, const float* d_fs, int ns, const fl
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
 }
+#endif  // TDV_STUDY
 }  // namespace
 
 // ---- packed target index -----------------------------------------------------------------------------------------
@@ -1716,9 +1728,9 @@ static int launch_fm_query(tdv_ctx* ctx, const FmTables& t, const FmIndex& ix, i
     // tuning knobs.  The leaf budget of pass A was 32 while a leaf cost what it did in the middle of round 2; with the packed
     // arithmetic and the scalar-side savings a wave is better off opening up to 128 leaves itself than handing over early
     // (143k x 151k relief part 0.81 -> 0.73 ms, cuboid 200k x 200k 4.05 -> 2.04 ms, random rows 100k x 100k 16.8 -> 17.7 ms)
-    static const int leaf_limit = getenv("TDV_FM_LIMIT") ? atoi(getenv("TDV_FM_LIMIT")) : 128;
-    static const int heavy_groups = getenv("TDV_FM_HEAVY") ? atoi(getenv("TDV_FM_HEAVY")) : 8;
-    const bool stats = getenv("TDV_FM_STATS") != nullptr;   // study knob: counts of box tests and leaf openings, printed to stderr
+    static const int leaf_limit = study_env("TDV_FM_LIMIT") ? atoi(study_env("TDV_FM_LIMIT")) : 128;
+    static const int heavy_groups = study_env("TDV_FM_HEAVY") ? atoi(study_env("TDV_FM_HEAVY")) : 8;
+    const bool stats = study_env("TDV_FM_STATS") != nullptr;   // study knob: counts of box tests and leaf openings, printed to stderr
     unsigned long long* d_stats = nullptr;
     if (stats) {
         TDV_TRY(ws_alloc(ctx, 12, &d_stats));
@@ -1805,11 +1817,11 @@ static int launch_fm_leafmajor(tdv_ctx* ctx, const FmTables& t, const FmIndex& i
     // round 0: every source against its home leaf.  The search order is sorted by home leaf, so it IS the sorted pair list.
     L[0] = LmLists{nullptr, nullptr, zeroed + 2 * per_round, home_hist, nullptr, nullptr, 0, INT_MAX, leaf_start, unit_start, unit_leaf, const_cast<int*>(t.sperm), keys, (int)unit_cap};
     unsigned long long* d_stats = nullptr;
-    if (getenv("TDV_FM_STATS")) { TDV_TRY(ws_alloc(ctx, 16, &d_stats)); TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, s)); }
-    static const int eval_blocks = getenv("TDV_LM_EVAL_BLOCKS") ? atoi(getenv("TDV_LM_EVAL_BLOCKS")) : 4096;   // tuning knob (a multiple of 8; 1024 / 2048 / 4096 / 8192: 0.51 / 0.49 / 0.477 / 0.478 ms at 143k x 151k)
+    if (study_env("TDV_FM_STATS")) { TDV_TRY(ws_alloc(ctx, 16, &d_stats)); TDV_HIP(ctx, hipMemsetAsync(d_stats, 0, 128, s)); }
+    static const int eval_blocks = study_env("TDV_LM_EVAL_BLOCKS") ? atoi(study_env("TDV_LM_EVAL_BLOCKS")) : 4096;   // tuning knob (a multiple of 8; 1024 / 2048 / 4096 / 8192: 0.51 / 0.49 / 0.477 / 0.478 ms at 143k x 151k)
     // One round of box tests after the home leaves (12.1 pairs per source at 143k x 151k).  TDV_LM_ROUNDS=2: the home groups first, the
     // other groups with the bounds those left (9.7 pairs per source, but a second set of launches: 0.525 against 0.487 ms).
-    const char* rounds_env = getenv("TDV_LM_ROUNDS");
+    const char* rounds_env = study_env("TDV_LM_ROUNDS");
     const int rounds = (ix.ngroup > 1 && rounds_env && atoi(rounds_env) == 2) ? 2 : 1;
     k_lm_plan<false><<<1, 1024, 0, s>>>(L[0], nleaf);
     k_lm_eval<true><<<eval_blocks, 64 * LM_WAVES, 0, s>>>(t, L[0]);
@@ -1873,7 +1885,7 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
     k_fm_bucket_hist<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, hist);
     TDV_TRY(exclusive_scan_dev(ctx, hist, FMP_BUCKETS, start, d_total));
     k_fm_scatter<<<sblocks, FMP_SORT_BLOCK, 0, s>>>(bucket_of, ns, start, cursor, sperm);
-    static const int force_k = getenv("TDV_FM_K") ? atoi(getenv("TDV_FM_K")) : 0;   // tuning knob (sources per wave)
+    static const int force_k = study_env("TDV_FM_K") ? atoi(study_env("TDV_FM_K")) : 0;   // tuning knob (sources per wave)
     const int k = force_k ? force_k : 2;
     float* fs2 = nullptr;
     const char* lm = getenv("TDV_FM_LEAFMAJOR");                  // A/B knob, read per call: 0 = round 2's walk (k_fm_query) for everything
@@ -1891,9 +1903,11 @@ int feature_match_indexed_dev(tdv_ctx* ctx, const float* d_fs, int ns, const FmI
         k_fm_interleave_rows<<<(unsigned)((n2 + 255) / 256), 256, 0, s>>>(d_fs, sperm, ns, kk, fs2);
     }
     FmTables t{d_fs, sperm, home, ns, fs2, ix.T, ix.torig, ix.nleaf, ix.ngroup, ix.lbox, ix.gbox, ix.pbox, ix.gpbox, sp, ix.amax, amax_s, ix.pscale};
+#ifdef TDV_STUDY
     if (k >= 4) return launch_fm_query<4>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
-    if (k >= 2) return launch_fm_query<2>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
-    return launch_fm_query<1>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
+    if (k < 2) return launch_fm_query<1>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);
+#endif
+    return launch_fm_query<2>(ctx, t, ix, overflow_count, overflow_list, overflow_src, part_d, part_j, d_corr);      // two sources per wave (1 and 4: measured slower, study build)
 }
 
 int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
@@ -1903,14 +1917,17 @@ int feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft
     if (nt == 0) { TDV_HIP(ctx, hipMemsetAsync(d_corr, 0, (size_t)ns * 4, s)); return TDV_OK; }
     ctx->last_fm_path = TDV_FM_PATH_SCAN;
     const char* brute = getenv("TDV_FM_BRUTE");         // A/B knobs: same results every way
-    const char* keyorder = getenv("TDV_FM_KEYORDER");
+    const char* keyorder = study_env("TDV_FM_KEYORDER");
     if (!brute && ns >= 4096 && nt >= 2048) {
-        if (keyorder) return feature_match_keyorder_dev(ctx, d_fs, ns, d_ft, nt, d_corr);
+#ifdef TDV_STUDY
+        if (keyorder) return feature_match_keyorder_dev(ctx, d_fs, ns, d_ft, nt, d_corr);      // round 1's key-ordered pruned scan
+#endif
+        (void)keyorder;
         FmIndex ix;
         TDV_TRY(fm_index_build(ctx, d_ft, nt, &ix));
         return feature_match_indexed_dev(ctx, d_fs, ns, ix, d_corr);
     }
-    static const bool early = getenv("TDV_FM_NO_EARLY_EXIT") == nullptr;   // A/B knob: same results either way
+    static const bool early = study_env("TDV_FM_NO_EARLY_EXIT") == nullptr;   // A/B knob: same results either way
     const int ns_pad = (int)align_up((size_t)ns, FM_SRC_PER_BLOCK);
     const int blocks_x = ns_pad / FM_SRC_PER_BLOCK;
     // part 0: the first n_seed targets in one split (its exact best seeds the bound of every later split)

@@ -1082,9 +1082,9 @@ NnPlan make_plan(int ns, int nt) {
     p.nsplit = std::max(1, std::min(std::min(want, max_split), 64));
     p.chunks_per_split = (p.n_chunks + p.nsplit - 1) / p.nsplit;
     p.nsplit = (p.n_chunks + p.chunks_per_split - 1) / p.chunks_per_split;
-    static const int ppt_env = getenv("TDV_ICP_PPT") ? atoi(getenv("TDV_ICP_PPT")) : 0;
+    static const int ppt_env = study_env("TDV_ICP_PPT") ? atoi(study_env("TDV_ICP_PPT")) : 0;
     // only 1, 2, 4 and 8 points per thread are instantiated (TDV_ACC below); anything else would size the grid for a kernel that is never launched
-    p.acc_ppt = (ppt_env == 1 || ppt_env == 2 || ppt_env == 4 || ppt_env == 8) ? ppt_env : 4;   // 4: make_plan's default; the brute-force path uses 1
+    p.acc_ppt = (kStudyBuild && (ppt_env == 1 || ppt_env == 2 || ppt_env == 4 || ppt_env == 8)) ? ppt_env : 4;   // 4: make_plan's default; the brute-force path uses 1
     p.acc_blocks = (ns + 256 * p.acc_ppt - 1) / (256 * p.acc_ppt);
     return p;
 }
@@ -1131,7 +1131,7 @@ int cell_grid_build(tdv_ctx* ctx, const float* d_tgt, int nt, float thr, CellGri
     const int* h = reinterpret_cast<const int*>(ctx->pin);
     const int bad = h[0], cells = h[1];
     g->table = table; g->node = node; g->mask = (unsigned)(size - 1); g->shift = 64 - log2; g->inv_cell = inv_cell;
-    static const int max_per_cell = getenv("TDV_GRID_MAX_PER_CELL") ? atoi(getenv("TDV_GRID_MAX_PER_CELL")) : GRID_MAX_PER_CELL;   // tuning knob
+    static const int max_per_cell = study_env("TDV_GRID_MAX_PER_CELL") ? atoi(study_env("TDV_GRID_MAX_PER_CELL")) : GRID_MAX_PER_CELL;   // tuning knob
     g->usable = (!bad && cells > 0 && (long long)nt <= (long long)max_per_cell * cells) ? 1 : 0;
     return TDV_OK;
 }
@@ -1163,7 +1163,7 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
     ctx->last_icp_search = cg.usable ? TDV_ICP_SEARCH_GRID : (pruned ? TDV_ICP_SEARCH_PRUNED : TDV_ICP_SEARCH_BRUTE);
     NnPlan p = make_plan(ns, nt);
     if (pruned) p.nsplit = 1;
-    else if (!getenv("TDV_ICP_PPT")) { p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256; }   // measured: 50k x 10k brute 7.6k vs 6.4k iters/s
+    else if (!study_env("TDV_ICP_PPT")) { p.acc_ppt = 1; p.acc_blocks = (ns + 255) / 256; }   // measured: 50k x 10k brute 7.6k vs 6.4k iters/s
     const bool ref_acc = ctx->icp_accumulate == TDV_ICP_ACCUMULATE_REFERENCE;
     TDV_TRY(pin_reserve(ctx, 2 * sizeof(IcpState)));
     IcpState* h = reinterpret_cast<IcpState*>(ctx->pin);
@@ -1256,7 +1256,11 @@ int icp_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt, co
             } else if (p2pl) {
 #define TDV_ACC1(MM, PP, NRM) k_icp_accumulate<MM, PP><<<p.acc_blocks, 256, 0, s>>>(d_src, ns, p.ns_pad, d_tgt, NRM, b.tx, b.ty, b.tz, \
                                    p.nsplit, b.pd2, b.pchunk, direct, b.st, tau, fixed_iterations, b.slabs, b.ticket, nullptr, nullptr, nullptr)
+#ifdef TDV_STUDY
 #define TDV_ACC(MM, NRM) do { if (p.acc_ppt == 8) TDV_ACC1(MM, 8, NRM); else if (p.acc_ppt == 4) TDV_ACC1(MM, 4, NRM); else if (p.acc_ppt == 2) TDV_ACC1(MM, 2, NRM); else TDV_ACC1(MM, 1, NRM); } while (0)
+#else
+#define TDV_ACC(MM, NRM) do { if (p.acc_ppt == 4) TDV_ACC1(MM, 4, NRM); else TDV_ACC1(MM, 1, NRM); } while (0)     // (2 and 8 points per thread: study build)
+#endif
                 TDV_ACC(0, d_tgt_normals);
             } else {
                 TDV_ACC(1, nullptr);

@@ -476,6 +476,7 @@ constexpr int FP_MAXNN = 100;
 #endif
 constexpr int FP_WAVES = FP_WAVES_VALUE;   // points (waves) per workgroup of k_spfh / k_fpfh
 
+#ifdef TDV_STUDY
 // SPFH (registration.cpp:137-170), ONE WAVE PER POINT in curve order, one neighbour per lane: the pair features
 // (incl. atan2f) are computed in parallel, and the histogram is counted with ballots — the CPU loop adds 1.0f
 // per pair, and sums of ones are exact in any order, so counting is the same arithmetic.
@@ -530,7 +531,9 @@ void k_spfh(const float* __restrict__ xyz, const float* __restrict__ nrm, int n,
     if (sum > 0.f) v /= sum;
     if (lane < 33) spfh[(size_t)i * 33 + lane] = v;
 }
+#endif  // TDV_STUDY
 
+#ifdef TDV_STUDY
 // FPFH (registration.cpp:176-197), ONE WAVE PER POINT in curve order: lane d < 33 owns bin d and adds
 // w_r * spfh[j_r][d] for r = 0, 1, ... in list order (the CPU loop's order per bin); every step reads one 132-byte
 // row coalesced, and the four points of a workgroup are spatial neighbours, so most rows come from L1/L2.
@@ -591,6 +594,7 @@ void k_fpfh(const float* __restrict__ xyz, int n, const int* __restrict__ order,
     if (sum > 0.f) v /= sum;
     if (lane < 33) desc[(size_t)i * 33 + lane] = v;
 }
+#endif  // TDV_STUDY
 
 // SPFH with TWO POINTS PER WAVE (round 3; the default): k_spfh gives a point's ~81 neighbours two passes of 64 lanes, the second
 // a quarter full.  Here a wave owns two points and lays their neighbour lists end to end over its lanes (three passes for ~162
@@ -745,7 +749,7 @@ int spatial_sort(tdv_ctx* ctx, const float* d_xyz, int n, const ScanPlan& p, Sor
     TDV_TRY(ws_alloc(ctx, (size_t)pad, &so.orig));
     TDV_TRY(ws_alloc(ctx, (size_t)n, &bucket_of));
     // a few buckets per point for a surface sample (most cells of the grid are empty)
-    static const int per_point = getenv("TDV_MORTON_BUCKETS_PER_POINT") ? atoi(getenv("TDV_MORTON_BUCKETS_PER_POINT")) : 8;
+    static const int per_point = study_env("TDV_MORTON_BUCKETS_PER_POINT") ? atoi(study_env("TDV_MORTON_BUCKETS_PER_POINT")) : 8;
     int bits = 12;
     while (bits < MORTON_MAX_BUCKET_BITS && (1ll << bits) < (long long)per_point * n) bits += 1;
     const int nbuckets = 1 << bits;
@@ -843,11 +847,17 @@ int fpfh_from_lists(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, in
     float* spfh;
     TDV_TRY(ws_alloc(ctx, (size_t)n * 33, &spfh));
     hipStream_t s = ctx->stream;
-    const char* pairs_env = getenv("TDV_FPFH_PAIRS");       // A/B knob, read per call: 0 = one point per wave (k_spfh, k_fpfh)
-    if (!(pairs_env && atoi(pairs_env) == 0)) k_spfh_pairs<<<(n + 2 * FP_WAVES - 1) / (2 * FP_WAVES), 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
-    else k_spfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
-    if (!(pairs_env && atoi(pairs_env) == 0)) k_fpfh_pairs<<<(n + 2 * FP2_WAVES - 1) / (2 * FP2_WAVES), 64 * FP2_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
-    else k_fpfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
+#ifdef TDV_STUDY
+    const char* pairs_env = study_env("TDV_FPFH_PAIRS");       // study build, read per call: 0 = one point per wave (k_spfh, k_fpfh: measured slower, 0.94-0.99 vs 0.87-0.92 ms at 200k)
+    if (pairs_env && atoi(pairs_env) == 0) {
+        k_spfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
+        k_fpfh<<<(n + FP_WAVES - 1) / FP_WAVES, 64 * FP_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
+    } else
+#endif
+    {
+        k_spfh_pairs<<<(n + 2 * FP_WAVES - 1) / (2 * FP_WAVES), 64 * FP_WAVES, 0, s>>>(d_xyz, d_normals, n, order, nbr, cnt, spfh);
+        k_fpfh_pairs<<<(n + 2 * FP2_WAVES - 1) / (2 * FP2_WAVES), 64 * FP2_WAVES, 0, s>>>(d_xyz, n, order, nbr, cnt, spfh, d_desc, d_nbr);
+    }
     TDV_CHECK_LAUNCH(ctx);
     if (d_nbr_cnt) TDV_HIP(ctx, hipMemcpyAsync(d_nbr_cnt, cnt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return TDV_OK;

@@ -243,13 +243,13 @@ struct ScoreJob {
 };
 // One block of hypotheses (lane = hypothesis `base`, -1: none) over the chunks [c0, c1) of the point pairs; returns the lane's
 // inlier count, adds the chunks the wave scored twice to n_rescored (wave-uniform).
-// FINE: the band test and the exact re-scoring per PAIR of points instead of per chunk of eight.  On the headline's clouds a wave
-// re-scores 5 % of its chunks and the coarser test is cheaper; on the batch's small clouds - half of whose hypotheses are decent, so
-// that some of a wave's 512 tests per chunk nearly always sit at the threshold - it re-scored 49 % of the chunks (k_rb_score, C5).
+// (A finer band test - per PAIR of points instead of per chunk of eight - was built for the batch's small clouds, half of whose
+// hypotheses are decent, so that some of a wave's 512 tests per chunk nearly always sit at the threshold and 49 % of the chunks are
+// re-scored (k_rb_score, C5): the share stayed at 49 % and the pass got slower, 2.52 against 2.30 ms.  Removed in round 4.)
 // ADAPT: a wave that had to re-score three of its first eight chunks stops trying the FMA pass and scores the rest of its range with
 // the reference arithmetic alone (28 ops per test instead of 16.6 + 28: cheaper from a re-scoring share of 0.4 on).  Measured on C5:
 // per-chunk band test 2.30 ms, per-pair band test 2.52 ms (the share stays at 49 % even for 128 tests), adaptive exact: see k_rb_score.
-template <bool FINE = false, bool ADAPT = false>
+template <bool ADAPT = false>
 __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, const int h_pad, const int base, const float* __restrict__ pq2,
                                                 const int c0, const int c1, const float tau, unsigned& n_rescored) {
     v2f r[12];
@@ -278,25 +278,12 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
             // d2_fma - mid as one chain ending in -mid: its own rounding, at most 3 u mid = 1.5 u s in distance, sits inside
             // the 3.7 u A + 4 u s that the band's E keeps in reserve over the proven bound
             const v2f t = fma2(dx, dx, fma2(dy, dy, fma2(dz, dz, nmid)));
-            if (!FINE) m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));            // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
+            m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));            // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
             sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.x), 31);      // sgn = sgn << 1 | sign(t.x)
             sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.y), 31);
-            if (FINE) {
-                const float m2 = fminf(fabsf(t.x), fabsf(t.y));
-                // (a NaN hypothesis: m2 is NaN, half is NaN: the pair is re-scored and counts nothing, as the exact arithmetic would)
-                if (__any(!(m2 >= half))) {     // some lane of the wave is inside its band (or has none): the reference arithmetic decides this pair
-                    ++n_rescored;
-                    const v2f x = (r[0] * px + (r[3] * py + r[6] * pz)) + r[9];
-                    const v2f y = (r[1] * px + (r[4] * py + r[7] * pz)) + r[10];
-                    const v2f z = (r[2] * px + (r[5] * py + r[8] * pz)) + r[11];
-                    const v2f ex = x - qx, ey = y - qy, ez = z - qz;
-                    const v2f d2 = ex * ex + (ey * ey + ez * ez);
-                    sgn = (sgn & ~3u) | ((d2.x < tau) ? 2u : 0u) | ((d2.y < tau) ? 1u : 0u);   // the two bits just shifted in
-                }
-            }
         }
         cf = __popc(sgn);
-        if (!FINE && __any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
+        if (__any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
             ++n_rescored;
             cf = 0;
 #pragma unroll
@@ -458,6 +445,7 @@ __global__ void k_ransac_select(const int4* __restrict__ triples, int count, con
     if (keep) list[at + __popcll(m & ((1ull << lane) - 1ull))] = h;
 }
 
+#ifdef TDV_STUDY
 // ------------------------------------------------------------------ scoring on the matrix cores (A/B variant, not the default)
 // R p + t is a [3H x 4] x [4 x N] product, so the transform can run on the matrix cores (v_mfma_f32_32x32x2_f32, twice for
 // K = 4 with a row of ones under the points for t) and leave the vector ALUs the subtraction of q, the squared norm and the
@@ -625,6 +613,8 @@ void k_ransac_score_mfma(const float* __restrict__ hyp, int h_pad, const float* 
 }
 
 // error sum of one hypothesis (column-major R in T[0..8], t in T[9..11]) over all points
+#endif  // TDV_STUDY
+
 __global__ __launch_bounds__(256)
 void k_ransac_rmse_partial(const float* __restrict__ pq, int ns, const float* __restrict__ hyp12, float tau,
                            double* __restrict__ slabs) {
@@ -703,21 +693,25 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     const float sqrt_tau = std::nextafter((float)std::sqrt((double)tau), INFINITY);
     static const bool score_exact_env = getenv("TDV_RANSAC_SCORE") && !strcmp(getenv("TDV_RANSAC_SCORE"), "exact");
     const bool score_fast = !score_exact_env && ctx->ransac_score_mode != TDV_RANSAC_SCORE_EXACT;
-    static const bool score_mfma_env = getenv("TDV_RANSAC_SCORE") && !strcmp(getenv("TDV_RANSAC_SCORE"), "mfma");
-    const bool score_mfma = score_fast && (score_mfma_env || ctx->ransac_score_mode == TDV_RANSAC_SCORE_MATRIX);
+    const bool score_mfma_env = study_env("TDV_RANSAC_SCORE") && !strcmp(study_env("TDV_RANSAC_SCORE"), "mfma");
+    const bool score_mfma = kStudyBuild && score_fast && (score_mfma_env || ctx->ransac_score_mode == TDV_RANSAC_SCORE_MATRIX);   // study build only
     static const bool bailout_env_off = getenv("TDV_RANSAC_BAILOUT") && atoi(getenv("TDV_RANSAC_BAILOUT")) == 0;   // A/B knob
     // RansacPlan; short calls run as one batch without it (C4's 10,000 iterations: a short first batch was tried for them and lost
     // 2 % - their best fitness is 0.1-0.2, so at most a fifth of the points could be left out)
     const bool bailout = score_fast && !score_mfma && !trace_inliers && !bailout_env_off && max_iterations > 16384;
     int* d_state = d_bad + 8;                       // [0] best count known so far
     int* d_plan[2] = {d_bad + 10, d_bad + 28};   // per batch buffer: phase-1 chunks, survivors, largest prefix count, chunks per workgroup
-    static const int drop_permille = getenv("TDV_RANSAC_DROP_PERMILLE") ? atoi(getenv("TDV_RANSAC_DROP_PERMILLE")) : 100;   // tuning knob
-    float* pq2 = nullptr; float* pq3 = nullptr;
+    const int drop_permille = study_env("TDV_RANSAC_DROP_PERMILLE") ? atoi(study_env("TDV_RANSAC_DROP_PERMILLE")) : 100;   // tuning knob (5 to 100 measured equal)
+    float* pq2 = nullptr;
+#ifdef TDV_STUDY
+    float* pq3 = nullptr;
     const int n_rec = (ns + 127) / 128;
     if (score_mfma) {
         TDV_TRY(ws_alloc(ctx, (size_t)n_rec * RM_REC_FLOATS, &pq3));
         k_pack_pq3<<<n_rec, 256, 0, s>>>(pq, ns_pad, n_rec, pq3);
-    } else {
+    } else
+#endif
+    {
         TDV_TRY(ws_alloc(ctx, (size_t)ns_pad * 6, &pq2));
         k_pack_pq2<<<(ns_pad / 2 + 255) / 256, 256, 0, s>>>(pq, ns_pad, pq2);
     }
@@ -810,6 +804,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                                                                  (score_mfma ? 24.f : 16.f) * 5.9604644775390625e-08f);
         const int hb = (int)(align_up((size_t)cnt, RS_HYP_PER_BLOCK) / RS_HYP_PER_BLOCK);
         {   // TDV_TIMER_RANSAC_SCORE brackets every dispatch of a scoring kernel on its own
+#ifdef TDV_STUDY
             if (score_mfma) {
                 ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
                 const int groups = (cnt + RM_HPW - 1) / RM_HPW, gblocks = (groups + RM_WAVES - 1) / RM_WAVES;
@@ -819,7 +814,9 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                 k_ransac_score_mfma<<<dim3(gblocks, splits), 64 * RM_WAVES, 0, s>>>(hyp[q], h_pad, pq3, n_rec, rec_per_split, tau, counts[q], d_rescored);
                 wave_chunks += (double)gblocks * RM_WAVES * 4.0 * (double)n_rec;
             }
-            else if (score_fast) {
+            else
+#endif
+            if (score_fast) {
                 const int ps = ranges_for(hb);
                 if (bailout) {
                     // One dispatch per batch: its phase 1 (job A) and, behind it, phase 2 of the batch before (job B).  The plan
@@ -835,7 +832,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                     }
                     // survivors of this batch: the in-batch bound first (largest prefix count), then the list; the prefix counts
                     // also raise the best known for the batches after this one
-                    const bool merge_on = getenv("TDV_RANSAC_MERGE") && atoi(getenv("TDV_RANSAC_MERGE")) == 1;     // (read per call: the tests switch it)
+                    const bool merge_on = study_env("TDV_RANSAC_MERGE") && atoi(study_env("TDV_RANSAC_MERGE")) == 1;     // (study build; read per call: the tests switch it)
                     k_ransac_best<<<(cnt + 1023) / 1024, 1024, 0, s>>>(d_tri[q], cnt, counts[q], d_plan[q] + 2);
                     k_ransac_select<<<(cnt + 255) / 256, 256, 0, s>>>(d_tri[q], cnt, counts[q], ns, confidence, d_state, d_plan[q], d_list[q]);
                     // (merged mode only: phase 2 comes a dispatch later, the prefix counts raise the bound for the batch in between;
@@ -1049,7 +1046,7 @@ void k_rb_score(const float* __restrict__ hyp, int h_pad, const float* __restric
     const int base = blockIdx.y * RS_BLOCK + threadIdx.x;
     const int chunks = (pos_off[b + 1] - pos_off[b]) / RS_PCH;
     unsigned n_rescored = 0;
-    const int cnt = score_range_fast<false, true>(hyp + (size_t)b * 14 * h_pad, h_pad, base, pq2 + (size_t)pos_off[b] * 6, 0, chunks, tau, n_rescored);
+    const int cnt = score_range_fast<true>(hyp + (size_t)b * 14 * h_pad, h_pad, base, pq2 + (size_t)pos_off[b] * 6, 0, chunks, tau, n_rescored);
     counts[(size_t)b * h_pad + base] = cnt;
     // statistics only (tdv_ctx_last_ransac_rescore): two atomics per workgroup
     __shared__ unsigned s_rescored;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "tdv_hip.h"
@@ -71,6 +72,20 @@ inline int set_err(tdv_ctx* ctx, hipError_t e, const char* what, int line) {
 #define TDV_CHECK_LAUNCH(ctx) TDV_HIP((ctx), hipGetLastError())
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Study build (-DTDV_STUDY -> lib3dvision_hip_study.so, used by tools/studies/ and by the tests marked `study`): keeps the A/B
+// variants that LOST their measurement (the matrix-core scoring pass, the merged scoring dispatch, round 1's key-ordered descriptor
+// scan, one-point-per-wave SPFH / FPFH, the full bitonic voxel sort, ...) and the tuning knobs, all behind study_env().  In the
+// product library study_env() is the constant nullptr: every branch behind it is dead code the compiler drops, and the kernels
+// only those branches launch are not compiled at all (#ifdef TDV_STUDY).  What stays a real getenv() is what a deployer or a
+// parity test of a LIVE path needs.
+#ifdef TDV_STUDY
+inline const char* study_env(const char* name) { return getenv(name); }
+constexpr bool kStudyBuild = true;
+#else
+constexpr const char* study_env(const char*) { return nullptr; }
+constexpr bool kStudyBuild = false;
+#endif
 
 #ifdef __HIPCC__
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS crossbar traffic, unlike __shfl_down): the result is

@@ -644,7 +644,7 @@ static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float*
     k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vcnt, members, voxel_of, overflow);
     // (measured, us per call one pass / split: 184k points in pixel order 65 / 76; random order 250k 82 / 74, 500k 138 / 103, 1M 233 / 160, 4M 858 / 550;
     //  256 clouds of 184k 8,100 / 4,400 - tools/studies/voxel_split_threshold.py)
-    static const int split_from = getenv("TDV_VOXEL_SPLIT_FROM") ? atoi(getenv("TDV_VOXEL_SPLIT_FROM")) : 224;   // tiles; tuning knob
+    static const int split_from = study_env("TDV_VOXEL_SPLIT_FROM") ? atoi(study_env("TDV_VOXEL_SPLIT_FROM")) : 224;   // tiles; tuning knob
     if (tiles < split_from)
         k_vh_finalize<0><<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vcnt, members, desc, ticket,
                                                     d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, nullptr, nullptr);
@@ -774,7 +774,7 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
     if (both && (order != TDV_VOXEL_ORDER_REFERENCE || !both->first_xyz || !both->ref2first || !both->first2ref)) return TDV_ERR_BAD_ARG;
     *n_out = 0;
     if (n == 0) return TDV_OK;
-    const bool legacy = getenv("TDV_VOXEL_LEGACY") != nullptr || getenv("TDV_VOXEL_SORT") != nullptr;   // A/B knobs: the counting-sort path / the full sort (read per call: the tests switch it)
+    const bool legacy = study_env("TDV_VOXEL_LEGACY") != nullptr || study_env("TDV_VOXEL_SORT") != nullptr;   // A/B knobs: the counting-sort path / the full sort (read per call: the tests switch it)
     if (legacy) return voxel_downsample_impl(ctx, d_xyz, d_rgb, n, voxel, order, d_out_xyz, d_out_rgb, capacity, n_out, false, both);
     // hash-table path (memset + 2 kernels); first-occurrence order lands in the caller's buffer directly
     hipStream_t s = ctx->stream;
@@ -1024,7 +1024,7 @@ static int voxel_downsample_impl(tdv_ctx* ctx, const float* d_xyz, const float* 
     TDV_TRY(ws_alloc(ctx, 1, &d_total));
     TDV_TRY(pin_reserve(ctx, 64));
     ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
-    static const bool force_sort = getenv("TDV_VOXEL_SORT") != nullptr;   // A/B knob: the full bitonic sort
+    static const bool force_sort = study_env("TDV_VOXEL_SORT") != nullptr;   // A/B knob: the full bitonic sort
     bool hashed = !force_sort && !full_sort;
     int* d_too_big = nullptr;
     float *mean_xyz = nullptr, *mean_rgb = nullptr;     // hashed path: means parked at their leader's input index
@@ -1102,7 +1102,7 @@ int voxel_reference_order(tdv_ctx* ctx, int v, int n, const int4* d_leaders, con
     int* order_pinned = reinterpret_cast<int*>(ctx->pin + pin_order_off);
     TDV_HIP(ctx, hipMemcpyAsync(ctx->pin, d_leaders, (size_t)v * sizeof(int4), hipMemcpyDeviceToHost, s));
     TDV_HIP(ctx, hipStreamSynchronize(s));
-    const bool real_map = !TDV_HAVE_LIBSTDCXX_EMULATION || getenv("TDV_VOXEL_REAL_MAP") != nullptr;   // A/B knob: a real std::unordered_map instead of the emulation
+    const bool real_map = !TDV_HAVE_LIBSTDCXX_EMULATION || study_env("TDV_VOXEL_REAL_MAP") != nullptr;   // A/B knob: a real std::unordered_map instead of the emulation
     const auto t_host0 = std::chrono::steady_clock::now();
     int n_first = 0;
     struct { int* p; int* n; void push_back(int x) { p[(*n)++] = x; } } order_first{order_pinned, &n_first};

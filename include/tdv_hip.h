@@ -85,8 +85,9 @@ int tdv_ctx_set_icp_accumulation(tdv_ctx* ctx, int mode);
  * reference's arithmetic only (registration.cpp:270-279). */
 #define TDV_RANSAC_SCORE_FAST 0
 #define TDV_RANSAC_SCORE_EXACT 1
-#define TDV_RANSAC_SCORE_MATRIX 2 /* A/B variant: the transform on the matrix cores (f32 MFMA), same band scheme, same counts; measured
-                                   * slower than FAST — env TDV_RANSAC_SCORE=mfma selects it too */
+#define TDV_RANSAC_SCORE_MATRIX 2 /* A/B variant kept in the STUDY library only (lib3dvision_hip_study.so): the transform on the
+                                   * matrix cores (f32 MFMA), same band scheme, same counts; measured slower than FAST.  The product
+                                   * library returns TDV_ERR_BAD_ARG for it */
 int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode);
 /* Statistics of the last tdv_ransac* call on this ctx: the fraction of (wave, 8-point chunk) pairs the FAST pass scored a
  * second time with the reference arithmetic (-1 if the call ran in EXACT mode or none has run). */

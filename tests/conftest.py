@@ -11,6 +11,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "study: exercises an A/B variant that only the -DTDV_STUDY library holds (lib3dvision_hip_study.so, loaded with "
+                                       "TDV_LIB_VARIANT=study); skipped on the product library, run by tests/test_gpu_study_build.py in a process of its own")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests marked `study` need the study library: skip them unless this process loaded it."""
+    if os.environ.get("TDV_LIB_VARIANT") == "study":
+        return
+    skip = pytest.mark.skip(reason="needs lib3dvision_hip_study.so (TDV_LIB_VARIANT=study): run by tests/test_gpu_study_build.py")
+    for item in items:
+        if "study" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -65,6 +65,7 @@ def test_fpfh(ctx, orc, synth, n, radius):
     assert same.all(), "rows differing: %d of %d" % ((~same).sum(), n)
 
 
+@pytest.mark.study
 @pytest.mark.parametrize("n", [1, 2, 3, 65, 1001])
 def test_fpfh_two_points_per_wave_equals_one(ctx, orc, synth, n):
     """k_spfh_pairs / k_fpfh_pairs (a wave owns two points; the default) against the one-point-per-wave kernels

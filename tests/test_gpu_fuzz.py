@@ -129,7 +129,8 @@ def test_feature_match_leaf_major_fuzz(ctx, orc):
         ft[17, 0] = np.nan; ft[18, 3] = np.inf                                            # never chosen
         got = {}
         try:
-            for name, knob, value in (("leaf-major", None, None), ("two rounds", "TDV_LM_ROUNDS", "2"), ("walk", "TDV_FM_LEAFMAJOR", "0"), ("scan", "TDV_FM_BRUTE", "1")):
+            study = os.environ.get("TDV_LIB_VARIANT") == "study"        # (the two-round variant lives in the study library; elsewhere the knob is inert)
+            for name, knob, value in (("leaf-major", None, None), ("two rounds", "TDV_LM_ROUNDS" if study else None, "2"), ("walk", "TDV_FM_LEAFMAJOR", "0"), ("scan", "TDV_FM_BRUTE", "1")):
                 if knob:
                     os.environ[knob] = value
                 got[name] = ctx.feature_match(fs, ft)

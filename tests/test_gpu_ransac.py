@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+STUDY_BUILD = os.environ.get("TDV_LIB_VARIANT") == "study"      # the library with the A/B variants that lost (matrix-core scoring, merged dispatch, key-ordered scan)
 
 
 def _case(synth, ns, nt, seed=42, good_frac=0.5):
@@ -122,7 +123,9 @@ def _both_modes(ctx, *a, **k):
         e = ctx.ransac(*a, **k); assert ctx.last_ransac_rescore() == -1.0
         ctx.set_ransac_score("fast")
         f = ctx.ransac(*a, **k); share = ctx.last_ransac_rescore()
-        # and the matrix-core variant of the fast pass (csrc/ransac.hip, k_ransac_score_mfma: an A/B kernel, same band scheme)
+        # and the matrix-core variant of the fast pass (csrc/ransac.hip, k_ransac_score_mfma: an A/B kernel kept in the study library, same band scheme)
+        if not STUDY_BUILD:
+            return e, f, share
         ctx.set_ransac_score("matrix")
         m = ctx.ransac(*a, **k); share_m = ctx.last_ransac_rescore()
         assert 0.0 <= share_m <= 1.0
@@ -309,7 +312,8 @@ def test_feature_match_four_paths_on_relief_descriptors(ctx, tdv, orc, synth):
     ft[200, 0] = np.nan; ft[201, 5] = np.inf     # rows that are never chosen
     ref = orc.feature_match(fs, ft)
     try:
-        for knob, value in ((None, None), ("TDV_FM_LEAFMAJOR", "0"), ("TDV_FM_KEYORDER", "1"), ("TDV_FM_BRUTE", "1")):
+        paths = ((None, None), ("TDV_FM_LEAFMAJOR", "0"), ("TDV_FM_BRUTE", "1")) + ((("TDV_FM_KEYORDER", "1"),) if tdv.STUDY_BUILD else ())   # (key-ordered scan: study library)
+        for knob, value in paths:
             if knob:
                 os.environ[knob] = value
             got = ctx.feature_match(fs, ft)
@@ -369,12 +373,13 @@ def test_ransac_bailout_returns_the_reference_result(ctx, orc, synth, ns, nt, it
     got = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence)
     scored = ctx.last_ransac_scored()
     _same_result(got, ref); _same_result(traced, ref)
-    try:                                  # phase 2 riding behind the next batch's phase 1 (one dispatch per batch): same result
-        os.environ["TDV_RANSAC_MERGE"] = "1"
-        _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence), ref)
-        assert 0.0 < ctx.last_ransac_scored() <= 1.0          # (its plans see other bounds: the share differs, the result does not)
-    finally:
-        os.environ.pop("TDV_RANSAC_MERGE", None)
+    if STUDY_BUILD:
+        try:                              # phase 2 riding behind the next batch's phase 1 (one dispatch per batch; study library): same result
+            os.environ["TDV_RANSAC_MERGE"] = "1"
+            _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=confidence), ref)
+            assert 0.0 < ctx.last_ransac_scored() <= 1.0          # (its plans see other bounds: the share differs, the result does not)
+        finally:
+            os.environ.pop("TDV_RANSAC_MERGE", None)
     print("ns %d, %d iterations, confidence %g: %.3f of the tests scored, best %d inliers at %d" % (ns, iters, confidence, scored, got.inliers, got.best_iteration))
     assert 0.0 < scored <= 1.0
     if ns >= 2500 and good >= 0.5 and confidence > 1.0 and iters > 16384: assert scored < 0.95      # the scheme does something where it can
@@ -455,10 +460,11 @@ def test_ransac_bailout_in_batch_rule_planted_jump(ctx, orc, seed):
         got = ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence)))
         scored = ctx.last_ransac_scored()
         _same_result(got, ref)
-        try:
-            os.environ["TDV_RANSAC_MERGE"] = "1"
-            _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence))), ref)
-        finally:
-            os.environ.pop("TDV_RANSAC_MERGE", None)
+        if STUDY_BUILD:
+            try:
+                os.environ["TDV_RANSAC_MERGE"] = "1"
+                _same_result(ctx.ransac(src, tgt, corr=corr, voxel=voxel, max_iterations=iters, confidence=float(np.float32(confidence))), ref)
+            finally:
+                os.environ.pop("TDV_RANSAC_MERGE", None)
         print("seed %d ns %d iters %d planted %s: level %d -> %d, confidence %.3f: best %d @ %d, run %d, scored %.3f"
               % (seed, ns, iters, planted, before, top, confidence, got.inliers, got.best_iteration, got.iterations_run, scored))

@@ -386,14 +386,19 @@ def test_ransac_bailout_scheme_is_exact_on_simulated_counts():
 
 
 def test_every_environment_switch_is_documented():
-    """INTEGRATION.md lists every TDV_* variable the library reads (A/B and study knobs included): a switch nobody can find is a trap."""
+    """INTEGRATION.md lists every TDV_* variable the product library reads (getenv) and, in its own table, every one only the study
+    library reads (study_env): a switch nobody can find is a trap.  The product library's list stays short (round 3 had 34)."""
     import glob
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
-    knobs = set()
+    product_doc, study_doc = doc.split("### The study library")
+    knobs, study = set(), set()
     for f in glob.glob(os.path.join(root, "3dvision_amd", "csrc", "*.h*")):
-        knobs.update(re.findall(r'getenv\("(TDV_[A-Z0-9_]+)"\)', open(f).read()))
-    assert len(knobs) > 20
-    missing = sorted(k for k in knobs if k not in doc)
+        src = open(f).read()
+        knobs.update(re.findall(r'(?<!_)getenv\("(TDV_[A-Z0-9_]+)"\)', src))
+        study.update(re.findall(r'study_env\("(TDV_[A-Z0-9_]+)"\)', src))
+    assert 8 <= len(knobs) <= 16, sorted(knobs)
+    assert len(study) >= 15
+    missing = sorted(k for k in knobs if k not in product_doc) + sorted(k for k in study - knobs if k not in study_doc)
     assert not missing, missing
