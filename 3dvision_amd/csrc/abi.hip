@@ -306,6 +306,11 @@ int tdv_compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normal
     TDV_TRY(compute_fpfh_dev(ctx, d_xyz, d_normals, n, radius, d_desc33, d_nbr, d_nbr_cnt));
     return finish(ctx);
 }
+int tdv_normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc33) {
+    TDV_TRY(begin(ctx));
+    TDV_TRY(normals_fpfh_dev(ctx, d_xyz, n, k, radius, d_normals, d_desc33));
+    return finish(ctx);
+}
 int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, const uint8_t* d_bgr,
                            int width, int height, float scale, int mask_mode,
                            float fx, float fy, float cx, float cy, float zmax,

@@ -148,8 +148,10 @@ __global__ void k_feature_match_combine(int ns, int ns_pad, int nparts, const fl
 // The order only affects speed: any key (and the arbitrary order inside a bucket) gives the same correspondences.
 constexpr int FMP_KEY_BITS = 7;                       // bits per key of the 2-D Morton bucket
 constexpr int FMP_BUCKETS = 1 << (2 * FMP_KEY_BITS);   // 16384 (64 KB of LDS counters in the ordering kernels)
+#ifdef TDV_STUDY
 constexpr int FMP_BOX = 64;
 constexpr int FMP_TWO_KEYS_MAX_TARGETS = 32768;
+#endif
 
 #ifdef TDV_STUDY
 __device__ __forceinline__ int fm_bucket(const float* __restrict__ f, int two_keys) {

@@ -337,7 +337,7 @@ def main():
         # committed summary of the same command when it covers this workload, else null
         pm = None
         try:
-            for pm_round in ("r3", "r2"):
+            for pm_round in ("r4", "r3", "r2"):
                 pm_path = os.path.join(ROOT, "profiles", pm_round, "pmc_summary.json")
                 if os.path.exists(pm_path):
                     break

@@ -275,6 +275,13 @@ int tdv_feature_match_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* 
 int tdv_estimate_normals_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float* d_normals, int* d_knn);
 int tdv_compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normals, int n, float radius,
                          float* d_desc33, int* d_nbr, int* d_nbr_cnt);
+/* estimateNormals(k) followed by computeFPFH(radius) on the same cloud (src/pipeline.cpp:93-95) with ONE neighbour walk: the radius
+ * lists are sorted by (d2, idx) and capped at the 100 smallest, so wherever a point has >= k neighbours in radius its k nearest
+ * neighbours ARE the head of its radius list (registration.cpp:68-74,95-99); only the deficient points (isolated points, silhouette
+ * edges) go through a kNN search of their own, as a subset.  Normals and descriptors are those of the two separate calls bit for bit
+ * (tests/test_gpu_features.py); what tdv_register_batch_dev and tdv_prepare_model_dev run.  k <= 100 shares the walk; larger k falls
+ * back to the two calls. */
+int tdv_normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc33);
 int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, const uint8_t* d_bgr,
                            int width, int height, float scale, int mask_mode,
                            float fx, float fy, float cx, float cy, float zmax,

@@ -26,6 +26,22 @@ def comm():
     lib.ncclCommDestroy(c)
 
 
+def test_c5_share_through_the_c_abi_collectives_on_a_one_rank_process_group():
+    """What bench.py's N > 1 line does for config C5 - an ncclComm_t made from the torch.distributed group's id
+    (3dvision_amd/sharding.py: rccl_comm_from_process_group), the model moved by tdv_broadcast_model, the results by
+    tdv_gather_results - with the one rank a one-GPU box allows: library resolution (torch's own RCCL, re-opened RTLD_GLOBAL so that
+    csrc/comm.hip resolves the same copy), the by-value ncclUniqueId through ctypes, both collectives, the result layout.  The N > 1
+    behaviour of the collectives' logic is tests/test_gpu_comm_world2.py; RCCL itself across GPUs is the driver's run."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_c5.py"), "--instances-per-gpu", "96", "--c-abi"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print(out)
+    assert out["collectives"].startswith("tdv_broadcast_model + tdv_gather_results") and out["results_gathered"] == 96 and out["registered_share"] >= 0.88
+
+
 def test_broadcast_model_and_gather_one_rank(ctx, tdv, synth, comm):
     dev = torch.device("cuda", 0)
     n, cap = 5000, 6000

@@ -65,6 +65,21 @@ def test_fpfh(ctx, orc, synth, n, radius):
     assert same.all(), "rows differing: %d of %d" % ((~same).sum(), n)
 
 
+@pytest.mark.parametrize("n,radius", [(3000, 0.012), (3000, 0.004), (40, 0.05), (1, 0.01)])
+def test_one_neighbour_walk_for_normals_and_fpfh(ctx, synth, n, radius):
+    """tdv_normals_fpfh_dev (ONE radius search; the 30-NN list is the head of the sorted radius list, a kNN search of their own only for
+    the points with fewer than 30 neighbours in radius - most of them at radius 0.004) == estimateNormals(30) then computeFPFH(radius),
+    bit for bit.  (registration.cpp:68-74,95-99: both lists are sorted by (d2, idx).)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    pts = _cloud(synth, max(n, 40))[:n].copy()
+    nrm = ctx.estimate_normals(pts, 30)
+    fp = ctx.compute_fpfh(pts, nrm, radius)
+    d_x = torch.from_numpy(pts).to(dev); d_n = torch.empty_like(d_x); d_f = torch.empty((n, 33), dtype=torch.float32, device=dev)
+    ctx.normals_fpfh_dev(d_x.data_ptr(), n, 30, radius, d_n.data_ptr(), d_f.data_ptr())
+    assert d_n.cpu().numpy().tobytes() == nrm.tobytes() and d_f.cpu().numpy().tobytes() == fp.tobytes()
+
+
 @pytest.mark.study
 @pytest.mark.parametrize("n", [1, 2, 3, 65, 1001])
 def test_fpfh_two_points_per_wave_equals_one(ctx, orc, synth, n):

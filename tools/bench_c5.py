@@ -112,11 +112,11 @@ def tray_share(tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, 
 
 def tray(args, tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev=None):
     out, ok = tray_share(tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev, args.instances_per_gpu, args.hyps, args.icp_iters,
-                         c_abi=False if args.torch_collectives else None)
+                         c_abi=False if args.torch_collectives else (True if args.c_abi else None))
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)
@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--voxel-px", type=float, default=1.2)
     ap.add_argument("--max-angle", type=float, default=1e-2)
     ap.add_argument("--torch-collectives", action="store_true", help="tray workload: move the model and the results with torch.distributed instead of the C ABI's collectives")
+    ap.add_argument("--c-abi", action="store_true", help="tray workload: the C ABI's collectives even with ONE rank (a one-rank RCCL process group is created): what a one-GPU box can "
+                                                         "check of the N > 1 path - library resolution, ncclCommInitRank from the group's id, tdv_broadcast_model, tdv_gather_results")
     args = ap.parse_args()
     launch = importlib.import_module("3dvision_amd.launch")
     if args.gpus > 1 and not launch.in_rendezvous():      # same self-launch as bench.py: the parent never touches HIP
@@ -150,8 +152,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearse else dev
-    if world > 1:
+    if world > 1 or args.c_abi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
         if rehearse: dist.init_process_group("gloo", rank=rank, world_size=world)
         else: dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     tdv = importlib.import_module("3dvision_amd")

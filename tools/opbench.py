@@ -117,6 +117,11 @@ def cloud_ops(ctx, tdv, synth, torch, dev, n, reps=3, want_match=True):
     d_desc = torch.empty((n, 33), dtype=torch.float32, device=dev)
     wall = median_ms(lambda: ctx.compute_fpfh_dev(d_xyz.data_ptr(), d_nrm.data_ptr(), n, spacing * 5.0, d_desc.data_ptr(), None, None), torch, reps=reps)
     out.append(pruned(dict(op="compute_fpfh", workload="%d points, radius 5 x spacing" % n, ms=wall), 2 * 9.0 * n * n, wall, "radius search + SPFH/FPFH gathers"))
+    d_nrm2 = torch.empty_like(d_xyz); d_desc2 = torch.empty_like(d_desc)
+    wall = median_ms(lambda: ctx.normals_fpfh_dev(d_xyz.data_ptr(), n, 30, spacing * 5.0, d_nrm2.data_ptr(), d_desc2.data_ptr()), torch, reps=reps)
+    out.append(pruned(dict(op="normals_fpfh_one_walk", workload="%d points: estimateNormals(30) + computeFPFH(5 x spacing) sharing ONE radius search (the 30-NN list is the head of the "
+                                                                "sorted radius list; a kNN search only for the points with fewer than 30 in radius); same bits as the two calls: %s"
+                                                                % (n, bool(torch.equal(d_nrm2, d_nrm) and torch.equal(d_desc2, d_desc))), ms=wall), 3 * 9.0 * n * n, wall, "one radius search + SPFH/FPFH gathers"))
     if want_match:
         d_mx = torch.from_numpy(mdl).to(dev); d_mn = torch.empty_like(d_mx); d_mdesc = torch.empty((n, 33), dtype=torch.float32, device=dev)
         ctx.estimate_normals_dev(d_mx.data_ptr(), n, 30, d_mn.data_ptr())

@@ -3,7 +3,7 @@
 # bench.py and for tools/bench_ops.py, and the full C4 batch.  Programs are started directly after `rocprofv3 ... --`.
 set -eu
 : "${GRAFT_REPO_ROOT:?must be set (gpurun exports it on the GPU box)}"
-ROUND="${TDV_ROUND:-r3}"
+ROUND="${TDV_ROUND:-r4}"
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/${ROUND}prof"
 [ -f "$R/bench.py" ] || { echo "no bench.py under $R" >&2; exit 1; }
 rm -rf "$O"; mkdir -p "$O"
@@ -28,6 +28,8 @@ python3 $R/tools/c5_tray.py --reps 3 > $O/bench_c5_1gpu.jsonl 2> $O/bench_c5_1gp
 TDV_RANSAC_BATCH=0 python3 $R/tools/c5_tray.py --reps 2 >> $O/bench_c5_1gpu.jsonl 2>> $O/bench_c5_1gpu.err
 TDV_BATCH_STAGED=0 python3 $R/tools/c5_tray.py --reps 2 >> $O/bench_c5_1gpu.jsonl 2>> $O/bench_c5_1gpu.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c5 -- python3 $R/tools/c5_tray.py --reps 1 > /dev/null 2> $O/kt_c5.err
+# ICP with the reference's accumulation order beside the tree, 200k x 200k, both ICP modes: rates and the kernel trace (k_icp_flags / scan_counts / rows / fold_ref)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_icpref -- python3 $R/tools/studies/icp_ref_order_probe.py 50000 200000 > $O/icp_reference_order.jsonl 2> $O/kt_icpref.err
 # fold the PMC passes here (the per-dispatch counter tables are hundreds of MB with the 256- and 1,024-instance batches in the run;
 # gpurun copies back at most 64 MiB), then keep only statistics and summaries
 nf() { ls -t $O/$1/*/*$2 2>/dev/null | head -1; }
