@@ -492,12 +492,18 @@ void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict
                 if (qx == cx && qy == cy && qz == cz) break;
             }
         }
-        pos0 = VH_EMPTY - atomicSub(&vcnt[j], size);       // arrival ranks pos0 .. pos0 + size - 1
+        // The claimer is a member by being the claimer: it neither counts itself nor writes itself into the row (round 4).  Four of five
+        // voxels of a depth-camera cloud hold one point: for them the insertion is now the load + the claiming CAS and nothing else
+        // (it was: + one more device-scope atomic and a scattered 4-byte store into a 64-byte row nobody reads).
+        const int others = j == g ? size - 1 : size;
+        if (others > 0) pos0 = VH_EMPTY - atomicSub(&vcnt[j], others);       // arrival ranks of the non-claimers pos0 .. pos0 + others - 1
     }
+    const int g_head = __shfl(g, head, 64);
     j = __shfl(j, head, 64); pos0 = __shfl(pos0, head, 64);
     voxel_of[g] = j;
-    const int pos = pos0 + rank;
-    if (pos < VH_K) members[(size_t)j * VH_K + pos] = g;
+    if (j == g) return;                                  // the claimer itself
+    const int pos = pos0 + (j == g_head ? rank - 1 : rank);
+    if (pos < VH_K - 1) members[(size_t)j * VH_K + pos] = g;
     else *overflow = 1;                                 // (any value but the fill pattern)
 }
 
@@ -525,17 +531,20 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
     const bool inside = g < total;
     // this point's voxel: its member row (the indices of its points in arrival order).  The smallest is the voxel's leader.
     const int j = inside ? voxel_of[g] : 0;
-    const int cnt = inside ? min(VH_EMPTY - vcnt[j], VH_K) : 0;     // (an overflowing voxel: the call is redone, whatever is written here is dropped)
+    // members = the claimer j + the `others` that found j's slot taken (their indices in j's row, arrival order)
+    const int others = inside ? min(VH_EMPTY - vcnt[j], VH_K - 1) : 0;     // (an overflowing voxel: the call is redone, whatever is written here is dropped)
+    const int cnt = inside ? others + 1 : 0;
     int m[VH_K];
     {
         const int4* row = reinterpret_cast<const int4*>(members + (size_t)j * VH_K);
 #pragma unroll
         for (int q = 0; q < VH_K / 4; ++q) {
-            int4 r = make_int4(q == 0 ? g : VH_EMPTY, VH_EMPTY, VH_EMPTY, VH_EMPTY);
-            if (4 * q < cnt && cnt > 1) r = row[q];          // (a voxel of one point - four of five in a depth-camera cloud - is that point: its row is never fetched)
-            m[4 * q] = 4 * q < cnt ? r.x : VH_EMPTY; m[4 * q + 1] = 4 * q + 1 < cnt ? r.y : VH_EMPTY;
-            m[4 * q + 2] = 4 * q + 2 < cnt ? r.z : VH_EMPTY; m[4 * q + 3] = 4 * q + 3 < cnt ? r.w : VH_EMPTY;
+            int4 r = make_int4(VH_EMPTY, VH_EMPTY, VH_EMPTY, VH_EMPTY);
+            if (4 * q < others) r = row[q];                  // (a voxel of one point - four of five in a depth-camera cloud - is that point: its row is never fetched)
+            m[4 * q] = 4 * q < others ? r.x : VH_EMPTY; m[4 * q + 1] = 4 * q + 1 < others ? r.y : VH_EMPTY;
+            m[4 * q + 2] = 4 * q + 2 < others ? r.z : VH_EMPTY; m[4 * q + 3] = 4 * q + 3 < others ? r.w : VH_EMPTY;
         }
+        m[VH_K - 1] = inside ? j : VH_EMPTY;                 // (others <= VH_K - 1: the last entry of the row is never used)
     }
     int first_member = VH_EMPTY;
 #pragma unroll
