@@ -480,6 +480,10 @@ void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict
     const int rank = __popcll(group & ((1ull << lane) - 1ull)), size = __popcll(group);
     int j = 0, pos0 = 0;
     if (lane == head) {
+        // (One table for all clouds, the cloud mixed into the hash.  Giving every cloud its OWN stretch of the table - two slots per
+        //  point at [2 lo, 2 hi), so that the workgroups in flight touch a few MB instead of 512 - was measured in round 4 and LOST:
+        //  k_vh_insert 2.2 -> 3.15 ms for the 256-cloud batch, 20 -> 39 us for one cloud.  The device-scope atomics of the ~2,000
+        //  workgroups in flight then land on a few memory channels instead of all of them; spreading them is worth more than locality.)
         unsigned h = voxel_hash((unsigned)cx, (unsigned)cy, (unsigned)cz) + (unsigned)b * 0x9e3779b9u;
         for (;; ++h) {
             int* slot = claim + (h & mask);
