@@ -160,7 +160,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = env_world > 1
+    # TDV_BENCH_FORCE_DIST=1 (tests/test_gpu_bench_dist.py): take the N > 1 code path with the ONE rank a one-GPU box allows - a real RCCL
+    # process group, its collectives, the C5 share through the C ABI's collectives - so that every line of it has run on hardware before
+    # the driver's multi-GPU node sees it (RCCL across two devices is the one thing this cannot show).  Never set by the driver.
+    distributed = env_world > 1 or os.environ.get("TDV_BENCH_FORCE_DIST") == "1"
     # Rehearsal on a ONE-GPU box (TDV_BENCH_REHEARSE=1): the ranks share GPU 0 and rendezvous over gloo with host tensors - RCCL
     # refuses two ranks on one device - so that every line of the N > 1 path below except RCCL itself runs before the driver's
     # multi-GPU node sees it.  Never the default: a real run is one rank per GPU over RCCL / xGMI.
@@ -170,6 +173,8 @@ def main():
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if env_world == 1:
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
         if rehearse: dist.init_process_group("gloo", rank=rank, world_size=env_world)
         else: dist.init_process_group("nccl", rank=rank, world_size=env_world, device_id=torch.device("cuda", local_rank))
     world = dist.get_world_size() if distributed else 1      # the ranks RCCL actually joined: what n_gpus reports

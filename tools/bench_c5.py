@@ -31,13 +31,13 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 def tray_share(tdv, synth, sharding, ctx, torch, dist, dev, rank, world, order, cdev=None, instances_per_gpu=1024, hyps=10000, icp_iters=50, c_abi=None):
     """One rank's 1,024-instance tray through ONE tdv_register_batch_dev call, the model moved once from rank 0 and the results
-    gathered once.  c_abi (default: whenever the job is a real RCCL job, i.e. world > 1 and the collectives' tensors live on the
-    GPU): the two steps go through the C ABI - tdv_broadcast_model / tdv_gather_results on an ncclComm_t made from the
+    gathered once.  c_abi (default: whenever the job is a real RCCL job, i.e. a torch.distributed group with backend nccl exists and
+    the collectives' tensors live on the GPU): the two steps go through the C ABI - tdv_broadcast_model / tdv_gather_results on an ncclComm_t made from the
     process group (sharding.rccl_comm_from_process_group) - else through torch.distributed (sharding.broadcast_model /
     gather_results: the one-GPU gloo rehearsal, where RCCL cannot hold two ranks on one device).  Returns (dict for rank 0 | None, ok)."""
     cdev = cdev or dev                                                 # where torch's collectives' tensors live (the CPU in a one-GPU rehearsal)
     if c_abi is None:
-        c_abi = world > 1 and cdev.type == "cuda"
+        c_abi = cdev.type == "cuda" and dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"    # a real RCCL job (any size)
     c5 = importlib.import_module("c5_tray")
     B = instances_per_gpu
     wl = c5.build(tdv, synth, ctx, B, dev, order=order, hyps=hyps, icp_iters=icp_iters, pose_seed=1000 + rank)
