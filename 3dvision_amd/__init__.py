@@ -45,14 +45,14 @@ DEPTH_BATCH_MASK_PASSES = 1   # the B masks cross HBM once in tdv_depth_to_cloud
 
 # every symbol include/tdv_hip.h declares (checked by the CPU test-suite against the built library)
 ABI_SYMBOLS = [
-    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_set_icp_accumulation", "tdv_ctx_last_icp_search", "tdv_ctx_last_batch_lanes", "tdv_ctx_last_feature_match_path", "tdv_ctx_workspace_bytes", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
+    "tdv_device_count", "tdv_ctx_create", "tdv_ctx_set_stream", "tdv_ctx_set_icp_search", "tdv_ctx_set_icp_accumulation", "tdv_ctx_last_icp_search", "tdv_ctx_last_batch_lanes", "tdv_ctx_last_voxel_grouping", "tdv_ctx_last_feature_match_path", "tdv_ctx_workspace_bytes", "tdv_ctx_set_ransac_score", "tdv_ctx_last_ransac_rescore", "tdv_ctx_last_ransac_scored", "tdv_ctx_get_stream", "tdv_ctx_synchronize",
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
     "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev", "tdv_normals_fpfh_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
     "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii", "tdv_load_mask_png", "tdv_load_masks_from_dir",
-    "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results", "tdv_mask_resize_nearest", "tdv_mask_resize_nearest_dev", "tdv_voxel_downsample_batch_dev",
+    "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results", "tdv_mask_resize_nearest", "tdv_mask_resize_nearest_dev", "tdv_voxel_downsample_batch_dev", "tdv_voxel_downsample_batch_pinhole_dev",
 ]
 
 
@@ -228,6 +228,10 @@ class Context:
     def last_feature_match_path(self):
         """'scan', 'leaf_major' or 'walk': the search the last feature_match call on this context ran."""
         return {0: "none", 1: "scan", 2: "leaf_major", 3: "walk"}[int(lib().tdv_ctx_last_feature_match_path(self._h))]
+
+    def last_voxel_grouping(self):
+        """'table' or 'pixels': how the last batched voxel stage on this context grouped its points."""
+        return {0: "none", 1: "table", 2: "pixels"}[int(lib().tdv_ctx_last_voxel_grouping(self._h))]
 
     def last_batch_lanes(self):
         """Host lanes the last register_batch_dev call on this context used."""
@@ -437,12 +441,18 @@ class Context:
         return m.value
 
 
-def _voxel_downsample_batch_dev(self, d_xyz, cloud_offsets, voxel, d_out_xyz):
-    """All clouds' voxels (first-occurrence order) in one set of launches; returns the voxel offsets (int32 [n_clouds + 1])."""
+def _voxel_downsample_batch_dev(self, d_xyz, cloud_offsets, voxel, d_out_xyz, pinhole=None):
+    """All clouds' voxels (first-occurrence order) in one set of launches; returns the voxel offsets (int32 [n_clouds + 1]).
+    pinhole = (fx, fy, cx, cy): the clouds come from depth images with these intrinsics, in row-major pixel order (pixel-window grouping)."""
     off = np.ascontiguousarray(cloud_offsets, np.int32)
     voff = np.zeros(len(off), np.int32)
-    _check(self._h, lib().tdv_voxel_downsample_batch_dev(self._h, _ptr(d_xyz), _ptr(off), len(off) - 1, C.c_float(voxel), _ptr(d_out_xyz), _ptr(voff)),
-           "tdv_voxel_downsample_batch_dev")
+    if pinhole is None:
+        _check(self._h, lib().tdv_voxel_downsample_batch_dev(self._h, _ptr(d_xyz), _ptr(off), len(off) - 1, C.c_float(voxel), _ptr(d_out_xyz), _ptr(voff)),
+               "tdv_voxel_downsample_batch_dev")
+    else:
+        fx, fy, cx, cy = pinhole
+        _check(self._h, lib().tdv_voxel_downsample_batch_pinhole_dev(self._h, _ptr(d_xyz), _ptr(off), len(off) - 1, C.c_float(voxel), C.c_float(fx), C.c_float(fy),
+                                                                     C.c_float(cx), C.c_float(cy), _ptr(d_out_xyz), _ptr(voff)), "tdv_voxel_downsample_batch_pinhole_dev")
     return voff
 
 

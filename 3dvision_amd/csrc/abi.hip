@@ -68,8 +68,20 @@ int tdv_bilateral_filter(tdv_ctx* ctx, const float* depth, int width, int height
     return finish(ctx);
 }
 
+static int voxel_batch_impl(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size, const float* pinhole4,
+                            float* d_out_xyz, int* h_voxel_offsets);
 int tdv_voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size,
                                    float* d_out_xyz, int* h_voxel_offsets) {
+    return voxel_batch_impl(ctx, d_xyz, h_cloud_offsets, n_clouds, voxel_size, nullptr, d_out_xyz, h_voxel_offsets);
+}
+int tdv_voxel_downsample_batch_pinhole_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size,
+                                           float fx, float fy, float cx, float cy, float* d_out_xyz, int* h_voxel_offsets) {
+    if (!(fx > 0.f) || !(fy > 0.f)) return TDV_ERR_BAD_ARG;
+    const float cam[4] = {fx, fy, cx, cy};
+    return voxel_batch_impl(ctx, d_xyz, h_cloud_offsets, n_clouds, voxel_size, cam, d_out_xyz, h_voxel_offsets);
+}
+static int voxel_batch_impl(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size, const float* pinhole4,
+                            float* d_out_xyz, int* h_voxel_offsets) {
     if (!h_cloud_offsets || !h_voxel_offsets || n_clouds < 0) return TDV_ERR_BAD_ARG;
     TDV_TRY(begin(ctx));
     h_voxel_offsets[0] = 0;
@@ -81,7 +93,8 @@ int tdv_voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* 
     TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 1, &d_off));
     TDV_HIP(ctx, hipMemcpyAsync(d_off, h_cloud_offsets, ((size_t)n_clouds + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     int overflowed = 0;
-    TDV_TRY(voxel_downsample_batch_dev(ctx, d_xyz, total, d_off, n_clouds, voxel_size, d_out_xyz, nullptr, nullptr, h_voxel_offsets, &overflowed));
+    TDV_TRY(voxel_downsample_batch_dev(ctx, d_xyz, total, d_off, n_clouds, voxel_size, d_out_xyz, nullptr, nullptr, h_voxel_offsets, &overflowed, nullptr,
+                                       pinhole4, pinhole4 ? h_cloud_offsets : nullptr));
     if (!overflowed) return TDV_OK;
     // a voxel with more points than the table's member rows hold (a coarse grid): cloud by cloud on the path without that limit
     int at = 0;

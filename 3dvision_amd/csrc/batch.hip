@@ -116,8 +116,9 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
         TDV_HIP(ctx, hipMemcpyAsync(d_off_inst, off.data(), ((size_t)n_instances + 1) * 4, hipMemcpyHostToDevice, ctx->stream));   // (off outlives the call's sync below)
         const WsMark vmark = ws_mark(ctx);                   // the table and member rows are scratch: given back after the call
         int overflowed = 0;
+        const float pinhole[4] = {prm->fx, prm->fy, prm->cx, prm->cy};     // the clouds come from this call's own unprojection: row-major pixel order, these intrinsics
         TDV_TRY(voxel_downsample_batch_dev(ctx, all_xyz, total_pts, d_off_inst, n_instances, prm->voxel_size, vox_first_all, vox_rank_all, vox_leaders_all,
-                                           voff.data(), &overflowed, d_voff));
+                                           voff.data(), &overflowed, d_voff, pinhole, off.data()));
         ws_rewind(ctx, vmark);
         batched_voxel = !overflowed;
         // ... and their reference order, on the device too (the host replay stays as the fall-back of a cloud whose hash degenerates)

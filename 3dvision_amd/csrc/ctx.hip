@@ -234,6 +234,7 @@ double tdv_ctx_last_ransac_scored(tdv_ctx* ctx) { return ctx ? ctx->last_ransac_
 
 int tdv_ctx_last_icp_search(tdv_ctx* ctx) { return ctx ? ctx->last_icp_search : 0; }
 int tdv_ctx_last_feature_match_path(tdv_ctx* ctx) { return ctx ? ctx->last_fm_path : 0; }
+int tdv_ctx_last_voxel_grouping(tdv_ctx* ctx) { return ctx ? ctx->last_voxel_grouping : 0; }
 int tdv_ctx_last_batch_lanes(tdv_ctx* ctx) { return ctx ? ctx->last_batch_lanes : 0; }
 unsigned long long tdv_ctx_workspace_bytes(tdv_ctx* ctx) {
     unsigned long long total = 0;

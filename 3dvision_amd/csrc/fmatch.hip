@@ -353,9 +353,8 @@ int fm_order(tdv_ctx* ctx, const float* d_f, int n, int two_keys, int* perm, int
 }
 #endif  // TDV_STUDY
 
-constexpr int FMP_SPL = 1;   // 1 measured better than 2 (C4: 0.84 vs 0.93 ms)
-
 #ifdef TDV_STUDY
+constexpr int FMP_SPL = 1;   // 1 measured better than 2 (C4: 0.84 vs 0.93 ms)
 int feature_match_keyorder_dev(tdv_ctx* ctx, const float* d_fs, int ns, const float* d_ft, int nt, int* d_corr) {
     hipStream_t s = ctx->stream;
     const int nt_pad = (int)align_up((size_t)nt, FMP_BOX);

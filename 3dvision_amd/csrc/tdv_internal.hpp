@@ -38,6 +38,7 @@ struct tdv_ctx {
     int ransac_score_mode = 0;    // TDV_RANSAC_SCORE_FAST (FMA pass + exact band) / _EXACT (the reference arithmetic only) / _MATRIX (tdv_ctx_set_ransac_score)
     double last_ransac_rescore = -1.0;   // fraction of (wave, 8-point chunk) pairs of the last RANSAC call that the fast pass scored again exactly (-1: exact mode)
     double last_ransac_scored = 1.0;     // share of the (hypothesis, point) tests the last RANSAC call evaluated (< 1: the exact bail-out left the rest out)
+    int last_voxel_grouping = 0;   // 1: the table (k_vh_insert), 2: pixel windows (k_vs_group) - the last batched voxel call (tdv_ctx_last_voxel_grouping)
     int last_fm_path = 0;      // TDV_FM_PATH_* of the last descriptor match on this ctx (tdv_ctx_last_feature_match_path)
     int last_batch_lanes = 0;  // host lanes the last tdv_register_batch_dev call on this ctx spread its instances over (tdv_ctx_last_batch_lanes)
     int last_icp_search = 0; // the search the last ICP / correspondence call on this ctx actually ran (tdv_ctx_last_icp_search)
@@ -206,8 +207,11 @@ int voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, i
                          float* d_out_xyz, float* d_out_rgb, int capacity, int* n_out, const VoxelBothOrders* both = nullptr);
 
 // batch: every cloud's voxels in first-occurrence order with one memset + two launches (voxel.hip); the reference order per cloud
+// pinhole4 (optional: fx, fy, cx, cy) + h_seg_off (the clouds' offsets on the host): the clouds were unprojected from a depth image with these
+// intrinsics, in row-major pixel order - they are then grouped through pixel windows in LDS instead of the table (voxel.hip: k_vs_group)
 int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, const int* d_seg_off, int n_clouds, float voxel,
-                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed, int* d_voff_keep = nullptr);
+                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed, int* d_voff_keep = nullptr,
+                               const float* pinhole4 = nullptr, const int* h_seg_off = nullptr);
 // the reference's container order of every cloud of a batch, computed on the device (voxel.hip); h_failed[b] != 0: finish cloud b with voxel_reference_order
 int voxel_reference_order_batch_dev(tdv_ctx* ctx, int n_clouds, const int* h_voff, const int* d_voff, const int4* d_leaders, const float* d_first_xyz,
                                     float* d_out_xyz, int* d_ref2first, int* d_first2ref, int* h_failed);

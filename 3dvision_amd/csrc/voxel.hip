@@ -511,6 +511,188 @@ void k_vh_insert(const float* __restrict__ xyz, int total, const int* __restrict
     else *overflow = 1;                                 // (any value but the fill pattern)
 }
 
+// ---- grouping WITHOUT the table, for clouds that come from a pinhole depth image (round 4; the batch's clouds) ---------------
+// k_vh_insert is bound by the chip's rate of device-scope atomics (20 G/s: profiles/r4/history/voxel_batch.md).  A cloud
+// unprojected from a depth image needs none: its points are in row-major pixel order, and all members of a voxel lie within a
+// few pixels of each other - two points of one voxel differ by less than the voxel size s in x, y and z, hence by
+//     |du| <= fx * (s / z) * (1 + |x / z|)        (u - cx = fx * x / z;  d(x / z) <= dx / z + |x / z| * dz / z)
+// pixels in u, the same with fy in v.  So one workgroup takes a TILE of consecutive points of one cloud plus a HALO of whole
+// rows before and after it, recovers every point's pixel (u = rint(cx + fx * x / z): the rounding error of the unprojection is
+// 4e-4 pixel), enters the points into a pixel map in LDS, and every point looks its voxel's members up in the (2 win_v + 1) x
+// (2 win_u + 1) window around its own pixel - 3 x 3 at the pipeline's 1.2-pixel voxels.  The window walk is in row-major order =
+// ascending input index: the smallest member index is the voxel's LEADER, and the leader can add its voxel's points up in the
+// reference's order right there.  The kernel writes voxel_of[g] = the leader (what k_vh_insert writes, with the leader as claimer)
+// and the voxel's mean at the leader's index; k_vh_finalize then only ranks the leaders and moves the means to their ranks - no
+// member rows, no counts, no limit on the members of a voxel, and nothing depends on a race.
+// Anything the argument does not cover makes the tile raise *fail (the caller redoes the call through the table): a window
+// above VS_WIN_MAX (coarse voxels), rows too long for the halo, a pixel map or a key range that does not fit, points that are not
+// in row-major pixel order (the cloud is not what the caller said it was), non-positive depth.
+struct VoxelPinhole { float fx, fy, cx, cy; };
+#ifndef VS_TILE_VALUE
+#define VS_TILE_VALUE 4096
+#endif
+#ifndef VS_HALO_VALUE
+#define VS_HALO_VALUE 2048
+#endif
+#ifndef VS_MAP_VALUE
+#define VS_MAP_VALUE 20480
+#endif
+constexpr int VS_TILE = VS_TILE_VALUE, VS_HALO = VS_HALO_VALUE, VS_LOAD = VS_TILE + 2 * VS_HALO, VS_BLOCK = 1024, VS_PER = VS_LOAD / VS_BLOCK;
+constexpr int VS_MAP = VS_MAP_VALUE;          // pixel map entries (u16: local index + 1)
+constexpr int VS_WIN_MAX = 3;
+constexpr int VS_FAILED = 2;           // value of the overflow word when a tile could not be grouped this way (written with atomicMin; the word starts as VH_EMPTY)
+
+// LDS per loaded point: its cell relative to the tile's first point, packed into 32 bits (10 + 8 + 14: a tile spans a few hundred cells in
+// x, a few dozen in y; a range that does not fit raises *fail), and its map entry: 73 KB per workgroup, two workgroups per CU.  (The
+// first version kept three 16-bit cells and the pixels - 129 KB, one workgroup per CU: 1.39 ms for the 256-cloud batch; 16-bit tags
+// with the neighbour's cell recomputed from memory on a match: 1.08 ms - the dependent loads of the checks, one after the other.)
+constexpr int VS_KX = 10, VS_KY = 8, VS_KZ = 14;
+
+__global__ __launch_bounds__(VS_BLOCK, 2)
+void k_vs_group(const float* __restrict__ xyz, const int* __restrict__ seg_off, const int2* __restrict__ tiles /* (first owned point, cloud) */,
+                float inv, float voxel, VoxelPinhole cam, float* __restrict__ mean_at /* [point][3]: a leader's voxel mean, at the leader's index */,
+                int* __restrict__ voxel_of, int* __restrict__ overflow) {
+    __shared__ unsigned key[VS_LOAD];
+    __shared__ unsigned short map[VS_MAP];
+    __shared__ unsigned edge[VS_PER][VS_BLOCK / 64];                      // pixel of every wave's last lane, per round (the order check across waves)
+    __shared__ int s_umin, s_umax, s_vlast, s_vend, s_bad;
+    __shared__ unsigned s_zmin, s_amax, s_bmax;
+    const int2 tl = tiles[blockIdx.x];
+    const int lo = seg_off[tl.y], hi = seg_off[tl.y + 1];
+    const int g0 = tl.x, g1 = min(g0 + VS_TILE, hi);
+    const int l0 = max(lo, g0 - VS_HALO), l1 = min(hi, g1 + VS_HALO), nl = l1 - l0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { s_umin = INT_MAX; s_umax = INT_MIN; s_vlast = 0; s_vend = 0; s_bad = 0; s_zmin = 0x7f800000u; s_amax = 0u; s_bmax = 0u; }
+    for (int e = threadIdx.x; e < VS_MAP / 2; e += VS_BLOCK) reinterpret_cast<unsigned*>(map)[e] = 0u;
+    __syncthreads();
+    // pass 1: pixel and tag of every loaded point (thread t holds points t, t + 1024, ...: the owned ones among them are its own in pass 3)
+    unsigned pvu[VS_PER], pk[VS_PER];                                     // v << 16 | u; the cell relative to the first loaded point's, biased to the middle of its bit field
+    int ox, oy, oz;
+    vh_cell(xyz, (size_t)l0, inv, ox, oy, oz);
+    ox -= 1 << (VS_KX - 1); oy -= 1 << (VS_KY - 1); oz -= 1 << (VS_KZ - 1);
+    int umin = INT_MAX, umax = INT_MIN;
+    float zmin = INFINITY, amax = 0.f, bmax = 0.f; bool bad = false;
+#pragma unroll
+    for (int q = 0; q < VS_PER; ++q) {
+        const int i = (int)threadIdx.x + q * VS_BLOCK;
+        pvu[q] = 0u; pk[q] = 0u;
+        if (i < nl) {
+            const size_t g = (size_t)(l0 + i);
+            const float x = xyz[3 * g], y = xyz[3 * g + 1], z = xyz[3 * g + 2];
+            int cx, cy, cz;
+            vh_cell(xyz, g, inv, cx, cy, cz);
+            const long long rx = (long long)cx - ox, ry = (long long)cy - oy, rq = (long long)cz - oz;
+            if (rx < 0 || rx >= (1 << VS_KX) || ry < 0 || ry >= (1 << VS_KY) || rq < 0 || rq >= (1 << VS_KZ)) bad = true;     // a tile wider than the packed cell: the table
+            pk[q] = (unsigned)rx | ((unsigned)ry << VS_KX) | ((unsigned)rq << (VS_KX + VS_KY));
+            key[i] = pk[q];
+            const float rz = __frcp_rn(z);                               // (a reciprocal is plenty: the pixel is recovered to 1e-3, rint needs 0.5)
+            const float a = x * rz, b = y * rz;
+            const float fu = rintf(cam.cx + cam.fx * a), fv = rintf(cam.cy + cam.fy * b);
+            if (!(z > 0.f) || !(fu >= 0.f && fu < 65535.f && fv >= 0.f && fv < 65535.f)) bad = true;
+            else {
+                const int u = (int)fu, v = (int)fv;
+                pvu[q] = ((unsigned)v << 16) | (unsigned)u;
+                umin = min(umin, u); umax = max(umax, u);
+                zmin = fminf(zmin, z); amax = fmaxf(amax, fabsf(a)); bmax = fmaxf(bmax, fabsf(b));
+                if (i == g1 - 1 - l0) s_vlast = v;
+                if (i == nl - 1) s_vend = v;
+            }
+        }
+        if (lane == 63) edge[q][wave] = pvu[q];
+    }
+    // (one LDS atomic per WAVE and value: an atomic per thread on a handful of addresses took longer than everything else here)
+    unsigned zb = __float_as_uint(zmin), ab = __float_as_uint(amax), bb = __float_as_uint(bmax);      // (non-negative floats order like their bits)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        umin = min(umin, __shfl_xor(umin, o, 64)); umax = max(umax, __shfl_xor(umax, o, 64));
+        zb = min(zb, (unsigned)__shfl_xor((int)zb, o, 64)); ab = max(ab, (unsigned)__shfl_xor((int)ab, o, 64)); bb = max(bb, (unsigned)__shfl_xor((int)bb, o, 64));
+    }
+    if (lane == 0) { atomicMin(&s_umin, umin); atomicMax(&s_umax, umax); atomicMin(&s_zmin, zb); atomicMax(&s_amax, ab); atomicMax(&s_bmax, bb); }
+    if (bad) s_bad = 1;
+    // row-major order inside the thread's rounds is checked against the lane before (the point before in memory); lane 0 looks at the wave before
+    bool viol = false;
+#pragma unroll
+    for (int q = 0; q < VS_PER; ++q) {
+        const unsigned prev = __shfl_up(pvu[q], 1, 64);
+        const int i = (int)threadIdx.x + q * VS_BLOCK;
+        if (lane > 0 && i < nl && !(pvu[q] > prev)) viol = true;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < VS_PER; ++q) {
+        const int i = (int)threadIdx.x + q * VS_BLOCK;
+        if (lane == 0 && i > 0 && i < nl) {
+            const unsigned prev = wave > 0 ? edge[q][wave - 1] : edge[q > 0 ? q - 1 : 0][VS_BLOCK / 64 - 1];
+            if (!(pvu[q] > prev)) viol = true;
+        }
+    }
+    const int u0 = s_umin, ur = s_umax - s_umin + 1;
+    const int qo = (g0 - l0) / VS_BLOCK;                                  // the thread's first owned round (g0 - l0 is 0 or VS_HALO: a multiple of the block)
+    const int v0 = (int)(__shfl(pvu[0], 0, 64) >> 16);                    // (wave 0 only: the first loaded point's row) - broadcast below
+    __shared__ int s_v0, s_vfirst;
+    if (threadIdx.x == 0) { s_v0 = v0; s_vfirst = (int)((qo == 0 ? pvu[0] : pvu[VS_HALO / VS_BLOCK < VS_PER ? VS_HALO / VS_BLOCK : 0]) >> 16); }
+    __syncthreads();
+    const int vbase = s_v0, vr = s_vend - s_v0 + 1;
+    const float z_min = __uint_as_float(s_zmin);
+    // how far apart (in pixels) two members of one voxel can be: the bound of the header, for points that need not be among the loaded
+    // ones (a member shares a voxel with a loaded point: its z is at most a voxel smaller, its |x| at most a voxel larger)
+    const float z_eff = z_min - voxel, rze = 1.f / z_eff;
+    const float reach = voxel * rze * 1.001f;
+    const int win_u = (int)floorf(cam.fx * reach * (1.f + (__uint_as_float(s_amax) * z_min + voxel) * rze) + 0.01f);
+    const int win_v = (int)floorf(cam.fy * reach * (1.f + (__uint_as_float(s_bmax) * z_min + voxel) * rze) + 0.01f);
+    bool ok = !s_bad && nl > 0 && z_eff > 0.f && vr > 0 && (long long)ur * vr <= VS_MAP && win_u <= VS_WIN_MAX && win_v <= VS_WIN_MAX;
+    // a halo of whole rows that covers the windows (the first and the last loaded row may be cut: they must lie outside every window)
+    if (ok && threadIdx.x == 0) {
+        if (l0 > lo && !(vbase < s_vfirst - win_v)) viol = true;
+        if (l1 < hi && !(s_vend > s_vlast + win_v)) viol = true;
+    }
+    if (__syncthreads_or(viol || !ok)) { if (threadIdx.x == 0) atomicMin(overflow, VS_FAILED); return; }
+    // pass 2: the pixel map
+#pragma unroll
+    for (int q = 0; q < VS_PER; ++q) {
+        const int i = (int)threadIdx.x + q * VS_BLOCK;
+        if (i < nl) map[((int)(pvu[q] >> 16) - vbase) * ur + ((int)(pvu[q] & 0xffffu) - u0)] = (unsigned short)(i + 1);
+    }
+    __syncthreads();
+    // pass 3: every owned point walks its window in row-major order = ascending input index
+#pragma unroll
+    for (int q = 0; q < VS_PER; ++q) {
+        const int li = (int)threadIdx.x + q * VS_BLOCK;
+        if (q < qo || li < g0 - l0 || li >= g1 - l0) continue;
+        const size_t gp = (size_t)(l0 + li);
+        const unsigned mk = pk[q];
+        // this point's own window: the bound with ITS depth and tangents - never larger than the tile's, which the halo was checked against
+        const float pz = xyz[3 * gp + 2], prz = __frcp_rn(pz - voxel), pa = fabsf(xyz[3 * gp]) * prz, pb = fabsf(xyz[3 * gp + 1]) * prz;
+        const float r0 = voxel * prz * 1.001f;
+        const int wu = min(win_u, (int)floorf(cam.fx * r0 * (1.f + pa + r0) + 0.01f)), wv = min(win_v, (int)floorf(cam.fy * r0 * (1.f + pb + r0) + 0.01f));
+        const int pu_ = (int)(pvu[q] & 0xffffu) - u0, pv_ = (int)(pvu[q] >> 16) - vbase;
+        const int ua = max(pu_ - wu, 0), ub = min(pu_ + wu, ur - 1), va = max(pv_ - wv, 0), vb = min(pv_ + wv, vr - 1);
+        auto member = [&](int m) -> bool { return m >= 0 && m != li && key[m] == mk; };
+        int leader = li, others = 0;
+        for (int vv = va; vv <= vb; ++vv)
+            for (int uu = ua; uu <= ub; ++uu) {
+                const int m = (int)map[vv * ur + uu] - 1;
+                if (member(m)) { ++others; leader = min(leader, m); }
+            }
+        const int g = l0 + li;
+        voxel_of[g] = l0 + leader;
+        if (leader == li) {
+            // the leader sums its voxel: itself, then the others as the window walk meets them - ascending input index, the order of
+            // registration.cpp:47-50 (the sum starts at 0, as there: a lone -0 becomes +0) - and divides by the count (:52-53)
+            float ax = 0.f, ay = 0.f, az = 0.f;
+            ax += xyz[3 * gp]; ay += xyz[3 * gp + 1]; az += pz;
+            if (others > 0)
+                for (int vv = va; vv <= vb; ++vv)
+                    for (int uu = ua; uu <= ub; ++uu) {
+                        const int m = (int)map[vv * ur + uu] - 1;
+                        if (member(m)) { const size_t gm = (size_t)(l0 + m); ax += xyz[3 * gm]; ay += xyz[3 * gm + 1]; az += xyz[3 * gm + 2]; }
+                    }
+            const float fn = (float)(others + 1);
+            mean_at[3 * gp] = ax / fn; mean_at[3 * gp + 1] = ay / fn; mean_at[3 * gp + 2] = az / fn;
+        }
+    }
+}
+
 // MODE 0: single pass (tiles numbered by ticket, decoupled look-back).  MODE 1 / 2: the same split in two for large inputs - count
 // the leaders per tile (tile_sums), [exclusive scan], emit with the scanned prefix (tile_prefix): with tens of thousands of tiles the
 // look-back's polling (device-scope loads in a loop from every tile in flight) slows the whole memory system down - 61 us of waiting
@@ -523,8 +705,14 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
                    int* __restrict__ rank_out /* per point: global first-occurrence rank of leaders */, int4* __restrict__ leaders /* optional */,
                    int* __restrict__ voff /* nseg + 2: the last entry receives the overflow flag */, int capacity /* voxels that fit out_xyz */,
                    const int* __restrict__ overflow_flag, int* __restrict__ host_result /* optional, pinned host memory: {voxels, overflow flag} */,
-                   int* __restrict__ tile_sums /* MODE 1 */, const int* __restrict__ tile_prefix /* MODE 2 */) {
+                   int* __restrict__ tile_sums /* MODE 1 */, const int* __restrict__ tile_prefix /* MODE 2 */,
+                   int leader_known /* voxel_of[g] IS the voxel's smallest index (k_vs_group): only the leaders look at counts and rows */,
+                   const float* __restrict__ mean_at /* with leader_known: the leaders' means are ready, at their own indices */) {
     __shared__ int s_ticket, s_excl, s_wave[VH_BLOCK / 64];
+    if (*overflow_flag == VS_FAILED) {          // k_vs_group gave up on a tile: voxel_of is not valid, nothing here may follow it - the caller redoes the call
+        if (blockIdx.x == 0 && threadIdx.x == 0) { voff[nseg + 1] = VS_FAILED; if (host_result) { host_result[0] = 0; host_result[1] = VS_FAILED; __threadfence_system(); } }
+        return;
+    }
     if (MODE == 0) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(ticket, 1) - VH_EMPTY;     // workgroups take their tiles in the order they start
         __syncthreads();
@@ -536,7 +724,8 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
     // this point's voxel: its member row (the indices of its points in arrival order).  The smallest is the voxel's leader.
     const int j = inside ? voxel_of[g] : 0;
     // members = the claimer j + the `others` that found j's slot taken (their indices in j's row, arrival order)
-    const int others = inside ? min(VH_EMPTY - vcnt[j], VH_K - 1) : 0;     // (an overflowing voxel: the call is redone, whatever is written here is dropped)
+    const bool look = inside && !leader_known;
+    const int others = look ? min(VH_EMPTY - vcnt[j], VH_K - 1) : 0;     // (an overflowing voxel: the call is redone, whatever is written here is dropped)
     const int cnt = inside ? others + 1 : 0;
     int m[VH_K];
     {
@@ -553,7 +742,7 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
     int first_member = VH_EMPTY;
 #pragma unroll
     for (int q = 0; q < VH_K; ++q) first_member = min(first_member, m[q]);
-    const bool lead = inside && first_member == g;
+    const bool lead = inside && (leader_known ? j == g : first_member == g);
     const int mine = lead ? 1 : 0;
     // workgroup scan of the leader flags
     int incl = mine;
@@ -609,6 +798,14 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
         for (int bb = b - 1; bb >= 0 && seg_off[bb] == g; --bb) voff[bb] = run;
     }
     if (!lead) return;
+    if (leader_known) {                                   // k_vs_group summed the voxel already: move its mean to its rank
+        const size_t o = (size_t)run;
+        if (rank_out) rank_out[g] = run;
+        if (run >= capacity) return;
+        out_xyz[3 * o] = mean_at[3 * (size_t)g]; out_xyz[3 * o + 1] = mean_at[3 * (size_t)g + 1]; out_xyz[3 * o + 2] = mean_at[3 * (size_t)g + 2];
+        if (leaders) { int cx, cy, cz; vh_cell(xyz, (size_t)g, inv, cx, cy, cz); leaders[o] = make_int4(cx, cy, cz, g - lo); }
+        return;
+    }
     // ascending index order without moving anything: cnt rounds of "smallest index above the last one"
     float ax = 0.f, ay = 0.f, az = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
     int last = -1;
@@ -635,14 +832,17 @@ void k_vh_finalize(const float* __restrict__ xyz, const float* __restrict__ rgb,
 // *overflowed = 1: a voxel had more than VH_K members (the outputs are garbage, take the counting-sort path).
 static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float* d_rgb, int total, const int* d_seg_off, int nseg, float voxel,
                                   float* d_out_xyz, float* d_out_rgb, int capacity, int* d_rank /* optional, total ints */,
-                                  int4* d_leaders /* optional, capacity entries */, int* d_voff, int* h_result /* optional: pinned {voxels, overflow flag} */) {
+                                  int4* d_leaders /* optional, capacity entries */, int* d_voff, int* h_result /* optional: pinned {voxels, overflow flag} */,
+                                  const VoxelPinhole* pinhole = nullptr, const int* h_seg_off = nullptr /* with pinhole: nseg + 1 host offsets */) {
     hipStream_t s = ctx->stream;
     const float inv = 1.0f / voxel;  // registration.cpp:32
-    size_t slots = 4096;
-    while (slots < 2 * (size_t)total) slots <<= 1;
+    const bool grouped_by_pixels = pinhole && h_seg_off && d_seg_off;      // k_vs_group instead of the table (the caller redoes the call without it if a tile fails)
     const int tiles = (total + VH_ITEMS - 1) / VH_ITEMS;
-    // one fill: claim[slots] | vcnt[total] | desc[tiles] (u64) | ticket | overflow
-    const size_t desc_at = (slots + (size_t)total + 1) & ~(size_t)1;
+    // one fill: claim[slots] | vcnt[total] | desc[tiles] (u64) | ticket | overflow.  Grouped by pixels: no table, no counts, no member rows -
+    // only the scan descriptors, the ticket and the overflow word are filled, and the leaders' means take 12 B per point
+    size_t slots = 0, n_cnt = 0;
+    if (!grouped_by_pixels) { slots = 4096; while (slots < 2 * (size_t)total) slots <<= 1; n_cnt = (size_t)total; }
+    const size_t desc_at = (slots + n_cnt + 1) & ~(size_t)1;
     const size_t n_fill = desc_at + 2 * (size_t)tiles + 2;
     int* fill;
     TDV_TRY(ws_alloc(ctx, n_fill, &fill));
@@ -650,27 +850,44 @@ static int voxel_hash_first_order(tdv_ctx* ctx, const float* d_xyz, const float*
     unsigned long long* desc = reinterpret_cast<unsigned long long*>(fill + desc_at);
     int* ticket = reinterpret_cast<int*>(desc + tiles);
     int* overflow = ticket + 1;
-    int *members, *voxel_of;
-    TDV_TRY(ws_alloc(ctx, (size_t)total * VH_K, &members));
+    int *members = nullptr, *voxel_of; float* mean_at = nullptr;
+    if (grouped_by_pixels) TDV_TRY(ws_alloc(ctx, (size_t)total * 3, &mean_at));
+    else TDV_TRY(ws_alloc(ctx, (size_t)total * VH_K, &members));
     TDV_TRY(ws_alloc(ctx, (size_t)total, &voxel_of));
-    TDV_HIP(ctx, hipMemsetAsync(fill, 0x7f, n_fill * 4, s));
-    k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vcnt, members, voxel_of, overflow);
+    if (grouped_by_pixels) {
+        // tiles: consecutive VS_TILE-point stretches of every cloud (a tile never spans two clouds)
+        size_t nt = 0;
+        for (int b = 0; b < nseg; ++b) nt += (size_t)((h_seg_off[b + 1] - h_seg_off[b] + VS_TILE - 1) / VS_TILE);
+        int2* d_tiles;
+        TDV_TRY(ws_alloc(ctx, nt, &d_tiles));
+        TDV_TRY(pin_reserve(ctx, nt * sizeof(int2) + 64 + ((size_t)nseg + 2) * 4));   // (+ what the caller stages afterwards: the buffer must not move while the copy below is in flight)
+        int2* h_tiles = reinterpret_cast<int2*>(ctx->pin);
+        size_t k = 0;
+        for (int b = 0; b < nseg; ++b)
+            for (int g = h_seg_off[b]; g < h_seg_off[b + 1]; g += VS_TILE) h_tiles[k++] = make_int2(g, b);
+        TDV_HIP(ctx, hipMemcpyAsync(d_tiles, h_tiles, nt * sizeof(int2), hipMemcpyHostToDevice, s));
+        TDV_HIP(ctx, hipMemsetAsync(fill, 0x7f, n_fill * 4, s));
+        k_vs_group<<<(unsigned)nt, VS_BLOCK, 0, s>>>(d_xyz, d_seg_off, d_tiles, inv, voxel, *pinhole, mean_at, voxel_of, overflow);
+    } else {
+        TDV_HIP(ctx, hipMemsetAsync(fill, 0x7f, n_fill * 4, s));
+        k_vh_insert<<<(total + 255) / 256, 256, 0, s>>>(d_xyz, total, d_seg_off, nseg, inv, (unsigned)(slots - 1), claim, vcnt, members, voxel_of, overflow);
+    }
     // (measured, us per call one pass / split: 184k points in pixel order 65 / 76; random order 250k 82 / 74, 500k 138 / 103, 1M 233 / 160, 4M 858 / 550;
     //  256 clouds of 184k 8,100 / 4,400 - tools/studies/voxel_split_threshold.py)
     static const int split_from = study_env("TDV_VOXEL_SPLIT_FROM") ? atoi(study_env("TDV_VOXEL_SPLIT_FROM")) : 224;   // tiles; tuning knob
     if (tiles < split_from)
         k_vh_finalize<0><<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vcnt, members, desc, ticket,
-                                                    d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, nullptr, nullptr);
+                                                    d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, nullptr, nullptr, grouped_by_pixels ? 1 : 0, mean_at);
     else {      // large inputs (a batch): count, scan, emit - launches without a wait inside
         int *tile_sums, *tile_prefix, *d_tot;
         TDV_TRY(ws_alloc(ctx, (size_t)tiles, &tile_sums));
         TDV_TRY(ws_alloc(ctx, (size_t)tiles, &tile_prefix));
         TDV_TRY(ws_alloc(ctx, 1, &d_tot));
         k_vh_finalize<1><<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vcnt, members, desc, ticket,
-                                                    d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, tile_sums, nullptr);
+                                                    d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, tile_sums, nullptr, grouped_by_pixels ? 1 : 0, mean_at);
         TDV_TRY(exclusive_scan_dev(ctx, tile_sums, tiles, tile_prefix, d_tot));
         k_vh_finalize<2><<<tiles, VH_BLOCK, 0, s>>>(d_xyz, d_rgb, total, d_seg_off, nseg, inv, voxel_of, vcnt, members, desc, ticket,
-                                                    d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, nullptr, tile_prefix);
+                                                    d_out_xyz, d_out_rgb, d_rank, d_leaders, d_voff, capacity, overflow, h_result, nullptr, tile_prefix, grouped_by_pixels ? 1 : 0, mean_at);
     }
     TDV_CHECK_LAUNCH(ctx);
     return TDV_OK;
@@ -997,7 +1214,8 @@ int voxel_reference_order_batch_dev(tdv_ctx* ctx, int n_clouds, const int* h_vof
 // voxel_reference_order needs.  *overflowed: a voxel held more than VH_K points - nothing of the output is valid, the caller
 // falls back to per-cloud calls.  d_voff_keep (optional): n_clouds + 2 device ints that receive the voxel offsets.  Synchronizes once.
 int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, const int* d_seg_off, int n_clouds, float voxel,
-                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed, int* d_voff_keep) {
+                               float* d_first_xyz, int* d_rank, int4* d_leaders, int* h_voff, int* overflowed, int* d_voff_keep,
+                               const float* pinhole4, const int* h_seg_off) {
     if (!ctx || n_clouds < 1 || total < 0 || !(voxel > 0.f) || !h_voff || !overflowed) return TDV_ERR_BAD_ARG;
     *overflowed = 0;
     for (int b = 0; b <= n_clouds; ++b) h_voff[b] = 0;
@@ -1007,12 +1225,30 @@ int voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, int total, cons
     if (!d_voff) TDV_TRY(ws_alloc(ctx, (size_t)n_clouds + 2, &d_voff));
     TDV_TRY(pin_reserve(ctx, ((size_t)n_clouds + 2) * 4));
     int* h = reinterpret_cast<int*>(ctx->pin);
-    {
-        ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
-        TDV_TRY(voxel_hash_first_order(ctx, d_xyz, nullptr, total, d_seg_off, n_clouds, voxel, d_first_xyz, nullptr, total, d_rank, d_leaders, d_voff, nullptr));
+    // Clouds unprojected from a depth image with the given intrinsics (pinhole4 = fx, fy, cx, cy; h_seg_off = the clouds' offsets on the
+    // host) are grouped through pixel windows, without the table (k_vs_group); if a tile cannot be (coarse voxels, very long rows, a cloud
+    // that is not what the caller said) the call is redone through the table.  TDV_VOXEL_PIXELS=0 (parity tests): the table at once.
+    VoxelPinhole cam{};
+    const char* px_env = getenv("TDV_VOXEL_PIXELS");
+    bool by_pixels = pinhole4 && h_seg_off && !(px_env && atoi(px_env) == 0);
+    if (by_pixels) { cam.fx = pinhole4[0]; cam.fy = pinhole4[1]; cam.cx = pinhole4[2]; cam.cy = pinhole4[3]; by_pixels = cam.fx > 0.f && cam.fy > 0.f; }
+    std::vector<int> seg_copy;
+    if (by_pixels) seg_copy.assign(h_seg_off, h_seg_off + n_clouds + 1);          // (the pinned staging below is reused by the tile table)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const WsMark mark = ws_mark(ctx);
+        {
+            ScopedTimer tm(ctx, TDV_TIMER_VOXEL);
+            TDV_TRY(voxel_hash_first_order(ctx, d_xyz, nullptr, total, d_seg_off, n_clouds, voxel, d_first_xyz, nullptr, total, d_rank, d_leaders, d_voff, nullptr,
+                                           by_pixels ? &cam : nullptr, by_pixels ? seg_copy.data() : nullptr));
+        }
+        TDV_TRY(pin_reserve(ctx, ((size_t)n_clouds + 2) * 4));
+        h = reinterpret_cast<int*>(ctx->pin);
+        TDV_HIP(ctx, hipMemcpyAsync(h, d_voff, ((size_t)n_clouds + 2) * 4, hipMemcpyDeviceToHost, s));   // offsets, then the overflow flag
+        TDV_HIP(ctx, hipStreamSynchronize(s));
+        ctx->last_voxel_grouping = by_pixels ? 2 : 1;
+        if (by_pixels && h[n_clouds + 1] == VS_FAILED) { by_pixels = false; ws_rewind(ctx, mark); continue; }   // a tile the pixel windows do not cover: the table
+        break;
     }
-    TDV_HIP(ctx, hipMemcpyAsync(h, d_voff, ((size_t)n_clouds + 2) * 4, hipMemcpyDeviceToHost, s));   // offsets, then the overflow flag
-    TDV_HIP(ctx, hipStreamSynchronize(s));
     if (h[n_clouds + 1] != VH_EMPTY) { *overflowed = 1; return TDV_OK; }
     std::memcpy(h_voff, h, ((size_t)n_clouds + 1) * 4);
     return TDV_OK;

@@ -106,6 +106,13 @@ int tdv_ctx_last_icp_search(tdv_ctx* ctx);
 #define TDV_FM_PATH_LEAF_MAJOR 2
 #define TDV_FM_PATH_WALK 3
 int tdv_ctx_last_feature_match_path(tdv_ctx* ctx);
+/* How the last tdv_register_batch_dev / tdv_voxel_downsample_batch_dev call on this ctx grouped its points into voxels (0 before any):
+ * TABLE = a hash table over all clouds (any cloud), PIXELS = pixel windows in LDS, without the table - for clouds the call itself unprojected
+ * from a depth image (row-major pixel order, known intrinsics); it hands over to TABLE when a tile is not covered (coarse voxels, rows longer
+ * than its halo).  Same voxels, means and orders either way; TDV_VOXEL_PIXELS=0 forces TABLE (parity tests). */
+#define TDV_VOXEL_GROUPING_TABLE 1
+#define TDV_VOXEL_GROUPING_PIXELS 2
+int tdv_ctx_last_voxel_grouping(tdv_ctx* ctx);
 /* Host lanes (the caller's thread + helper threads) the last tdv_register_batch_dev call on this ctx used (0 before any). */
 int tdv_ctx_last_batch_lanes(tdv_ctx* ctx);
 /* Device memory this ctx holds in its grow-only workspace arenas, its batch lanes' included: the high-water mark of every
@@ -298,6 +305,14 @@ int tdv_voxel_downsample_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_rg
  * index).  What tdv_register_batch_dev runs for its instances. */
 int tdv_voxel_downsample_batch_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size,
                                    float* d_out_xyz, int* h_voxel_offsets);
+/* The same for clouds that were unprojected from depth images with the given pinhole intrinsics and are still in the row-major pixel
+ * order tdv_depth_to_cloud*_dev emits (src/pipeline.cpp:68-83): the members of a voxel then lie within a few pixels of each other, and the
+ * points are grouped through pixel windows in LDS instead of a hash table (no device-scope atomics; csrc/voxel.hip: k_vs_group) - what
+ * tdv_register_batch_dev does for its own clouds.  Same voxels, means and order, bit for bit; a cloud or voxel size the window argument
+ * does not cover (coarse voxels, rows longer than the halo, points not in pixel order) is redone through the table inside the call
+ * (tdv_ctx_last_voxel_grouping tells). */
+int tdv_voxel_downsample_batch_pinhole_dev(tdv_ctx* ctx, const float* d_xyz, const int* h_cloud_offsets, int n_clouds, float voxel_size,
+                                           float fx, float fy, float cx, float cy, float* d_out_xyz, int* h_voxel_offsets);
 
 /* ---- batched, device-resident Pipeline::processInstance ------------------------
  * One call runs the whole per-instance chain of src/pipeline.cpp:25-150 for n_instances masks that

@@ -13,7 +13,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 W, H, F = 640, 480, 600.0
-KNOBS = ("TDV_BATCH_STAGED", "TDV_BATCH_VOXEL", "TDV_VOXEL_DEVICE_ORDER", "TDV_BATCH_FEATURES", "TDV_RANSAC_BATCH", "TDV_ICP_SMALL", "TDV_BATCH_LANES")
+KNOBS = ("TDV_BATCH_STAGED", "TDV_BATCH_VOXEL", "TDV_VOXEL_PIXELS", "TDV_VOXEL_DEVICE_ORDER", "TDV_BATCH_FEATURES", "TDV_RANSAC_BATCH", "TDV_ICP_SMALL", "TDV_BATCH_LANES")
 
 
 def _surface(rng, yy, xx):
@@ -111,11 +111,15 @@ def test_batch_shapes_agree(ctx, tdv, synth, seed, with_big, model_n):
             ("staged, features per instance", 0, dict(TDV_BATCH_STAGED="1", TDV_BATCH_FEATURES="0")),
             ("staged, ICP per iteration", 2, dict(TDV_BATCH_STAGED="1", TDV_ICP_SMALL="0")),
             ("staged, host replay of the order", 1, dict(TDV_BATCH_STAGED="1", TDV_VOXEL_DEVICE_ORDER="0")),
+            ("staged, voxels through the table", 2, dict(TDV_BATCH_STAGED="1", TDV_VOXEL_PIXELS="0")),
+            ("instance by instance, voxels through the table", 1, dict(TDV_BATCH_STAGED="0", TDV_VOXEL_PIXELS="0")),
             ("instance by instance, voxels batched", 2, dict(TDV_BATCH_STAGED="0")),
             ("instance by instance, ICP per iteration", 0, dict(TDV_BATCH_STAGED="0", TDV_ICP_SMALL="0", TDV_BATCH_VOXEL="0")),
         ]
         for what, fmt, env in variants:
             _same(_run(ctx, tdv, d_depth, formats[fmt], fmt, n_inst, model, voxel, order, env), base, "%s (order %d, seed %d)" % (what, order, seed))
+            if env.get("TDV_BATCH_VOXEL") != "0":
+                assert ctx.last_voxel_grouping() == ("table" if env.get("TDV_VOXEL_PIXELS") == "0" else "pixels"), (what, ctx.last_voxel_grouping())
             if "TDV_BATCH_LANES" in env:
                 assert ctx.last_batch_lanes() == int(env["TDV_BATCH_LANES"]), (what, ctx.last_batch_lanes())     # the knob took effect
             elif n_inst > 1:

@@ -27,6 +27,7 @@ def test_c5_1024_instances_from_one_label_image(ctx, tdv, synth, orc):
     sc = wl["sc"]
     S, F, CX, CY, V, ZMAX = sc["scale"], sc["fx"], sc["cx"], sc["cy"], sc["voxel"], sc["zmax"]
     assert len(res) == N_INST and all(r["status"] == 0 for r in res)
+    assert own.last_voxel_grouping() == "pixels"          # the batch's clouds come from its own unprojection: voxels through pixel windows, no table
     assert 450000 <= out["scene_points"] <= 600000 and out["scene_points"] == int((sc["label"] > 0).sum())
     per = np.bincount(sc["label"].ravel(), minlength=N_INST + 1)[1:]
     assert [r["n_points"] for r in res] == per.tolist()                      # every instance got exactly its label's pixels

@@ -222,6 +222,16 @@ def voxel_image_order(ctx, tdv, synth, torch, dev, reps=5):
     out.append(hbm(dict(op="voxel_downsample_batch", workload="%d instance clouds of %d points in ONE set of launches -> %d voxels" % (B, n, v), ms=wall, kernels_ms=kms,
                         us_per_instance=wall * 1e3 / B, note="what tdv_register_batch_dev runs for its instances; frac from the kernels' time"),
                    12.0 * B * n + 12.0 * v, kms))
+    d_allout2 = torch.empty_like(d_all)
+
+    def gp():
+        voff[0] = ctx.voxel_downsample_batch_dev(d_all.data_ptr(), off, voxel, d_allout2.data_ptr(), pinhole=(bb.F, bb.F, bb.CX, bb.CY))
+    wall, kms, _ = kernel_ms(ctx, tdv.TIMER_VOXEL, gp, torch, reps=3, warm=2)
+    same = bool(torch.equal(d_allout2[:v], d_allout[:v])) and int(voff[0][-1]) == v
+    out.append(hbm(dict(op="voxel_downsample_batch_pixel_windows", workload="%d instance clouds of %d points in ONE set of launches -> %d voxels, grouped through pixel windows (%s); "
+                                                                             "same voxels as the table path: %s" % (B, n, v, ctx.last_voxel_grouping(), same), ms=wall, kernels_ms=kms,
+                        us_per_instance=wall * 1e3 / B, note="what tdv_register_batch_dev runs for its instances (their clouds come from its own unprojection); frac from the kernels' time"),
+                   12.0 * B * n + 12.0 * v, kms))
     return out
 
 
