@@ -160,6 +160,9 @@ __device__ __forceinline__ unsigned long long shfl_u64_down(unsigned long long v
 #ifndef RS_BLOCK_VALUE
 #define RS_BLOCK_VALUE 1024
 #endif
+#ifndef RS_XCD_R
+#define RS_XCD_R 8           // XCD groups over the point ranges (1, 2, 4 or 8); 8 / RS_XCD_R groups over the hypothesis blocks
+#endif
 #ifndef RS_WG_TARGET
 #define RS_WG_TARGET 6144
 #endif
@@ -331,7 +334,15 @@ void k_ransac_score_fast(const ScoreJob a, const ScoreJob b, const int g1, const
     unsigned n_rescored = 0;     // wave-uniform
     unsigned chunks = 0;         // chunks this workgroup walked (workgroup-uniform)
     if (id < g1) {
-        const int hblock = id % a.hb, split = id / a.hb;          // consecutive ids = the hypothesis blocks of one point range: an XCD (id mod 8) keeps 1/8 of them
+        // XCD-aware deal (round 4).  An XCD (workgroup id mod 8) has its own L2.  Round 3 gave every XCD an eighth of the hypothesis blocks
+        // and ALL point ranges: every L2 pulled the whole pair array (PMC: 38.4 MB of HBM traffic per dispatch for 4.8 MB of pairs).  Now
+        // the eight XCDs form RS_XCD_R groups over the point ranges x 8 / RS_XCD_R groups over the hypothesis blocks: an L2 holds
+        // 1 / RS_XCD_R of the pairs and 1 / (8 / RS_XCD_R) of the hypotheses (52 B each).
+        const int xcd = id & 7, k = id >> 3;
+        constexpr int XR = RS_XCD_R, XH = 8 / RS_XCD_R;
+        const int hbl = (a.hb + XH - 1) / XH;
+        const int hblock = (k % hbl) * XH + xcd / XR, split = (k / hbl) * XR + xcd % XR;
+        if (hblock >= a.hb || split >= a.ps) return;                // (counts that are not multiples of the group sizes: the last groups are short)
         const int c_split = a.plan ? a.plan[0] : n_pchunks;
         const int per = (c_split + a.ps - 1) / a.ps;
         const int c0 = split * per, c1 = min(c_split, c0 + per);
@@ -771,6 +782,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
         return cnt;
     };
     // point ranges of a scoring dispatch with hb hypothesis blocks (counts are accumulated by atomics, so the cut may differ per dispatch)
+    auto score_grid = [](int hb, int ps) { return 8 * ((hb + 8 / RS_XCD_R - 1) / (8 / RS_XCD_R)) * ((ps + RS_XCD_R - 1) / RS_XCD_R); };   // k_ransac_score_fast's job-A workgroups
     auto ranges_for = [&](int hb) {
         const int ps = std::max(1, std::min(std::min((RS_WG_TARGET + hb - 1) / hb, std::max(1, n_pchunks / 32)), 512));
         const int per = (n_pchunks + ps - 1) / ps;
@@ -824,7 +836,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                     // the prefix counts of the pending one (a lower bound of its full counts - a bound is all the rule needs).
                     k_ransac_plan<<<1, 1, 0, s>>>(d_state, d_plan[q], ns, n_pchunks, ps, drop_permille);
                     ScoreJob ja{hyp[q], counts[q], d_plan[q], nullptr, hb, ps};
-                    const int g1 = (hb * ps + 7) / 8 * 8;     // (job B's XCD numbering starts at a multiple of 8; the few ids past hb * ps walk an empty range)
+                    const int g1 = score_grid(hb, ps);        // (a multiple of 8: job B's XCD numbering starts there)
                     if (pending >= 0) TDV_TRY(finish_pending(&ja, g1));
                     else {
                         ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
@@ -852,7 +864,8 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
                 } else {
                     ScopedTimer tm(ctx, TDV_TIMER_RANSAC_SCORE);
                     ScoreJob ja{hyp[q], counts[q], nullptr, nullptr, hb, ps};
-                    k_ransac_score_fast<<<hb * ps, RS_BLOCK, 0, s>>>(ja, ja, hb * ps, h_pad, pq2, n_pchunks, tau, d_rescored);
+                    const int gA = score_grid(hb, ps);
+                    k_ransac_score_fast<<<gA, RS_BLOCK, 0, s>>>(ja, ja, gA, h_pad, pq2, n_pchunks, tau, d_rescored);
                 }
                 wave_chunks += (double)hb * (RS_BLOCK / 64) * (double)n_pchunks;
             }
