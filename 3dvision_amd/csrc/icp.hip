@@ -90,10 +90,17 @@ void k_icp_nn_scan(const float* __restrict__ src, int ns, int ns_pad,
                    const IcpState* __restrict__ st,
                    float* __restrict__ pd2, int* __restrict__ pchunk) {
     if (st->done) return;
-    const int split = blockIdx.y;
+    // XCD-aware deal (round 4, as k_ransac_score_fast): workgroups are dispatched x-fastest and an XCD takes every eighth of them, so with
+    // the plain mapping every XCD's L2 pulled ALL target splits (PMC round 3: 49.7 MB per launch for 7.2 MB).  When the split count is a
+    // multiple of 8 an XCD takes every eighth SPLIT and all source blocks of it: its L2 holds an eighth of the targets.
+    int bxi = blockIdx.x, split = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x, k = lin >> 3;
+        bxi = k % gridDim.x; split = (k / gridDim.x) * 8 + (lin & 7);
+    }
     const int c0 = split * chunks_per_split;
     const int c1 = min(n_chunks, c0 + chunks_per_split);
-    const int base = blockIdx.x * NN_SRC_PER_BLOCK + threadIdx.x;
+    const int base = bxi * NN_SRC_PER_BLOCK + threadIdx.x;
     float px[NN_SPL], py[NN_SPL], pz[NN_SPL], best[NN_SPL];
     int bc[NN_SPL];
 #pragma unroll
