@@ -122,6 +122,37 @@ def test_icp_step_against_numpy_least_squares(orc, synth):
     assert np.allclose(one["T"], D @ T0.astype(np.float64), atol=2e-5)
 
 
+def test_icp_sums_are_sequential_float32_sums_in_source_order(orc, synth):
+    """What the GPU's reference-order mode is held to (tests/test_gpu_icp_reference_order.py) is itself pinned here, without the
+    oracle's code: registration.cpp:340-341,353-354 add one correspondence after the other in float, in ascending source index.  numpy's
+    cumsum IS that sequential float32 sum (add.reduce would be pairwise): its last element must equal the oracle's total_error, ATA and ATb
+    bit for bit, the terms being single float32 operations in the oracle's expression order."""
+    f = np.float32
+    tgt, nrm = synth.sample_object(3000, 2)
+    src, T_gt = synth.make_scene(2500, 2)
+    T0 = synth.perturb(T_gt, angle_deg=0.4, trans=0.0008)
+    thr = 0.004
+    r = orc.icp_correspondences(src, tgt, nrm, T0, thr)
+    a = r["accepted"]; assert a.sum() > 500
+    R = T0[:3, :3].astype(f); t = T0[:3, 3].astype(f)
+    s = src.astype(f)
+    p = np.stack([(R[k, 0] * s[:, 0] + (R[k, 1] * s[:, 1] + R[k, 2] * s[:, 2])) + t[k] for k in range(3)], 1).astype(f)     # c0 + (c1 + c2), then + t
+    q = tgt[r["corr"]].astype(f); n = nrm[r["corr"]].astype(f)
+    d = p - q
+    d2 = (d[:, 0] * d[:, 0] + (d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])).astype(f)
+    assert d2.tobytes() == r["d2"].tobytes()
+    J = np.stack([p[:, 1] * n[:, 2] - p[:, 2] * n[:, 1], p[:, 2] * n[:, 0] - p[:, 0] * n[:, 2], p[:, 0] * n[:, 1] - p[:, 1] * n[:, 0], n[:, 0], n[:, 1], n[:, 2]], 1).astype(f)
+    res = (d[:, 0] * n[:, 0] + (d[:, 1] * n[:, 1] + d[:, 2] * n[:, 2])).astype(f)
+    seq = lambda v: np.cumsum(np.concatenate([[f(0)], v[a].astype(f)]), dtype=f)[-1]          # 0 + v0 + v1 + ... one rounding per step
+    assert f(seq(d2)).tobytes() == f(r["total_error"]).tobytes()
+    for i in range(6):
+        assert f(seq(J[:, i] * res)).tobytes() == f(r["ATb"][i]).tobytes(), i
+        for k in range(6):
+            assert f(seq(J[:, i] * J[:, k])).tobytes() == f(r["ATA"][i, k]).tobytes(), (i, k)
+    # and a pairwise (tree) sum of the same terms is NOT that number: the order is what the test pins
+    assert f(np.add.reduce((J[:, 0] * J[:, 0])[a].astype(f))).tobytes() != f(r["ATA"][0, 0]).tobytes() or a.sum() < 64
+
+
 def test_ransac_hypothesis_and_score_against_numpy(orc, synth):
     tgt, _ = synth.sample_object(2500, 4)
     src, T_gt = synth.make_scene(2000, 4)
