@@ -265,6 +265,7 @@ void tdv_ctx_destroy(tdv_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->blocks) (void)hipFree(b.p);
     if (ctx->scan_ticket) (void)hipFree(ctx->scan_ticket);
+    if (ctx->chain_status) (void)hipFree(ctx->chain_status);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& t : ctx->timers) for (auto& p : t.pending) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -6,11 +6,12 @@
 //   depth  = float(raw) * float(1.0/scale), zero where the mask rejects the pixel
 //   keep 0 < z <= zmax ; x = (u - cx) * z / fx ; y = (v - cy) * z / fy ; colour = BGR->RGB / 255
 // and — unlike the reference's CUDA kernel, whose global atomicAdd makes the order
-// nondeterministic — points are emitted in the CPU's row-major scan order:
-//   pass 1 (k_valid_count)  : 1024 pixels per workgroup, ballot/popcount -> one count per block
-//   pass 2 (k_block_scan)   : exclusive scan of the block counts (one workgroup)
-//   pass 3 (k_emit)         : recompute validity, wave-ballot prefix + block offset -> slot
-// Algorithmic HBM bytes per frame (fused u16+mask+bgr path): 2x(2+1) in + 3 in + 24n out.
+// nondeterministic — points are emitted in the CPU's row-major scan order.  One frame is ONE launch (round 4, k_depth_cloud_chain):
+// a workgroup takes the next tile of 1,024 pixels (a ticket), counts its valid pixels, learns how many precede it from the tiles before it
+// (a chained scan: every tile publishes its count, then its inclusive prefix, in one 64-bit word; a wave looks back over 64 predecessors
+// at a time) and writes its points.  Rounds 1-3 ran three launches (count per block, scan of the blocks, emit), whose two launch gaps
+// were half of the 13 us a frame took; they are kept in the study build (TDV_DEPTH_THREE_PASS=1).
+// Algorithmic HBM bytes per frame (fused u16+mask+bgr path): 2 + 1 in (+ 3 per valid pixel) + 12n (24n) out.
 #include "tdv_internal.hpp"
 #include <cfloat>
 #include <cmath>
@@ -68,6 +69,7 @@ __device__ __forceinline__ float pixel_depth(const uint16_t* __restrict__ raw, c
     return depth[i];
 }
 
+#ifdef TDV_STUDY
 template <bool RAW>
 __global__ __launch_bounds__(DP_BLOCK)
 void k_valid_count(const uint16_t* __restrict__ raw, const float* __restrict__ depth, const uint8_t* __restrict__ mask,
@@ -165,6 +167,143 @@ void k_emit(const uint16_t* __restrict__ raw, const float* __restrict__ depth, c
             }
         }
         run += (wcnt[k][0] + wcnt[k][1]) + (wcnt[k][2] + wcnt[k][3]);
+    }
+}
+
+#endif  // TDV_STUDY
+
+// One frame in one launch: tile = ticket, chained scan over the tiles' counts, emit.
+// status[tile] = epoch << 34 | state << 32 | value; state 1: value = the tile's own count, 2: value = the inclusive prefix up to and with
+// the tile.  The epoch (one per call) makes words of earlier calls read as "not there yet" - the array is never cleared.  Tickets are
+// handed out in the order workgroups START, so every tile a workgroup waits for is already running and publishes its count without
+// waiting for anything: the chain cannot deadlock.  A wave that waited CHAIN_SPIN_LIMIT rounds gives up and reports it (fail word) instead of
+// hanging the GPU - that would be a bug here, not a state of the machine.
+// Tiles are 4,096 pixels (1,024 threads): a 1280 x 720 frame is 225 tiles - one round of workgroups, all running at once - and the wave that
+// looks back reads 256 predecessors per round trip (four loads per lane in flight), so such a frame's whole scan is one publish and one
+// read.  (First version: 1,024-pixel tiles and 64 predecessors per round; the last of 900 tiles walked 15 dependent device-scope round
+// trips, 22.6 us per frame against the three launches' 13.1.)
+constexpr int CHAIN_SPIN_LIMIT = 1 << 22;
+constexpr int CH_BLOCK = 1024, CH_WAVES = CH_BLOCK / 64, CH_TILE = CH_BLOCK * DP_PX_PER_THREAD, CH_LOOK = 4;
+template <bool RAW, bool VEC>
+__global__ __launch_bounds__(CH_BLOCK)
+void k_depth_cloud_chain(const uint16_t* __restrict__ raw, const float* __restrict__ depth, const uint8_t* __restrict__ mask,
+                         const uint8_t* __restrict__ bgr, int width, size_t n, float inv_scale, int mask_mode,
+                         float fx, float fy, float cx, float cy, float zmax,
+                         unsigned* __restrict__ ticket, unsigned ticket_base, unsigned long long* __restrict__ status, unsigned epoch, int ntiles,
+                         int capacity, float* __restrict__ xyz, float* __restrict__ rgb, int* __restrict__ host_total /* pinned: [0] total, [1] fail */) {
+    __shared__ int s_tile, s_excl;
+    __shared__ int wcnt[CH_WAVES];
+    if (threadIdx.x == 0) s_tile = (int)(atomicAdd(ticket, 1u) - ticket_base);
+    __syncthreads();
+    const int tile = s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // four CONSECUTIVE pixels per lane: one 8-byte depth load, one 4-byte mask load
+    const size_t i0 = (size_t)tile * CH_TILE + (size_t)threadIdx.x * DP_PX_PER_THREAD;
+    float zs[DP_PX_PER_THREAD]; bool ok[DP_PX_PER_THREAD];
+    if (VEC && i0 + DP_PX_PER_THREAD <= n) {
+        if (RAW) {
+            const ushort4 r = *reinterpret_cast<const ushort4*>(raw + i0);
+            zs[0] = (float)r.x * inv_scale; zs[1] = (float)r.y * inv_scale; zs[2] = (float)r.z * inv_scale; zs[3] = (float)r.w * inv_scale;
+            if (mask) {
+                const uchar4 m = *reinterpret_cast<const uchar4*>(mask + i0);
+                if (!mask_keeps(m.x, mask_mode)) zs[0] = 0.f;
+                if (!mask_keeps(m.y, mask_mode)) zs[1] = 0.f;
+                if (!mask_keeps(m.z, mask_mode)) zs[2] = 0.f;
+                if (!mask_keeps(m.w, mask_mode)) zs[3] = 0.f;
+            }
+        } else {
+            const float4 d = *reinterpret_cast<const float4*>(depth + i0);
+            zs[0] = d.x; zs[1] = d.y; zs[2] = d.z; zs[3] = d.w;
+        }
+#pragma unroll
+        for (int k = 0; k < DP_PX_PER_THREAD; ++k) ok[k] = !(zs[k] <= 0.f || zs[k] > zmax);
+    } else {
+#pragma unroll
+        for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+            const size_t i = i0 + k;
+            zs[k] = i < n ? pixel_depth<RAW>(raw, depth, mask, i, inv_scale, mask_mode) : 0.f;
+            ok[k] = i < n && !(zs[k] <= 0.f || zs[k] > zmax);
+        }
+    }
+    // rank of pixel (lane, k) inside its wave: pixels of lower lanes, then the lane's own earlier pixels
+    int before = 0, wave_total = 0, own = 0;
+    int rank[DP_PX_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        const unsigned long long b = __ballot(ok[k]);
+        before += __popcll(b & ((1ull << lane) - 1ull));
+        wave_total += __popcll(b);
+        rank[k] = own;
+        own += ok[k] ? 1 : 0;
+    }
+    if (lane == 0) wcnt[wave] = wave_total;
+    __syncthreads();
+    if (wave == 0) {
+        int total = lane < CH_WAVES ? wcnt[lane] : 0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+        total = __shfl(total, 0, 64);
+        const unsigned long long tag = (unsigned long long)epoch << 34;
+        if (lane == 0) __hip_atomic_store(&status[tile], tag | ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int excl = 0; bool failed = false;
+        for (int look = tile - 1; look >= 0; look -= 64 * CH_LOOK) {
+            unsigned long long sv[CH_LOOK];      // predecessor look - (64 j + lane): near to far
+            int spins = 0;
+            while (true) {
+                bool ready = true;
+#pragma unroll
+                for (int j = 0; j < CH_LOOK; ++j) {
+                    const int idx = look - (64 * j + lane);
+                    sv[j] = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tag | (2ull << 32));   // before the first tile: an inclusive prefix of 0
+                }
+#pragma unroll
+                for (int j = 0; j < CH_LOOK; ++j) ready = ready && (unsigned)(sv[j] >> 34) == epoch && ((sv[j] >> 32) & 3ull) != 0ull;
+                if (__all(ready)) break;
+                if (++spins > CHAIN_SPIN_LIMIT) { failed = true; break; }      // (wave-uniform: every lane counts the same rounds)
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (failed) break;
+            int v = 0; bool cut = false;                                         // nothing beyond the nearest inclusive prefix
+#pragma unroll
+            for (int j = 0; j < CH_LOOK; ++j) {
+                const unsigned long long m = __ballot(((sv[j] >> 32) & 3ull) == 2ull);
+                if (!cut && (!m || lane <= __ffsll((long long)m) - 1)) v += (int)(unsigned)sv[j];
+                cut = cut || m != 0ull;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            excl += v;
+            if (cut) break;
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&status[tile], tag | (2ull << 32) | (unsigned)(excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if (failed) { host_total[1] = 1; __threadfence_system(); }
+            if (tile == ntiles - 1) { host_total[0] = excl + total; __threadfence_system(); }   // straight into pinned host memory: a 4-byte D2H copy is a 9-us blit kernel
+        }
+    }
+    __syncthreads();
+    if (!xyz) return;
+    int slot0 = s_excl + before;
+#pragma unroll
+    for (int w = 0; w < CH_WAVES; ++w) slot0 += (w < wave) ? wcnt[w] : 0;
+#pragma unroll
+    for (int k = 0; k < DP_PX_PER_THREAD; ++k) {
+        const int slot = slot0 + rank[k];
+        if (ok[k] && slot < capacity) {
+            const size_t i = i0 + k;
+            const int v = (int)(i / width), u = (int)(i - (size_t)v * width);
+            const float z = zs[k];
+            const float x = ((float)u - cx) * z / fx;   // pipeline.cpp:73
+            const float y = ((float)v - cy) * z / fy;   // pipeline.cpp:74
+            xyz[3 * (size_t)slot] = x; xyz[3 * (size_t)slot + 1] = y; xyz[3 * (size_t)slot + 2] = z;
+            if (rgb && bgr) {
+                const uint8_t* p = bgr + i * 3;
+                rgb[3 * (size_t)slot] = (float)p[2] / 255.0f;
+                rgb[3 * (size_t)slot + 1] = (float)p[1] / 255.0f;
+                rgb[3 * (size_t)slot + 2] = (float)p[0] / 255.0f;
+            }
+        }
     }
 }
 
@@ -868,15 +1007,58 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
     const size_t n = (size_t)w * h;
     if (n == 0) return TDV_OK;
     const float inv_scale = (float)(1.0 / (double)scale);
+    TDV_TRY(pin_reserve(ctx, 64));
+    hipStream_t s = ctx->stream;
+    int* h_total = reinterpret_cast<int*>(ctx->pin);
+    const bool three_pass = study_env("TDV_DEPTH_THREE_PASS") && atoi(study_env("TDV_DEPTH_THREE_PASS")) == 1;     // (study build: rounds 1-3)
+    if (!three_pass) {
+        const int tiles = (int)((n + CH_TILE - 1) / CH_TILE);
+        // the chain's persistent state: status words (never cleared: the epoch tells this call's words from older ones) and the ticket
+        if ((size_t)tiles > ctx->chain_cap || ctx->chain_epoch >= (1u << 30) - 2u) {
+            TDV_HIP(ctx, hipStreamSynchronize(s));
+            if (ctx->chain_status) (void)hipFree(ctx->chain_status);
+            ctx->chain_status = nullptr; ctx->chain_cap = 0;
+            const size_t cap = std::max<size_t>((size_t)tiles, 4096);
+            TDV_HIP(ctx, hipMalloc((void**)&ctx->chain_status, cap * sizeof(unsigned long long)));
+            TDV_HIP(ctx, hipMemset(ctx->chain_status, 0, cap * sizeof(unsigned long long)));
+            ctx->chain_cap = cap; ctx->chain_epoch = 0;
+        }
+        const unsigned epoch = ++ctx->chain_epoch;
+        unsigned* ticket = ctx->scan_ticket + 8;
+        h_total[0] = -1; h_total[1] = 0;
+        float* xyz = (d_xyz && capacity > 0) ? d_xyz : nullptr;
+        const bool vec = d_raw ? (((uintptr_t)d_raw & 7) == 0 && (!d_mask || ((uintptr_t)d_mask & 3) == 0)) : (((uintptr_t)d_depth & 15) == 0);
+        {
+            ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
+#define TDV_CHAIN(RW, VC) k_depth_cloud_chain<RW, VC><<<tiles, CH_BLOCK, 0, s>>>(d_raw, d_depth, d_raw ? d_mask : nullptr, d_bgr, w, n, d_raw ? inv_scale : 0.f, \
+            d_raw ? mask_mode : 0, fx, fy, cx, cy, zmax, ticket, ctx->chain_ticket_base, ctx->chain_status, epoch, tiles, capacity, xyz, d_rgb, h_total)
+            if (d_raw) { if (vec) TDV_CHAIN(true, true); else TDV_CHAIN(true, false); }
+            else { if (vec) TDV_CHAIN(false, true); else TDV_CHAIN(false, false); }
+#undef TDV_CHAIN
+        }
+        ctx->chain_ticket_base += (unsigned)tiles;
+        const hipError_t le = hipGetLastError();
+        const hipError_t se = le == hipSuccess ? hipStreamSynchronize(s) : le;
+        if (se != hipSuccess || h_total[1] != 0 || h_total[0] < 0) {
+            // the ticket word and the host's base may no longer agree (a launch that did not run): start over
+            (void)hipMemset(ctx->scan_ticket + 8, 0, 4); ctx->chain_ticket_base = 0;
+            if (se != hipSuccess) return set_err(ctx, se, "k_depth_cloud_chain", __LINE__);
+            snprintf(ctx->err, sizeof(ctx->err), "%s", h_total[1] ? "depth_to_cloud: the chained scan gave up waiting for a tile" : "depth_to_cloud: the count did not reach the host");
+            return TDV_ERR_INTERNAL;
+        }
+        *n_out = h_total[0];
+        if (h_total[0] > capacity) return TDV_ERR_BAD_ARG;  // caller's buffers too small; *n_out = needed
+        return TDV_OK;
+    }
+#ifdef TDV_STUDY
     const int blocks = (int)((n + DP_PX_PER_BLOCK - 1) / DP_PX_PER_BLOCK);
     int *counts, *offsets;
     TDV_TRY(ws_alloc(ctx, (size_t)blocks, &counts));
     TDV_TRY(ws_alloc(ctx, (size_t)blocks + 1, &offsets));
-    TDV_TRY(pin_reserve(ctx, 64));
-    hipStream_t s = ctx->stream;
     {
         ScopedTimer tm(ctx, TDV_TIMER_DEPTH);
-        if (d_raw) k_valid_count<true><<<blocks, DP_BLOCK, 0, s>>>(d_raw, nullptr, d_mask, n, inv_scale, mask_mode, zmax, counts);
+        if (d_raw) k_valid_count<true>
+<<<blocks, DP_BLOCK, 0, s>>>(d_raw, nullptr, d_mask, n, inv_scale, mask_mode, zmax, counts);
         else k_valid_count<false><<<blocks, DP_BLOCK, 0, s>>>(nullptr, d_depth, nullptr, n, 0.f, 0, zmax, counts);
         int* h_total0 = reinterpret_cast<int*>(ctx->pin);
         *h_total0 = -1;
@@ -887,12 +1069,14 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
         }
     }
     TDV_CHECK_LAUNCH(ctx);
-    int* h_total = reinterpret_cast<int*>(ctx->pin);
     TDV_HIP(ctx, hipStreamSynchronize(s));
     if (*h_total < 0) { snprintf(ctx->err, sizeof(ctx->err), "depth_to_cloud: the count did not reach the host"); return TDV_ERR_INTERNAL; }
     *n_out = *h_total;
     if (*h_total > capacity) return TDV_ERR_BAD_ARG;  // caller's buffers too small; *n_out = needed
     return TDV_OK;
+#else
+    return TDV_ERR_INTERNAL;
+#endif
 }
 
 }  // namespace tdv

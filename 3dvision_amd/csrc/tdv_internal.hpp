@@ -42,7 +42,10 @@ struct tdv_ctx {
     int last_fm_path = 0;      // TDV_FM_PATH_* of the last descriptor match on this ctx (tdv_ctx_last_feature_match_path)
     int last_batch_lanes = 0;  // host lanes the last tdv_register_batch_dev call on this ctx spread its instances over (tdv_ctx_last_batch_lanes)
     int last_icp_search = 0; // the search the last ICP / correspondence call on this ctx actually ran (tdv_ctx_last_icp_search)
-    unsigned* scan_ticket = nullptr;  // persistent device word of exclusive_scan_dev (last-workgroup ticket)
+    unsigned* scan_ticket = nullptr;  // persistent device words: [0] exclusive_scan_dev's last-workgroup ticket, [1..] ICP's, [8] the tile ticket of depth.hip's chained scan
+    unsigned long long* chain_status = nullptr;   // depth.hip k_depth_cloud_chain: one status word per tile, persistent (told apart by chain_epoch)
+    size_t chain_cap = 0;
+    unsigned chain_epoch = 0, chain_ticket_base = 0;   // calls so far; tickets handed out so far (the kernel's tile = ticket - base)
     uint16_t* depth_bits = nullptr;   // validity bitmap between the two passes of the batched depth -> cloud (workspace memory of the current call)
     tdv_ctx* helper = nullptr;   // second stream + workspace of the batched pipeline's other lane (owned; created on first use)
     tdv::TimerSlot timers[TDV_TIMER_COUNT];

@@ -112,3 +112,83 @@ def test_label_image_masks(ctx, orc, tdv):
         xyz, rgb = ctx.depth_to_cloud(raw, labels, bgr, 1000.0, 600, 600, 65, 48, 10.0, tdv.TDV_MASK_LABEL_BASE + lab)
         assert xyz.tobytes() == ref_xyz.tobytes() and rgb.tobytes() == ref_rgb.tobytes()
         assert ctx.depth_preprocess(raw, labels, 1000.0, tdv.TDV_MASK_LABEL_BASE + lab).tobytes() == orc.depth_preprocess(raw, binmask, 1000.0).tobytes()
+
+
+def _numpy_cloud(raw, mask, scale, fx, fy, cx, cy, zmax):
+    """src/pipeline.cpp:46-54,61-84 in numpy float32 (the oracle's loop is slow at megapixels): same operations, same order."""
+    z = raw.astype(np.float32) * np.float32(1.0 / scale)
+    if mask is not None:
+        z[mask <= 10] = 0
+    keep = ~((z <= 0) | (z > np.float32(zmax)))
+    v, u = np.nonzero(keep)
+    zz = z[keep]
+    x = (u.astype(np.float32) - np.float32(cx)) * zz / np.float32(fx)
+    y = (v.astype(np.float32) - np.float32(cy)) * zz / np.float32(fy)
+    return np.stack([x, y, zz], axis=1)
+
+
+def test_one_launch_chain_many_tiles_and_repeated_calls(ctx, orc):
+    """k_depth_cloud_chain (round 4): tiles of 4,096 pixels chained through persistent status words.  Frames of 1 tile, 225 tiles
+    (one look-back round), ~2,000 tiles (several rounds, inclusive prefixes of finished tiles cut the walk), a ragged last tile; the same
+    ctx alternates sizes, so words of earlier calls (older epochs) lie in the array; results equal numpy's and, at the small size, the oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    sizes = [(16, 16), (720, 1280), (2160, 3840), (97, 131), (2161, 3839), (720, 1280), (1, 1), (64, 64), (2160, 3840)]
+    for rep, (h, w) in enumerate(sizes):
+        rng = np.random.default_rng(1000 + rep)
+        raw = rng.integers(0, 3000, (h, w)).astype(np.uint16)
+        raw[rng.random((h, w)) < (0.1 + 0.2 * (rep % 4))] = 0
+        mask = rng.choice(np.array([0, 5, 10, 11, 200], np.uint8), (h, w), p=[0.2, 0.1, 0.1, 0.3, 0.3])
+        if rep == 2:
+            mask[: h // 2] = 0                                                   # hundreds of tiles without a single point
+        ref = _numpy_cloud(raw, mask, 1000.0, 611.5, 609.25, w / 2.0, h / 2.0, 2.5)
+        d_raw = torch.from_numpy(raw.view(np.int16)).to(dev); d_mask = torch.from_numpy(mask).to(dev)
+        d_xyz = torch.full((h * w, 3), -7.0, dtype=torch.float32, device=dev)
+        n = ctx.depth_to_cloud_dev(d_raw.data_ptr(), d_mask.data_ptr(), None, w, h, 1000.0, 611.5, 609.25, w / 2.0, h / 2.0, 2.5, d_xyz.data_ptr(), None, h * w)
+        assert n == len(ref), (h, w, n, len(ref))
+        assert d_xyz[:n].cpu().numpy().tobytes() == ref.astype(np.float32).tobytes(), (h, w)
+        assert bool((d_xyz[n:] == -7.0).all())                                   # nothing written past the count
+        if h * w < 20000:
+            oxyz, _ = orc.unproject(orc.depth_preprocess(raw, mask, 1000.0), None, 611.5, 609.25, w / 2.0, h / 2.0, 2.5)
+            assert oxyz.tobytes() == ref.tobytes()
+
+
+def test_one_launch_chain_unaligned_buffers_and_small_capacity(ctx, tdv):
+    """Pointers that do not allow the 8-byte depth / 4-byte mask loads take the scalar loads; a capacity below the count returns the count needed."""
+    import torch
+    dev = torch.device("cuda", 0)
+    h, w = 301, 517
+    rng = np.random.default_rng(77)
+    raw = rng.integers(1, 2000, (h, w)).astype(np.uint16); mask = rng.choice(np.array([0, 255], np.uint8), (h, w))
+    ref = _numpy_cloud(raw, mask, 1000.0, 500.0, 500.0, 250.0, 150.0, 1.5)
+    buf_r = torch.zeros(h * w + 8, dtype=torch.int16, device=dev); buf_m = torch.zeros(h * w + 8, dtype=torch.uint8, device=dev)
+    for shift_r, shift_m in ((1, 0), (0, 1), (3, 3), (0, 0)):
+        buf_r[shift_r:shift_r + h * w] = torch.from_numpy(raw.view(np.int16).ravel()).to(dev); buf_m[shift_m:shift_m + h * w] = torch.from_numpy(mask.ravel()).to(dev)
+        d_xyz = torch.empty((h * w, 3), dtype=torch.float32, device=dev)
+        n = ctx.depth_to_cloud_dev(buf_r.data_ptr() + 2 * shift_r, buf_m.data_ptr() + shift_m, None, w, h, 1000.0, 500.0, 500.0, 250.0, 150.0, 1.5, d_xyz.data_ptr(), None, h * w)
+        assert n == len(ref) and d_xyz[:n].cpu().numpy().tobytes() == ref.tobytes(), (shift_r, shift_m)
+    with pytest.raises(tdv.TdvError):
+        ctx.depth_to_cloud_dev(buf_r.data_ptr(), buf_m.data_ptr(), None, w, h, 1000.0, 500.0, 500.0, 250.0, 150.0, 1.5, d_xyz.data_ptr(), None, len(ref) - 1)
+    n = ctx.depth_to_cloud_dev(buf_r.data_ptr(), buf_m.data_ptr(), None, w, h, 1000.0, 500.0, 500.0, 250.0, 150.0, 1.5, d_xyz.data_ptr(), None, h * w)      # the ctx goes on working
+    assert n == len(ref)
+
+
+@pytest.mark.study
+def test_three_launch_path_equals_the_chain(ctx):
+    """Rounds 1-3 (count per block, scan, emit: TDV_DEPTH_THREE_PASS=1, study library) against the one-launch chain: same points, same order."""
+    import os
+    import torch
+    dev = torch.device("cuda", 0)
+    out = {}
+    for (h, w) in ((97, 131), (720, 1280)):
+        raw, mask, bgr = _random_frame(h + w, h, w)
+        d_raw = torch.from_numpy(raw.view(np.int16)).to(dev); d_mask = torch.from_numpy(mask).to(dev); d_bgr = torch.from_numpy(bgr).to(dev)
+        try:
+            for mode in ("0", "1"):
+                os.environ["TDV_DEPTH_THREE_PASS"] = mode
+                d_xyz = torch.zeros((h * w, 3), dtype=torch.float32, device=dev); d_rgb = torch.zeros_like(d_xyz)
+                n = ctx.depth_to_cloud_dev(d_raw.data_ptr(), d_mask.data_ptr(), d_bgr.data_ptr(), w, h, 1000.0, 611.5, 609.25, 60.0, 50.0, 2.0, d_xyz.data_ptr(), d_rgb.data_ptr(), h * w)
+                out[mode] = (n, d_xyz.cpu().numpy().tobytes(), d_rgb.cpu().numpy().tobytes())
+        finally:
+            os.environ.pop("TDV_DEPTH_THREE_PASS", None)
+        assert out["0"] == out["1"] and out["0"][0] > 0

@@ -1,7 +1,7 @@
 """The A/B variants that lost their measurement live in lib3dvision_hip_study.so (-DTDV_STUDY; csrc/tdv_internal.hpp: study_env), not in
 the product library: the matrix-core scoring pass (k_ransac_score_mfma), the merged scoring dispatch (TDV_RANSAC_MERGE), round 1's
 key-ordered descriptor scan (TDV_FM_KEYORDER), the two-round leaf-major search (TDV_LM_ROUNDS), one-point-per-wave SPFH / FPFH
-(TDV_FPFH_PAIRS=0).  Their parity tests still run - here, in a process of its own that loads the study library - so a variant
+(TDV_FPFH_PAIRS=0), the three-launch depth -> cloud (TDV_DEPTH_THREE_PASS=1).  Their parity tests still run - here, in a process of its own that loads the study library - so a variant
 kept as a record stays a correct record.  The product library's own tests are everything else in this directory."""
 import os
 import subprocess
@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VARIANT_TESTS = ("four_paths or fast_scoring_equals_exact or fast_scoring_over_magnitudes or bailout_returns_the_reference or in_batch_rule "
-                 "or two_points_per_wave or leaf_major_fuzz or c3_features_at_100k")
+                 "or two_points_per_wave or leaf_major_fuzz or c3_features_at_100k or three_launch_path")
 
 
 def test_variant_parity_on_the_study_library(tdv):
