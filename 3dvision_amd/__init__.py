@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "tdv_ctx_destroy", "tdv_status_string", "tdv_last_error", "tdv_version", "tdv_timing_enable", "tdv_timing_read",
     "tdv_depth_preprocess", "tdv_deproject", "tdv_depth_to_cloud", "tdv_voxel_downsample", "tdv_estimate_normals",
     "tdv_compute_fpfh", "tdv_feature_match", "tdv_ransac", "tdv_icp", "tdv_icp_correspondences",
-    "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev", "tdv_normals_fpfh_dev",
+    "tdv_icp_dev", "tdv_ransac_dev", "tdv_feature_match_dev", "tdv_estimate_normals_dev", "tdv_compute_fpfh_dev", "tdv_normals_fpfh_dev", "tdv_radix_sort_pairs_dev",
     "tdv_depth_to_cloud_dev", "tdv_voxel_downsample_dev", "tdv_sample_triples", "tdv_pose_compose",
     "tdv_register_batch_dev", "tdv_prepare_model_dev", "tdv_bilateral_filter", "tdv_filter_duplicates", "tdv_load_ply_ascii", "tdv_load_mask_png", "tdv_load_masks_from_dir",
     "tdv_depth_to_cloud_batch_dev", "tdv_broadcast_model", "tdv_gather_results", "tdv_mask_resize_nearest", "tdv_mask_resize_nearest_dev", "tdv_voxel_downsample_batch_dev", "tdv_voxel_downsample_batch_pinhole_dev",
@@ -425,6 +425,11 @@ class Context:
     def normals_fpfh_dev(self, d_xyz, n, k, radius, d_normals, d_desc):
         """estimateNormals(k) + computeFPFH(radius) with one neighbour walk (device pointers); same bits as the two calls."""
         _check(self._h, lib().tdv_normals_fpfh_dev(self._h, _ptr(d_xyz), n, k, C.c_float(radius), _ptr(d_normals), _ptr(d_desc)), "tdv_normals_fpfh_dev")
+
+    def radix_sort_pairs_dev(self, d_keys_in, d_keys_out, d_vals_in, d_vals_out, n, end_bit):
+        """Stable sort of n (u64 key, u32 value) pairs on the low end_bit bits of the key (device pointers; csrc/sort.hip)."""
+        _check(self._h, lib().tdv_radix_sort_pairs_dev(self._h, _ptr(d_keys_in), _ptr(d_keys_out), _ptr(d_vals_in), _ptr(d_vals_out), C.c_size_t(n), end_bit),
+               "tdv_radix_sort_pairs_dev")
 
     def depth_to_cloud_dev(self, d_raw, d_mask, d_bgr, w, h, scale, fx, fy, cx, cy, zmax, d_xyz, d_rgb, capacity,
                            mask_mode=TDV_MASK_THRESHOLD10):

@@ -324,6 +324,12 @@ int tdv_normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float r
     TDV_TRY(normals_fpfh_dev(ctx, d_xyz, n, k, radius, d_normals, d_desc33));
     return finish(ctx);
 }
+int tdv_radix_sort_pairs_dev(tdv_ctx* ctx, const unsigned long long* d_keys_in, unsigned long long* d_keys_out, const unsigned* d_vals_in,
+                             unsigned* d_vals_out, size_t n, int end_bit) {
+    TDV_TRY(begin(ctx));
+    TDV_TRY(radix_sort_pairs_dev(ctx, d_keys_in, d_keys_out, d_vals_in, d_vals_out, n, end_bit));
+    return finish(ctx);
+}
 int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, const uint8_t* d_bgr,
                            int width, int height, float scale, int mask_mode,
                            float fx, float fy, float cx, float cy, float zmax,

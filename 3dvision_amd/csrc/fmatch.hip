@@ -1687,7 +1687,7 @@ int fm_index_build(tdv_ctx* ctx, const float* d_ft, int nt, FmIndex* ix) {
     const unsigned gn = (unsigned)((nt + 255) / 256);
     TDV_HIP(ctx, hipMemsetAsync(ix->amax, 0, 4, s));
     k_fm_project<<<gn, 256, 0, s>>>(d_ft, nt, basis, p0, p1, p2, ix->amax);
-    // slabs along p0, columns along p1: two stable radix sorts of (key, row) pairs (rocPRIM; two bitonic sorts of 16-byte records,
+    // slabs along p0, columns along p1: two stable radix sorts of (key, row) pairs (csrc/sort.hip; two bitonic sorts of 16-byte records,
     // ~30 launches and 0.19 ms each at 150k rows, until the end of round 2)
     k_fm_key_p0<<<gn, 256, 0, s>>>(p0, nt, table, slot_of, key_a, row_a);
     TDV_TRY(radix_sort_pairs_dev(ctx, key_a, key_b, row_a, row_b, (size_t)nt, 33));   // the distinct rows lead; the copies follow

@@ -222,7 +222,7 @@ int voxel_reference_order(tdv_ctx* ctx, int v, int n, const int4* d_leaders, con
                           float* d_out_xyz, float* d_out_rgb, const VoxelBothOrders* both);
 
 int sort_records_dev(tdv_ctx* ctx, uint4* rec, size_t n_pow2);  // voxel.hip: ascending bitonic sort, n_pow2 >= 2048
-// sort.hip: stable radix sort (rocPRIM) of (key, value) pairs on the low end_bit bits of the 64-bit key; any n; scratch from the workspace
+// sort.hip: stable LSD radix sort (hand-written) of (key, value) pairs on the low end_bit bits of the 64-bit key; any n; scratch from the workspace
 int radix_sort_pairs_dev(tdv_ctx* ctx, const unsigned long long* d_keys_in, unsigned long long* d_keys_out,
                          const unsigned* d_vals_in, unsigned* d_vals_out, size_t n, int end_bit);
 // every segment [d_seg_start[c], d_seg_start[c + 1]) sorted on its own in one launch; segments of at most segment_sort_max_len() records

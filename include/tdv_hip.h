@@ -289,6 +289,11 @@ int tdv_compute_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, const float* d_normal
  * (tests/test_gpu_features.py); what tdv_register_batch_dev and tdv_prepare_model_dev run.  k <= 100 shares the walk; larger k falls
  * back to the two calls. */
 int tdv_normals_fpfh_dev(tdv_ctx* ctx, const float* d_xyz, int n, int k, float radius, float* d_normals, float* d_desc33);
+/* The stable radix sort the descriptor index build uses (csrc/sort.hip, hand-written: a utility without a counterpart in the reference,
+ * exported so that it is tested on its own): n (64-bit key, 32-bit value) pairs in device memory ordered by the low end_bit bits of the
+ * key, pairs of equal keys in input order.  The in and out buffers must not overlap. */
+int tdv_radix_sort_pairs_dev(tdv_ctx* ctx, const unsigned long long* d_keys_in, unsigned long long* d_keys_out, const unsigned* d_vals_in,
+                             unsigned* d_vals_out, size_t n, int end_bit);
 int tdv_depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_mask, const uint8_t* d_bgr,
                            int width, int height, float scale, int mask_mode,
                            float fx, float fy, float cx, float cy, float zmax,
