@@ -211,14 +211,16 @@ int register_batch_dev(tdv_ctx* ctx, const uint16_t* d_raw, const uint8_t* d_bgr
     // depend on the lanes.  Round 2 needed 12 lanes in the reference's voxel order to hide 3 ms of host replay per instance
     // (395 / 466 / 513 instances/s of C4 with 4 / 8 / 12 lanes); with the order made on the device large instances no longer
     // care much (round 3, C4, 256 instances: 613 / 603-628 / 631-667 / 625-651 with 2 / 4 / 6 / 8 lanes once the kernels of an instance
-    // had shrunk to 1.6 ms; the GPU is busy either way) and take 6.  Small instances are chains of
+    // had shrunk to 1.6 ms; the GPU is busy either way; round 4, three runs each on one box, instance kernels at 1.4 ms: 645-653 / 667-673 /
+    // 632-638 / 660-676 with 2 / 3 / 4 / 6 lanes) and take 3: the throughput of 6 with half the host threads and half the lane
+    // workspaces (8 caller threads x 6 lanes were 48 threads and ~10 GB of workspace per caller on a real host).  Small instances are chains of
     // launch-bound kernels and host read-backs and still gain from more lanes (C5, 1,024 instances of ~400 voxels:
     // 5,650 / 6,550 / 6,790 instances/s with 8 / 12 / 16): they take 12.  Never more than the host has hardware threads;
     // TDV_BATCH_LANES overrides (1 = the caller's thread only, at most 16).
     const int lanes_env = getenv("TDV_BATCH_LANES") ? atoi(getenv("TDV_BATCH_LANES")) : 0;   // read per call, like the other knobs (the tests switch it)
     const int hw_threads = std::max(1u, std::thread::hardware_concurrency());
     const bool small_instances = off[n_instances] / std::max(n_instances, 1) < 8192;      // points per instance, on average
-    const int lanes_default = std::min(small_instances ? 12 : 6, hw_threads);
+    const int lanes_default = std::min(small_instances ? 12 : 3, hw_threads);
     const int want = std::max(1, std::min(std::min(lanes_env > 0 ? lanes_env : lanes_default, 16), n_instances));
     std::vector<tdv_ctx*> lane_ctx{ctx};
     for (tdv_ctx* c = ctx; (int)lane_ctx.size() < want; c = c->helper) {
