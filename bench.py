@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--points", type=int, default=200000, help="N_s = N_t (headline: 200000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-operators", action="store_true", help="skip the per-operator block measured after the timed region")
+    ap.add_argument("--c5-timeout-s", type=float, default=300.0, help="N > 1: deadline of the C5 share; past it the line is printed without C5")
     ap.add_argument("--c5-instances", type=int, default=1024, help="N > 1: instances per rank of the C5 tray measured after the timed region")
     ap.add_argument("--cpu-budget-s", type=float, default=16.0)
     ap.add_argument("--min-region-ms", type=float, default=100.0,
@@ -321,14 +322,34 @@ def main():
     # N > 1: config C5 (BASELINE.json configs[4]) rides in the same line - every rank registers its own 1,024-instance tray, the model
     # moved once by tdv_broadcast_model and the results gathered once by tdv_gather_results (C ABI, ncclComm_t over RCCL); in the one-GPU
     # rehearsal (gloo) the same two steps go through torch.distributed.  Outside `value`.
-    c5_out = None
+    # The share has never met more than one device (no multi-GPU box in the builder's reach), so it must not be able to take the headline
+    # down with it: it runs on a thread of its own with a deadline.  An exception becomes `c5_error` in the line; a rank still inside a
+    # collective at the deadline is abandoned - the line is printed without C5 and every rank leaves through os._exit (all ranks share the
+    # deadline, so they leave together).
+    c5_out = None; c5_error = None; c5_hung = False
     if distributed and not args.no_operators:
+        import threading
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_c5
-        c5_ctx = tdv.Context(local_rank)
-        c5_out, c5_ok = bench_c5.tray_share(tdv, synth, sharding, c5_ctx, torch, dist, dev, rank, world, tdv.TDV_VOXEL_ORDER_REFERENCE, cdev,
-                                            instances_per_gpu=args.c5_instances)
-        c5_ctx.close()
+        box = {}
+
+        def c5_work():
+            try:
+                torch.cuda.set_device(local_rank)                     # (the current device is per host thread)
+                c5_ctx = tdv.Context(local_rank)
+                box["out"], box["ok"] = bench_c5.tray_share(tdv, synth, sharding, c5_ctx, torch, dist, dev, rank, world, tdv.TDV_VOXEL_ORDER_REFERENCE, cdev,
+                                                            instances_per_gpu=args.c5_instances)
+                c5_ctx.close()
+            except BaseException as e:                                 # noqa: BLE001 - reported, never fatal for the headline
+                box["err"] = "%s: %s" % (type(e).__name__, e)
+        th = threading.Thread(target=c5_work, name="c5-share", daemon=True)
+        th.start(); th.join(timeout=args.c5_timeout_s)
+        if th.is_alive():
+            c5_hung = True; c5_error = "the C5 share did not finish within %.0f s (abandoned; the headline above is unaffected)" % args.c5_timeout_s
+        elif "err" in box:
+            c5_error = box["err"]
+        else:
+            c5_out = box.get("out")
 
     if rank == 0:
         steps_total = steps_timed * world
@@ -486,6 +507,9 @@ def main():
             "result_check": {"icp_fitness": float(r_icp.fitness), "icp_rmse": float(r_icp.rmse), "ransac_inliers": int(r_rs.inliers),
                              "ransac_iterations_run": int(r_rs.iterations_run)},
         }
+        if c5_error is not None:
+            out["config"]["c5_error"] = c5_error[:120]
+            out["c5_error"] = c5_error
         if c5_out is not None:
             out["c5"] = c5_out
             out["config"].update({"c5_instances_per_s": c5_out["instances_per_s"], "c5_instances": c5_out["instances"], "c5_model_bcast_ms": c5_out["model_bcast_ms"],
@@ -508,8 +532,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(orc, src_np, model[:, :3].cpu().numpy(), model[:, 3:6].cpu().numpy(), corr_np, T0, icp_thr, voxel, args.cpu_budget_s)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         print(json.dumps(out))
+        sys.stdout.flush()
+    if c5_hung:
+        os._exit(0)        # a thread of this process is still inside a collective: no orderly shutdown is possible, and the line is out
     ctx.close()
     if distributed:
+        if c5_error is not None:
+            os._exit(0)    # (a communicator of this process may be in an undefined state: leave without the orderly shutdown; the line is out)
         dist.destroy_process_group()
 
 

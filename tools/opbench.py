@@ -232,6 +232,15 @@ def voxel_image_order(ctx, tdv, synth, torch, dev, reps=5):
                                                                              "same voxels as the table path: %s" % (B, n, v, ctx.last_voxel_grouping(), same), ms=wall, kernels_ms=kms,
                         us_per_instance=wall * 1e3 / B, note="what tdv_register_batch_dev runs for its instances (their clouds come from its own unprojection); frac from the kernels' time"),
                    12.0 * B * n + 12.0 * v, kms))
+    d_o1 = torch.empty_like(d_one); off1 = np.array([0, n], np.int32)
+
+    def g1():
+        voff[0] = ctx.voxel_downsample_batch_dev(d_one.data_ptr(), off1, voxel, d_o1.data_ptr(), pinhole=(bb.F, bb.F, bb.CX, bb.CY))
+    wall, kms, _ = kernel_ms(ctx, tdv.TIMER_VOXEL, g1, torch, reps=reps, warm=2)
+    same = bool(torch.equal(d_o1[:m[0]], d_out[:m[0]])) and int(voff[0][-1]) == m[0]
+    out.append(hbm(dict(op="voxel_downsample_pixel_windows_one_cloud", workload="one instance cloud of %d points with its intrinsics -> %d voxels, grouped through pixel windows (%s); same voxels as "
+                                                                                 "voxel_downsample: %s" % (n, m[0], ctx.last_voxel_grouping(), same), ms=wall, kernels_ms=kms,
+                        note="tdv_voxel_downsample_batch_pinhole_dev with one cloud: 45 tiles of 4,096 points - a fifth of the chip; frac from the kernels' time"), 12 * n + 12 * m[0], kms))
     return out
 
 
