@@ -331,7 +331,9 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
 // workgroup is 16 waves (4 per SIMD), so ONE workgroup per CU - 4 waves per SIMD to hide the scalar loads of a loop whose waves walk the
 // same chunks nearly in step.  Capped at the 8-wave budget (80 SGPRs; 43 values spilled to VGPR lanes, all outside the chunk loop) two
 // workgroups share a CU: 1,098 -> 1,211 steps/s of bench.py on the same box, `frac` 0.70 -> 0.78.  Also measured: chunks of 4 points
-// with it (16 spills: 1,209-1,223, within a point of this), chunks of 2 (1,140), 512-thread workgroups (1,177), chunks of 4 without it (1,034).
+// with it (16 spills: 1,209-1,223, within a point of this), chunks of 2 (1,140), 512-thread workgroups (1,177), chunks of 4 without it (1,034);
+// and, at 8 waves, a loop that loads the NEXT pair of points while it computes one (12 SGPRs in flight instead of 48, two waits per chunk
+// instead of one wait on everything): 1,196-1,210 against 1,213-1,221 on one box - with two workgroups per CU the scalar loads are hidden already.
 __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_ransac_score_fast(const ScoreJob a, const ScoreJob b, const int g1, const int h_pad, const float* __restrict__ pq2,
                          const int n_pchunks, const float tau, unsigned long long* __restrict__ rescored) {
