@@ -217,7 +217,7 @@ class Context:
         _check(self._h, lib().tdv_ctx_set_ransac_score(self._h, {"fast": 0, "exact": 1, "matrix": 2}[mode]), "tdv_ctx_set_ransac_score")
 
     def last_ransac_rescore(self):
-        """Fraction of (wave, 8-point chunk) pairs the last RANSAC call scored a second time exactly (-1 in 'exact' mode)."""
+        """Fraction of the (hypothesis, point) tests the last RANSAC call scored a second time exactly (-1 in 'exact' mode)."""
         return float(lib().tdv_ctx_last_ransac_rescore(self._h))
 
     def last_ransac_scored(self):

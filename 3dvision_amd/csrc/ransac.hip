@@ -245,7 +245,7 @@ struct ScoreJob {
     int ps;      // A: point ranges
 };
 // One block of hypotheses (lane = hypothesis `base`, -1: none) over the chunks [c0, c1) of the point pairs; returns the lane's
-// inlier count, adds the chunks the wave scored twice to n_rescored (wave-uniform).
+// inlier count, adds the point PAIRS the wave scored twice to n_rescored (wave-uniform; RS_PCH / 2 per chunk that was re-scored whole).
 // (A finer band test - per PAIR of points instead of per chunk of eight - was built for the batch's small clouds, half of whose
 // hypotheses are decent, so that some of a wave's 512 tests per chunk nearly always sit at the threshold and 49 % of the chunks are
 // re-scored (k_rb_score, C5): the share stayed at 49 % and the pass got slower, 2.52 against 2.30 ms.  Removed in round 4.)
@@ -263,7 +263,7 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
     int cnt = 0;
     int c_fast_end = c1;         // ADAPT: where the FMA pass gives up (wave-uniform)
     for (int c = c0; c < c_fast_end; ++c) {
-        if (ADAPT && c == c0 + 8 && n_rescored >= 3u) { c_fast_end = c; break; }
+        if (ADAPT && c == c0 + 8 && n_rescored >= 3u * (RS_PCH / 2)) { c_fast_end = c; break; }      // (n_rescored counts pairs: three whole chunks)
         const float* __restrict__ g = pq2 + (size_t)c * (6 * RS_PCH);  // RS_PCH points = RS_PCH/2 records of 12 floats, wave-uniform
         float v[6 * RS_PCH];
 #pragma unroll
@@ -271,6 +271,7 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
         float m = INFINITY;      // smallest |d2_fma - mid| of this lane in the chunk
         unsigned sgn = 0u;       // the signs of d2_fma - mid, shifted in one per test (1 = below mid = inlier)
         int cf = 0;
+        v2f tt[RS_PCH / 2];      // d2_fma - mid of every test, kept for the re-scoring branch (which pairs are inside a band)
 #pragma unroll
         for (int p = 0; p < RS_PCH / 2; ++p) {
             const v2f px = {v[12 * p + 0], v[12 * p + 1]}, py = {v[12 * p + 2], v[12 * p + 3]}, pz = {v[12 * p + 4], v[12 * p + 5]};
@@ -281,16 +282,20 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
             // d2_fma - mid as one chain ending in -mid: its own rounding, at most 3 u mid = 1.5 u s in distance, sits inside
             // the 3.7 u A + 4 u s that the band's E keeps in reserve over the proven bound
             const v2f t = fma2(dx, dx, fma2(dy, dy, fma2(dz, dz, nmid)));
+            tt[p] = t;
             m = fminf(fminf(m, fabsf(t.x)), fabsf(t.y));            // one v_min3_f32; a NaN (invalid hypothesis) leaves m alone: half is NaN there
             sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.x), 31);      // sgn = sgn << 1 | sign(t.x)
             sgn = __builtin_amdgcn_alignbit(sgn, __float_as_uint(t.y), 31);
         }
         cf = __popc(sgn);
-        if (__any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides this chunk
-            ++n_rescored;
-            cf = 0;
+        if (__any(!(m >= half))) {      // some lane of the wave is inside its band (or has none): the reference arithmetic decides
+            // ... the PAIRS of points that some lane has inside its band (round 4; until then the whole chunk: a hit is nearly always one
+            // (lane, point), so three quarters of the second scoring were spent on pairs nobody doubted).  n_rescored counts pairs.
 #pragma unroll
             for (int p = 0; p < RS_PCH / 2; ++p) {
+                const float mp = fminf(fminf(INFINITY, fabsf(tt[p].x)), fabsf(tt[p].y));       // (NaN - an invalid hypothesis - leaves INFINITY)
+                if (!ADAPT && !__any(!(mp >= half))) continue;                                 // (the small-cloud pass keeps re-scoring whole chunks: its ADAPT rule counts them)
+                ++n_rescored;
                 const v2f px = {v[12 * p + 0], v[12 * p + 1]}, py = {v[12 * p + 2], v[12 * p + 3]}, pz = {v[12 * p + 4], v[12 * p + 5]};
                 const v2f qx = {v[12 * p + 6], v[12 * p + 7]}, qy = {v[12 * p + 8], v[12 * p + 9]}, qz = {v[12 * p + 10], v[12 * p + 11]};
                 const v2f x = (r[0] * px + (r[3] * py + r[6] * pz)) + r[9];
@@ -298,6 +303,8 @@ __device__ __forceinline__ int score_range_fast(const float* __restrict__ hyp, c
                 const v2f z = (r[2] * px + (r[5] * py + r[8] * pz)) + r[11];
                 const v2f dx = x - qx, dy = y - qy, dz = z - qz;
                 const v2f d2 = dx * dx + (dy * dy + dz * dz);
+                // the pair's two sign bits in sgn: test 2p at bit RS_PCH - 1 - 2p, test 2p + 1 right below it
+                cf -= __popc((sgn >> (RS_PCH - 2 - 2 * p)) & 3u);
                 cf += (d2.x < tau) ? 1 : 0;
                 cf += (d2.y < tau) ? 1 : 0;
             }
@@ -929,7 +936,7 @@ int ransac_run_dev(tdv_ctx* ctx, const float* d_src, int ns, const float* d_tgt,
     // bail-out leaves chunks out), and the scored share of all pairs
     auto stats = [&](const unsigned long long* r) {
         const double scored = r[1] ? (double)r[1] : wave_chunks;
-        ctx->last_ransac_rescore = (double)r[0] / scored;
+        ctx->last_ransac_rescore = (double)r[0] / (scored * (score_mfma ? 1.0 : (double)(RS_PCH / 2)));      // the FMA kernel counts point pairs scored twice, the matrix-core study kernel chunks
         ctx->last_ransac_scored = scored / wave_chunks;
     };
     for (int q = 0; q < 2; ++q) event_release(ctx, ev[q]);
@@ -1197,7 +1204,7 @@ int ransac_small_batch_dev(tdv_ctx* ctx, const float* d_src, const int* h_off, c
     TDV_HIP(ctx, hipStreamSynchronize(s));
     {
         const unsigned long long* st = reinterpret_cast<const unsigned long long*>(h_flags + 4);
-        ctx->last_ransac_rescore = st[1] ? (double)st[0] / (double)st[1] : 0.0; ctx->last_ransac_scored = 1.0;
+        ctx->last_ransac_rescore = st[1] ? (double)st[0] / ((double)st[1] * (RS_PCH / 2)) : 0.0; ctx->last_ransac_scored = 1.0;      // (pairs scored twice / pairs scored)
     }
     if (h_flags[0]) { std::snprintf(ctx->err, sizeof(ctx->err), "ransac: a correspondence index lies outside [0, %d)", nt); return TDV_ERR_BAD_ARG; }
     if (h_flags[1]) { *fell_back = 1; return TDV_OK; }

@@ -271,7 +271,7 @@ def main():
     ctx.icp_dev(d_src.data_ptr(), n, d_tgt.data_ptr(), d_nrm.data_ptr(), n, T0, icp_thr, args.steps, True, fixed_iterations=True)
     nn_ms, nn_launches = ctx.timing_read(tdv.TIMER_ICP_NN)
     ctx.timing_enable(False)
-    rescore_share = ctx.last_ransac_rescore()  # fast scoring pass: share of (wave, chunk) pairs scored a second time exactly; -1: exact mode
+    rescore_share = ctx.last_ransac_rescore()  # fast scoring pass: share of the tests scored a second time exactly (whole waves on a pair of points); -1: exact mode
     scored_share = ctx.last_ransac_scored()    # share of the (hypothesis, point) tests evaluated at all (exact bail-out: DESIGN.md 4)
 
     times = torch.tensor([elapsed, t_icp, t_rs], dtype=torch.float64, device=cdev)
@@ -382,7 +382,8 @@ def main():
         # Scoring kernel of the timed region.  Reference arithmetic (k_ransac_score): per hypothesis-point 18 ops transform +
         # 3 sub + 5 squared norm + 1 compare + 1 count = 28 VALU lane-ops (issued as packed f32 pairs).  Default
         # (k_ransac_score_fast): 16.6 lane-ops per hypothesis-point in the FMA pass (per 8 points 60 packed instructions -
-        # 48 fma, 12 add - and 13 scalar-f32 ones) + 28 for every (wave, chunk) pair scored again exactly
+        # 48 fma, 12 add - and 13 scalar-f32 ones) + 28 for every test scored again exactly: a wave re-scores the PAIR of points that
+        # one of its 64 hypotheses has inside its rounding band (round 4; the whole 8-point chunk until then)
         # (rescore_share, counted by the kernel).  An FMA is ONE lane-op here, as in the peak (lane-instructions, not flops).
         # Algorithmic HBM bytes per launch: the packed pairs once (24 B per point) + 48 B per hypothesis in, 4 B out.
         # A "launch" is one dispatch of the scoring kernel (what rocprofv3's kernel statistics average over).  With the exact
@@ -401,8 +402,8 @@ def main():
         score = {
             "kernel": sc_kernel, "bound": "valu_f32",
             "achieved": sc_tops, "peak": VALU_PEAK_TOPS,
-            "unit": ("T VALU lane-ops/s executed: %.1f per hypothesis-point = 16.6 in the FMA pass + 28 x the %.3f of the (wave, chunk) pairs "
-                     "scored again with the reference arithmetic; same inlier counts as the 28-op reference arithmetic" % (ops_per_test, rescore_share))
+            "unit": ("T VALU lane-ops/s executed: %.1f per hypothesis-point = 16.6 in the FMA pass + 28 x the %.3f of the tests (whole waves on a pair of "
+                     "points) scored again with the reference arithmetic; same inlier counts as the 28-op reference arithmetic" % (ops_per_test, rescore_share))
                     if fast else "Tops/s (f32 VALU, FMA contraction forbidden by parity; 28 ops per hypothesis-point)",
             "frac": sc_tops / VALU_PEAK_TOPS, "avg_launch_ms": sc_avg_ms, "launches": sc_launches,
             "hyps_per_launch": sc_hyps_per_launch, "batches": sc_batches, "total_ms": sc_ms,

@@ -89,8 +89,9 @@ int tdv_ctx_set_icp_accumulation(tdv_ctx* ctx, int mode);
                                    * matrix cores (f32 MFMA), same band scheme, same counts; measured slower than FAST.  The product
                                    * library returns TDV_ERR_BAD_ARG for it */
 int tdv_ctx_set_ransac_score(tdv_ctx* ctx, int mode);
-/* Statistics of the last tdv_ransac* call on this ctx: the fraction of (wave, 8-point chunk) pairs the FAST pass scored a
- * second time with the reference arithmetic (-1 if the call ran in EXACT mode or none has run). */
+/* Statistics of the last tdv_ransac* call on this ctx: the fraction of the (hypothesis, point) tests the FAST pass scored a second time
+ * with the reference arithmetic - whole waves of 64 hypotheses on a pair of points that one of them has inside its rounding band
+ * (until round 4: on the whole 8-point chunk) - (-1 if the call ran in EXACT mode or none has run). */
 double tdv_ctx_last_ransac_rescore(tdv_ctx* ctx);
 /* The share of the (hypothesis, point) tests the last tdv_ransac* call on this ctx evaluated.  Below 1 when the call ran without
  * a per-iteration trace: a hypothesis whose count over a prefix of the points plus ALL remaining points cannot exceed the best
