@@ -23,6 +23,7 @@ ordinary row-major ``[4,4]`` numpy arrays at this level; the column-major ``floa
 """
 import ctypes as C
 import os
+import sys
 import threading
 from dataclasses import dataclass, field
 from typing import Optional
@@ -107,6 +108,14 @@ def lib():
             if not os.path.exists(LIB_PATH):
                 raise TdvError("lib3dvision_hip.so is not built (%s). Run `python 3dvision_amd/build.py` or "
                                "__graft_entry__.build(); there is no CPU fallback." % LIB_PATH)
+            # A process that will also use torch must load torch FIRST: its wheel brings its own copy of the HIP runtime, and once the system's
+            # copy (this library's dependency) has initialised the device, torch's reports "No HIP GPUs are available".  The harness around
+            # this package (tests, bench.py, tools) always uses torch for device buffers, so it is imported here when it is installed.
+            if "torch" not in sys.modules:
+                try:
+                    import torch  # noqa: F401
+                except ImportError:
+                    pass
             l = C.CDLL(LIB_PATH)
             l.tdv_status_string.restype = C.c_char_p
             l.tdv_last_error.restype = C.c_char_p

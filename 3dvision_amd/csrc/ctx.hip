@@ -195,7 +195,9 @@ int tdv_ctx_create(int device, tdv_ctx** out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return TDV_ERR_NO_DEVICE; }
     c->own_stream = true;
     // one persistent device word: the "last workgroup" ticket of the scans (reset by the kernel that uses it)
-    if (hipMalloc((void**)&c->scan_ticket, 64) != hipSuccess || hipMemset(c->scan_ticket, 0, 64) != hipSuccess) {
+    // (cleared on the ctx's own stream and waited for: a null-stream memset is not ordered against a non-blocking stream)
+    if (hipMalloc((void**)&c->scan_ticket, 64) != hipSuccess || hipMemsetAsync(c->scan_ticket, 0, 64, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->stream); delete c; return TDV_ERR_OOM;
     }
     if (const char* e = getenv("TDV_ICP_SEARCH")) {

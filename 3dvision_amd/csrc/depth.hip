@@ -1020,7 +1020,7 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
             ctx->chain_status = nullptr; ctx->chain_cap = 0;
             const size_t cap = std::max<size_t>((size_t)tiles, 4096);
             TDV_HIP(ctx, hipMalloc((void**)&ctx->chain_status, cap * sizeof(unsigned long long)));
-            TDV_HIP(ctx, hipMemset(ctx->chain_status, 0, cap * sizeof(unsigned long long)));
+            TDV_HIP(ctx, hipMemsetAsync(ctx->chain_status, 0, cap * sizeof(unsigned long long), s));     // on the ctx's stream: ordered before the kernel (the stream is non-blocking - a null-stream memset would not be)
             ctx->chain_cap = cap; ctx->chain_epoch = 0;
         }
         const unsigned epoch = ++ctx->chain_epoch;
@@ -1041,7 +1041,7 @@ int depth_to_cloud_dev(tdv_ctx* ctx, const uint16_t* d_raw, const float* d_depth
         const hipError_t se = le == hipSuccess ? hipStreamSynchronize(s) : le;
         if (se != hipSuccess || h_total[1] != 0 || h_total[0] < 0) {
             // the ticket word and the host's base may no longer agree (a launch that did not run): start over
-            (void)hipMemset(ctx->scan_ticket + 8, 0, 4); ctx->chain_ticket_base = 0;
+            (void)hipMemsetAsync(ctx->scan_ticket + 8, 0, 4, s); (void)hipStreamSynchronize(s); ctx->chain_ticket_base = 0;
             if (se != hipSuccess) return set_err(ctx, se, "k_depth_cloud_chain", __LINE__);
             snprintf(ctx->err, sizeof(ctx->err), "%s", h_total[1] ? "depth_to_cloud: the chained scan gave up waiting for a tile" : "depth_to_cloud: the count did not reach the host");
             return TDV_ERR_INTERNAL;

@@ -4,6 +4,11 @@ import sys
 
 import pytest
 
+try:                      # torch BEFORE the HIP library: torch brings its own copy of the HIP runtime, and a process that has initialised the
+    import torch          # system's copy first (tdv_ctx_create) makes torch's report "No HIP GPUs are available" - whatever the test order
+except ImportError:       # (a test file that only imported torch inside a function failed when it was run on its own)
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
