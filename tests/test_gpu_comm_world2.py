@@ -40,7 +40,9 @@ def _statuses(case):
 
 def test_the_collectives_went_through_the_stand_in(world2):
     s = world2["shim"]
-    assert s["calls"] >= 40 and s["timeouts"] == 0 and s["mismatches"] == 0 and not s["rccl_loaded"]
+    # (every collective of every case is counted by the stand-in itself: that they went through it is what `calls` shows.  librccl may be
+    #  mapped all the same - the package loads torch before the HIP library, and torch brings RCCL along)
+    assert s["calls"] >= 40 and s["timeouts"] == 0 and s["mismatches"] == 0
 
 
 @pytest.mark.parametrize("case", ["happy", "root1", "happy_again"])
